@@ -1,0 +1,160 @@
+/* pevae_hip.h -- C ABI of libpevae_hip.so: the MI355X (gfx950) kernels behind the DLS_VAE training step.
+ *
+ * The reference (oklen/PEVAE) has no FFI of its own: its hot path is Python nn.Modules calling PyTorch
+ * (cuDNN / cuBLAS / ATen).  Every entry point below therefore cites the reference call site whose vendor
+ * kernel it replaces (file:line into /root/reference).  Conventions:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked host;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - return 0 on success, <0 on error (PV_ERR_*); pv_last_error() gives the message (thread local);
+ *   - no hidden allocations: every scratch buffer is a caller-provided workspace whose size comes from the
+ *     matching *_bytes() query, so all entry points can be captured into HIP graphs;
+ *   - bf16 buffers are raw uint16 bits; "ld" = leading dimension in ELEMENTS.
+ */
+#ifndef PEVAE_HIP_H
+#define PEVAE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PV_ABI_VERSION 1
+
+const char* pv_last_error(void);
+int pv_abi_version(void);
+/* host out-params: number of CUs, LDS bytes per CU, gcnArchName copied into arch[arch_len] */
+int pv_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ---- bf16 MFMA GEMM core -------------------------------------------------------------------------------
+ * C[M,N] = A[M,K] B[N,K]^T (+bias[N]); A,B bf16 row-major, K % 64 == 0 (zero padded), lda/ldb % 8 == 0,
+ * 16-byte aligned.  Writes fp32 C and/or bf16 Cb.  Replaces the cuBLAS GEMMs inside nn.GRU's input
+ * projection (models/enc2dec/base_modules.py:42) and the weight/data-gradient GEMMs of nn.Linear backward
+ * for `project` (models/enc2dec/decoders.py:162). */
+int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                    float* C, int ldc, void* Cb, int ldcb, void* stream);
+
+/* ---- fused vocabulary projection + log-softmax + NLL -----------------------------------------------------
+ * Forward: logits = (h W^T + bias) * inv_temp are produced tile-wise by the MFMA GEMM and reduced on the fly
+ * to per-token lse[t] and nll[t] = lse - logit[target] (0 where target == ignore_index); the [T,V] log-prob
+ * tensor is never written.  Replaces decoders.py:191-193 (Linear + /temperature + log_softmax) fused with
+ * criterions.py:55-64 (NLLLoss sum) and criterions.py:133-138 (Perplexity's token mean).
+ * h [T][ldh] bf16, W [V][ldw] bf16, H % 64 == 0. */
+size_t pv_vocab_nll_fwd_ws_bytes(int T, int V);
+int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float* bias, const int64_t* target,
+                     int T, int V, int H, float inv_temp, int64_t ignore_index, void* workspace, float* lse,
+                     float* nll, void* stream);
+/* Backward, stage 1: recompute the logits tile-wise and emit P = (softmax - onehot(target)) * gscale[t] *
+ * inv_temp as bf16, both as P [round_up(T,64)][ldp] and P^T [round_up(V,64)][ldpt], plus
+ * dbias[v] = sum_t P[t,v].  Stage 2 is two pv_gemm_bf16_nt calls: dH = P (W^T)^T and dW = P^T (h^T)^T.
+ * dbias_part: [round_up(T,64)/64][ldp] floats of scratch. */
+int pv_vocab_nll_bwd_prob(const void* h, int ldh, const void* W, int ldw, const float* bias,
+                          const int64_t* target, const float* lse, const float* gscale, int T, int V, int H,
+                          float inv_temp, void* P, int ldp, void* PT, int ldpt, float* dbias_part, float* dbias,
+                          void* stream);
+/* Dense [T][V] fp32 log-probs for callers that need the reference's DecoderRNN return value as a tensor
+ * (decoders.py:193,292); needs lse from pv_vocab_nll_fwd. */
+int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const float* bias, const float* lse,
+                           int T, int V, int H, float inv_temp, float* out, void* stream);
+/* Backward of the dense path: P = (dlogp - exp(logp) * rowsum(dlogp)) * inv_temp as bf16 [T][ldp] (+ dbias). */
+int pv_logsoftmax_bwd_bf16(const float* logp, const float* dlogp, int T, int V, float inv_temp, void* P, int ldp,
+                           float* dbias, void* stream);
+
+/* ---- persistent GRU recurrence ---------------------------------------------------------------------------
+ * torch.nn.GRU semantics (gate order r,z,n) as used at encoders.py:59-62 and decoders.py:182.
+ * xproj [L][Bpad][3H] fp32 = W_ih x + b_ih (time-major; from pv_gemm_bf16_nt); whh_bf16 [3H][Hk];
+ * hseq_bf16 [(L+1)][Bpad][Hk] scratch (bf16 states, slot i = state before processing step i);
+ * out (optional) is written as out[b*out_sb + t*out_st + u]; gsave (optional, training) [L][Bpad][4][H];
+ * hall (optional, training) [(L+1)][Bpad][H]; hn [B][H]; sync: pv_gru_sync_bytes(B) bytes, word NG = error flag
+ * (1 = a bounded spin timed out).  reverse != 0 walks time backwards (bidirectional encoders).
+ * max_wgs <= 0 means "one workgroup per CU of the current device". */
+int pv_gru_geometry(int B, int H, int* Hk, int* K3, int* Bpad, int* NG);   /* host out-params */
+size_t pv_gru_sync_bytes(int B);
+int pv_gru_fwd(const float* xproj, const void* whh_bf16, const float* bhh, const float* h0, int L, int B, int H,
+               int reverse, float* out, long out_sb, long out_st, void* hseq_bf16, float* gsave, float* hall,
+               float* hn, void* sync, int max_wgs, void* stream);
+/* Backward through time.  whhT_bf16 [H][K3] = W_hh^T.  Emits dgi_bf16 / dgh_bf16 [L][Bpad][K3] (gate
+ * gradients w.r.t. the input / hidden pre-activations; GEMM operands for dW_ih, dx, dW_hh), dh0 [B][H],
+ * db_ih / db_hh [3H].  dbias_part: NG*4*H floats of scratch. */
+int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsave,
+               const float* hall, const void* whhT_bf16, int L, int B, int H, int reverse, void* dgi_bf16,
+               void* dgh_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
+               int max_wgs, void* stream);
+
+/* ---- embedding gather / sorted scatter-add -----------------------------------------------------------------
+ * Occurrence r = i0*n1 + i1 reads ids[i0*s0 + i1*s1] and is row i0*n1p + i1 of the output (n1p >= n1).  Replaces nn.Embedding forward at
+ * dialog_models.py:758-765 / decoders.py:174 and embedding_dense_backward (atomic on GPU) with a stable
+ * radix sort + per-row segmented sum (no atomics, bitwise reproducible). */
+int pv_embedding_gather(const float* table, long num_rows, int D, const int64_t* ids, int n, int n1, int n1p,
+                        long s0, long s1, float* out, int ldo, void* out_bf16, int ldb, int* oob_counter,
+                        void* stream);
+size_t pv_embedding_bwd_ws_bytes(int n);
+int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n, int n1, int n1p, long s0, long s1,
+                     long num_rows, int D, long padding_idx, int accumulate, float* dtable, void* workspace,
+                     size_t ws_bytes, void* stream);
+
+/* ---- layout helpers ------------------------------------------------------------------------------------------ */
+/* dst[(i0*n1p + i1)*ldd + c] = bf16(src[i0*s0 + i1*s1 + c*sc]) for c < C, 0 for C <= c < ldd */
+int pv_cast_pack_bf16(const float* src, int n0, int n1, int n1p, int C, long s0, long s1, long sc, void* dst,
+                      int ldd, void* stream);
+int pv_transpose_to_bf16(const void* src, int src_is_f32, int R, int C, long lds, void* dst, long ldd, int Rpad,
+                         void* stream);
+int pv_colsum_f32(const float* X, int R, long ld, int n, float* out, int accumulate, void* stream);
+/* out2[0] = sum of x[i] over i with mask[i] != ignore (all i when mask == NULL), out2[1] = their count */
+int pv_masked_sum(const float* x, const int64_t* mask, int64_t ignore, long n, float* out2, void* stream);
+/* dense-input NLL (criterions.py:57-63 on a materialised log-prob tensor): out[t] = -logp[t][target[t]] */
+int pv_pick_nll_fwd(const float* logp, const int64_t* target, int64_t ignore, int T, int V, float* out,
+                    void* stream);
+int pv_pick_nll_bwd(const float* dout, const int64_t* target, int64_t ignore, int T, int V, float* dlogp,
+                    void* stream);
+
+/* ---- latent connectors: fused reparameterisation + KL, Gumbel-softmax, categorical KL ------------------------
+ * mode 0: NormKLLoss (criterions.py:145-155, logvar = log sigma^2); mode 1: gaussian_analytical_kl
+ * (dialog_models.py:3215-3217, inputs log sigma).  z = mu_q + exp(lv_q) * eps (dialog_models.py:191-203,
+ * :323-325, :3206-3207); eps == NULL gives z = mu_q (eval). */
+int pv_reparam_kl_fwd(const float* mu_q, const float* lv_q, const float* mu_p, const float* lv_p, const float* eps,
+                      int B, int Z, int mode, float* z, float* kl_row, void* stream);
+int pv_reparam_kl_bwd(const float* mu_q, const float* lv_q, const float* mu_p, const float* lv_p, const float* eps,
+                      const float* dz, const float* dkl_row, int B, int Z, int mode, float* dmu_q, float* dlv_q,
+                      float* dmu_p, float* dlv_p, void* stream);
+/* nn_lib.py:226-265 with the uniform draw `u` supplied by the caller. */
+int pv_gumbel_softmax_fwd(const float* logits, const float* u, int rows, int k, float tau, int hard, float* y_soft,
+                          float* y, int64_t* ids, void* stream);
+int pv_softmax_bwd_rows(const float* y_soft, const float* dy, int rows, int k, float scale, float* dlogits,
+                        void* stream);
+/* criterions.py:161-175 (mode 0) and :200-211 (mode 1): per-row sums. */
+int pv_cat_rows_fwd(const float* log_q, const float* log_p, long log_p_numel, int rows, int k, int mode, float* out,
+                    void* stream);
+int pv_cat_rows_bwd(const float* log_q, const float* log_p, long log_p_numel, const float* drow, int rows, int k,
+                    int mode, float* dlog_q, float* dlog_p, void* stream);
+
+/* ---- small exact-fp32 strided GEMM (Hidden2Gaussian nn_lib.py:198-199, LinearConnector nn_lib.py:143, Block
+ * dialog_models.py:258-263, attention bmm decoders.py:85-107) ------------------------------------------------- */
+int pv_linear_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias,
+                  float* C, long ldc, int M, int N, int K, float alpha, int accumulate, int batch, long bsa,
+                  long bsb, long bsc, void* stream);
+
+/* ---- decoder attention (decoders.py:89-118): fused additive scores, row softmax, tanh / GELU ---------------------
+ * score[b,i,j] = qw . tanh(k[b,j,:] + q[b,i,:]) + qb without the [B,Lo,Li,D] intermediate of decoders.py:92-94.
+ * dqw_part: B*Lo*D floats of scratch. */
+int pv_additive_scores_fwd(const float* q, const float* k, const float* qw, const float* qb, int B, int Lo, int Li,
+                           int D, float* score, void* stream);
+int pv_additive_scores_bwd(const float* q, const float* k, const float* qw, const float* dscore, int B, int Lo,
+                           int Li, int D, float* dq, float* dk, float* dqw_part, float* dqw, void* stream);
+int pv_softmax_rows(const float* x, int rows, int n, float* y, void* stream);
+int pv_softmax_rows_bwd(const float* y, const float* dy, int rows, int n, float* dx, void* stream);
+/* op 0: tanh(a); 1: b*(1-a^2) (a = tanh output); 2: gelu(a) (erf form, dialog_models.py:266-269); 3: b*gelu'(a) */
+int pv_unary_f32(const float* a, const float* b, long n, int op, float* out, void* stream);
+
+/* ---- clip + skip guards + Adam over one flat buffer (main_pretrain.py:207-225,268-269;
+ * dialog_models.py:122-131) ------------------------------------------------------------------------------------ */
+size_t pv_optim_state_bytes(void);
+int pv_grad_guard(const float* grads, long n, void* state, float max_norm, float lr, int warmup_steps, float beta1,
+                  float beta2, int guards, void* stream);
+int pv_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, const void* state,
+                 float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEVAE_HIP_H */

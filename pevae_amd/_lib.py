@@ -1,0 +1,91 @@
+"""ctypes binding of libpevae_hip.so (the C ABI declared in include/pevae_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or fails to load, importing the kernels raises.
+`python __graft_entry__.py` (or `make -C pevae_amd/csrc`) builds it in-tree with hipcc for gfx950.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpevae_hip.so")
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+lng = C.c_long
+
+# name -> (restype, argtypes); mirrors include/pevae_hip.h one-to-one (tests/test_abi.py checks that)
+SIGNATURES = {
+    "pv_last_error": (C.c_char_p, []),
+    "pv_abi_version": (i32, []),
+    "pv_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
+    "pv_gemm_bf16_nt": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
+    "pv_vocab_nll_fwd_ws_bytes": (sz, [i32, i32]),
+    "pv_vocab_nll_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i64, vp, vp, vp, vp]),
+    "pv_vocab_nll_bwd_prob": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, i32, vp, i32, vp, vp, vp]),
+    "pv_vocab_logprob_dense": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, vp, vp]),
+    "pv_logsoftmax_bwd_bf16": (i32, [vp, vp, i32, i32, f32, vp, i32, vp, vp]),
+    "pv_gru_geometry": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "pv_gru_sync_bytes": (sz, [i32]),
+    "pv_gru_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, lng, lng, vp, vp, vp, vp, vp, i32, vp]),
+    "pv_gru_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "pv_embedding_gather": (i32, [vp, lng, i32, vp, i32, i32, i32, lng, lng, vp, i32, vp, i32, vp, vp]),
+    "pv_embedding_bwd_ws_bytes": (sz, [i32]),
+    "pv_embedding_bwd": (i32, [vp, i32, vp, i32, i32, i32, lng, lng, lng, i32, lng, i32, vp, vp, sz, vp]),
+    "pv_cast_pack_bf16": (i32, [vp, i32, i32, i32, i32, lng, lng, lng, vp, i32, vp]),
+    "pv_transpose_to_bf16": (i32, [vp, i32, i32, i32, lng, vp, lng, i32, vp]),
+    "pv_colsum_f32": (i32, [vp, i32, lng, i32, vp, i32, vp]),
+    "pv_masked_sum": (i32, [vp, vp, i64, lng, vp, vp]),
+    "pv_pick_nll_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "pv_pick_nll_bwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "pv_reparam_kl_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "pv_reparam_kl_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "pv_gumbel_softmax_fwd": (i32, [vp, vp, i32, i32, f32, i32, vp, vp, vp, vp]),
+    "pv_softmax_bwd_rows": (i32, [vp, vp, i32, i32, f32, vp, vp]),
+    "pv_cat_rows_fwd": (i32, [vp, vp, lng, i32, i32, i32, vp, vp]),
+    "pv_cat_rows_bwd": (i32, [vp, vp, lng, vp, i32, i32, i32, vp, vp, vp]),
+    "pv_linear_f32": (i32, [vp, lng, lng, vp, lng, lng, vp, vp, lng, i32, i32, i32, f32, i32, i32, lng, lng, lng, vp]),
+    "pv_additive_scores_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "pv_additive_scores_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "pv_softmax_rows": (i32, [vp, i32, i32, vp, vp]),
+    "pv_softmax_rows_bwd": (i32, [vp, vp, i32, i32, vp, vp]),
+    "pv_unary_f32": (i32, [vp, vp, lng, i32, vp, vp]),
+    "pv_optim_state_bytes": (sz, []),
+    "pv_grad_guard": (i32, [vp, lng, vp, f32, f32, i32, f32, f32, i32, vp]),
+    "pv_adam_step": (i32, [vp, vp, vp, vp, lng, vp, f32, f32, f32, vp]),
+}
+
+_lib = None
+
+
+class PevaeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (once) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pevae_amd: %s is missing -- build the HIP kernels first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C pevae_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pv_abi_version() != 1:
+        raise ImportError("pevae_amd: ABI version mismatch in %s" % LIB_PATH)
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().pv_last_error().decode("utf-8", "replace")
+        raise PevaeHipError("%s failed (code %d): %s" % (what or "libpevae_hip call", rc, msg))
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

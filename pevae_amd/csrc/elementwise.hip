@@ -1,0 +1,424 @@
+// Fused elementwise / row-reduce passes of the DLS_VAE step for gfx950 (HBM-bound, one pass each):
+//   * layout helpers: fp32 -> bf16 cast-and-pack (K zero-padded), LDS-tiled transposes
+//   * reparameterisation + Gaussian KL, forward and backward   (dialog_models.py:191-203, :323-325,
+//     :3206-3207; criterions.py:145-155; dialog_models.py:3215-3221)
+//   * Gumbel-softmax with straight-through one-hot              (nn_lib.py:226-265)
+//   * categorical KL / entropy rows                             (criterions.py:157-175, :196-211)
+//   * masked sum (loss assembly), dense log-softmax backward
+#include "common.h"
+#include "../../include/pevae_hip.h"
+
+namespace {
+
+// dst[(i0*n1p+i1)*ldd + c] = bf16(src[i0*s0 + i1*s1 + c*sc]), c < C; zero for C <= c < ldd  (i1 < n1 <= n1p)
+__global__ void cast_pack_kernel(const float* __restrict__ src, int n0, int n1, int n1p, int C, long s0, long s1,
+                                 long sc, bf16_t* __restrict__ dst, int ldd) {
+  const long total = (long)n0 * n1 * ldd;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldd);
+    const long r = i / ldd;
+    const int i1 = (int)(r % n1);
+    const long i0 = r / n1;
+    dst[(i0 * n1p + i1) * ldd + c] = c < C ? f2bf(src[i0 * s0 + i1 * s1 + c * sc]) : (bf16_t)0;
+  }
+}
+
+// dst[c*ldd + r] = bf16(src[r*lds + c]) for r < R, c < C; dst columns R..Rpad zero-filled.  64x64 LDS tiles.
+template <typename TS>
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restrict__ src, int R, int C, long lds_,
+                                                              bf16_t* __restrict__ dst, long ldd, int Rpad) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    bf16_t v = 0;
+    if (r < R && c < C) {
+      if constexpr (sizeof(TS) == 4) v = f2bf((float)src[(size_t)r * lds_ + c]);
+      else v = (bf16_t)src[(size_t)r * lds_ + c];
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < Rpad) dst[(size_t)c * ldd + r] = tile[tx][i];
+  }
+}
+
+// mode 0: logvar = log sigma^2 (NormKLLoss);  mode 1: inputs are log sigma (gaussian_analytical_kl).
+// z = mu_q + exp(lv_q) * eps in both (the reference's std = exp(logvar), dialog_models.py:194).
+__global__ void reparam_kl_fwd_kernel(const float* __restrict__ mq, const float* __restrict__ lq,
+                                      const float* __restrict__ mp, const float* __restrict__ lp,
+                                      const float* __restrict__ eps, int B, int Z, int mode, float* __restrict__ z,
+                                      float* __restrict__ kl_row) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int d = lane; d < Z; d += 64) {
+    const size_t i = (size_t)b * Z + d;
+    const float a = mq[i], la = lq[i];
+    if (z) z[i] = eps ? a + expf(la) * eps[i] : a;
+    if (kl_row) {
+      const float c = mp[i], lc = lp[i];
+      const float diff = c - a;
+      if (mode == 0) acc += 1.f + (la - lc) - diff * diff * expf(-lc) - expf(la - lc);
+      else acc += -0.5f + lc - la + 0.5f * (expf(2.f * la) + diff * diff) * expf(-2.f * lc);
+    }
+  }
+  if (kl_row) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) kl_row[b] = mode == 0 ? -0.5f * acc : acc;
+  }
+}
+
+__global__ void reparam_kl_bwd_kernel(const float* __restrict__ mq, const float* __restrict__ lq,
+                                      const float* __restrict__ mp, const float* __restrict__ lp,
+                                      const float* __restrict__ eps, const float* __restrict__ dz,
+                                      const float* __restrict__ dkl_row, int B, int Z, int mode,
+                                      float* __restrict__ dmq, float* __restrict__ dlq, float* __restrict__ dmp,
+                                      float* __restrict__ dlp) {
+  const long n = (long)B * Z;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / Z);
+    const float a = mq[i], la = lq[i];
+    float gmq = 0.f, glq = 0.f, gmp = 0.f, glp = 0.f;
+    if (dz) {
+      gmq += dz[i];
+      if (eps) glq += dz[i] * expf(la) * eps[i];
+    }
+    if (dkl_row) {
+      const float g = dkl_row[b], c = mp[i], lc = lp[i], diff = c - a;
+      if (mode == 0) {
+        const float ip = expf(-lc), ratio = expf(la - lc);
+        // kl = -0.5 * sum(1 + la - lc - diff^2*ip - ratio)
+        gmq += g * (-0.5f) * (2.f * diff * ip);
+        gmp += g * (-0.5f) * (-2.f * diff * ip);
+        glq += g * (-0.5f) * (1.f - ratio);
+        glp += g * (-0.5f) * (-1.f + diff * diff * ip + ratio);
+      } else {
+        const float ip2 = expf(-2.f * lc), e2a = expf(2.f * la);
+        // kl = sum(-0.5 + lc - la + 0.5*(e2a + diff^2)*ip2)
+        gmq += g * (-diff * ip2);
+        gmp += g * (diff * ip2);
+        glq += g * (-1.f + e2a * ip2);
+        glp += g * (1.f - (e2a + diff * diff) * ip2);
+      }
+    }
+    if (dmq) dmq[i] = gmq;
+    if (dlq) dlq[i] = glq;
+    if (dmp) dmp[i] = gmp;
+    if (dlp) dlp[i] = glp;
+  }
+}
+
+// one thread per row (k is small: 5 in the reference config, <= 64 supported)
+__global__ void gumbel_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ u, int rows, int k,
+                                  float inv_tau, int hard, float* __restrict__ y_soft, float* __restrict__ y,
+                                  int64_t* __restrict__ ids) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* lg = logits + (size_t)r * k;
+  const float* ur = u + (size_t)r * k;
+  float m = -INFINITY;
+  for (int j = 0; j < k; ++j) {
+    const float gn = -logf(-logf(ur[j] + 1e-20f) + 1e-20f);    // nn_lib.py:232
+    m = fmaxf(m, (lg[j] + gn) * inv_tau);
+  }
+  float s = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const float gn = -logf(-logf(ur[j] + 1e-20f) + 1e-20f);
+    s += expf((lg[j] + gn) * inv_tau - m);
+  }
+  int best = 0;
+  float bestv = -1.f;
+  for (int j = 0; j < k; ++j) {
+    const float gn = -logf(-logf(ur[j] + 1e-20f) + 1e-20f);
+    const float p = expf((lg[j] + gn) * inv_tau - m) / s;
+    y_soft[(size_t)r * k + j] = p;
+    if (p > bestv) {           // first maximum, as torch.max
+      bestv = p;
+      best = j;
+    }
+  }
+  if (ids) ids[r] = best;
+  for (int j = 0; j < k; ++j) {
+    const float p = y_soft[(size_t)r * k + j];
+    // straight-through value (onehot - y).detach() + y, evaluated in the reference's order (nn_lib.py:256)
+    y[(size_t)r * k + j] = hard ? ((j == best ? 1.f : 0.f) - p) + p : p;
+  }
+}
+
+__global__ void softmax_bwd_rows_kernel(const float* __restrict__ y_soft, const float* __restrict__ dy, int rows,
+                                        int k, float scale, float* __restrict__ dlogits) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float dot = 0.f;
+  for (int j = 0; j < k; ++j) dot += dy[(size_t)r * k + j] * y_soft[(size_t)r * k + j];
+  for (int j = 0; j < k; ++j)
+    dlogits[(size_t)r * k + j] = scale * y_soft[(size_t)r * k + j] * (dy[(size_t)r * k + j] - dot);
+}
+
+// rows of sum_j q*(log q - log p)  (mode 0, CatKLLoss) or  sum_j -q*log q (mode 1, Entropy);  log_p may be a
+// single broadcast scalar (lp_n == 1: log(1/k), dialog_models.py:3426) or a full [rows,k] matrix.
+__global__ void cat_rows_fwd_kernel(const float* __restrict__ log_q, const float* __restrict__ log_p, long lp_n,
+                                    int rows, int k, int mode, float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const float lq = log_q[(size_t)r * k + j], q = expf(lq);
+    if (mode == 0) s += q * (lq - (lp_n == 1 ? log_p[0] : log_p[(size_t)r * k + j]));
+    else s += -lq * q;
+  }
+  out[r] = s;
+}
+
+__global__ void cat_rows_bwd_kernel(const float* __restrict__ log_q, const float* __restrict__ log_p, long lp_n,
+                                    const float* __restrict__ drow, int rows, int k, int mode,
+                                    float* __restrict__ dlog_q, float* __restrict__ dlog_p) {
+  const long n = (long)rows * k;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float lq = log_q[i], q = expf(lq), g = drow[i / k];
+  if (mode == 0) {
+    const float lp = lp_n == 1 ? log_p[0] : log_p[i];
+    dlog_q[i] = g * q * (lq - lp + 1.f);
+    if (dlog_p) dlog_p[i] = -g * q;
+  } else {
+    dlog_q[i] = -g * q * (lq + 1.f);
+  }
+}
+
+// out[0] = sum_i x[i] * (mask ? mask[i] != ignore : 1),  out[1] = count of unmasked.  Single block, fixed order.
+__global__ __launch_bounds__(1024) void masked_sum_kernel(const float* __restrict__ x, const int64_t* __restrict__ mask,
+                                                           int64_t ignore, long n, float* __restrict__ out) {
+  __shared__ float ss[1024];
+  __shared__ float sc[1024];
+  float s = 0.f, c = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const bool on = !mask || mask[i] != ignore;
+    if (on) {
+      s += x[i];
+      c += 1.f;
+    }
+  }
+  ss[threadIdx.x] = s;
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      ss[threadIdx.x] += ss[threadIdx.x + o];
+      sc[threadIdx.x] += sc[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = ss[0];
+    out[1] = sc[0];
+  }
+}
+
+// backward of a dense log-softmax row: g = (dlogp - exp(logp) * sum(dlogp)) * inv_temp, emitted as bf16 in both
+// P[T][ldp] and (through the caller's transpose) P^T.  One workgroup per row.
+__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __restrict__ logp,
+                                                              const float* __restrict__ dlogp, int T, int V,
+                                                              float inv_temp, bf16_t* __restrict__ P, int ldp,
+                                                              float* __restrict__ rowsum_out) {
+  __shared__ float red[256];
+  const int r = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) s += dlogp[(size_t)r * V + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float tot = red[0];
+  if (threadIdx.x == 0 && rowsum_out) rowsum_out[r] = tot;
+  for (int c = threadIdx.x; c < ldp; c += 256) {
+    float g = 0.f;
+    if (c < V) g = (dlogp[(size_t)r * V + c] - expf(logp[(size_t)r * V + c]) * tot) * inv_temp;
+    P[(size_t)r * ldp + c] = f2bf(g);
+  }
+}
+
+// column sums of a bf16 matrix [R][ld] over rows, fp32 accumulate (bias gradient of the dense path)
+__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ P, int R, int ld, int n, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += bf2f(P[(size_t)r * ld + c]);
+  out[c] = s;
+}
+
+__global__ void colsum_f32_kernel(const float* __restrict__ X, int R, long ld, int n, float* __restrict__ out,
+                                  int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = accumulate ? out[c] : 0.f;
+  for (int r = 0; r < R; ++r) s += X[(size_t)r * ld + c];
+  out[c] = s;
+}
+
+// dense-input NLL pick: out[t] = -logp[t][target[t]] (0 where target == ignore)   (criterions.py:57-63)
+__global__ void pick_nll_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target, int64_t ignore,
+                                int T, int V, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int64_t c = target[t];
+  out[t] = (c == ignore || c < 0 || c >= V) ? 0.f : -logp[(size_t)t * V + c];
+}
+
+__global__ void pick_nll_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ target,
+                                    int64_t ignore, int T, int V, float* __restrict__ dlogp) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int64_t c = target[t];
+  if (!(c == ignore || c < 0 || c >= V)) dlogp[(size_t)t * V + c] = -dout[t];
+}
+
+inline int grid_for(long n, int block) {
+  long g = (n + block - 1) / block;
+  return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv_cast_pack_bf16(const float* src, int n0, int n1, int n1p, int C, long s0, long s1, long sc, void* dst,
+                      int ldd, void* stream) {
+  PV_REQUIRE(src && dst && n0 > 0 && n1 > 0 && n1p >= n1 && C > 0 && ldd >= C, "pv_cast_pack_bf16: bad argument");
+  hipLaunchKernelGGL(cast_pack_kernel, dim3(grid_for((long)n0 * n1 * ldd, 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, n0, n1, n1p, C, s0, s1, sc, (bf16_t*)dst, ldd);
+  PV_LAUNCH_CHECK("cast_pack_kernel");
+  return PV_OK;
+}
+
+int pv_transpose_to_bf16(const void* src, int src_is_f32, int R, int C, long lds_, void* dst, long ldd, int Rpad,
+                         void* stream) {
+  PV_REQUIRE(src && dst && R > 0 && C > 0 && lds_ >= C && Rpad >= R && ldd >= Rpad, "pv_transpose_to_bf16: bad argument");
+  dim3 grid(cdiv(C, 64), cdiv(Rpad, 64));
+  if (src_is_f32)
+    hipLaunchKernelGGL(transpose_bf16_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, R, C,
+                       lds_, (bf16_t*)dst, ldd, Rpad);
+  else
+    hipLaunchKernelGGL(transpose_bf16_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, R,
+                       C, lds_, (bf16_t*)dst, ldd, Rpad);
+  PV_LAUNCH_CHECK("transpose_bf16_kernel");
+  return PV_OK;
+}
+
+int pv_reparam_kl_fwd(const float* mu_q, const float* lv_q, const float* mu_p, const float* lv_p, const float* eps,
+                      int B, int Z, int mode, float* z, float* kl_row, void* stream) {
+  PV_REQUIRE(mu_q && lv_q && B > 0 && Z > 0 && (z || kl_row), "pv_reparam_kl_fwd: bad argument");
+  PV_REQUIRE(!kl_row || (mu_p && lv_p), "pv_reparam_kl_fwd: KL needs the prior");
+  PV_REQUIRE(mode == 0 || mode == 1, "pv_reparam_kl_fwd: mode must be 0 (log sigma^2) or 1 (log sigma)");
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, mu_q, lv_q, mu_p,
+                     lv_p, eps, B, Z, mode, z, kl_row);
+  PV_LAUNCH_CHECK("reparam_kl_fwd_kernel");
+  return PV_OK;
+}
+
+int pv_reparam_kl_bwd(const float* mu_q, const float* lv_q, const float* mu_p, const float* lv_p, const float* eps,
+                      const float* dz, const float* dkl_row, int B, int Z, int mode, float* dmu_q, float* dlv_q,
+                      float* dmu_p, float* dlv_p, void* stream) {
+  PV_REQUIRE(mu_q && lv_q && B > 0 && Z > 0, "pv_reparam_kl_bwd: bad argument");
+  PV_REQUIRE(!dkl_row || (mu_p && lv_p), "pv_reparam_kl_bwd: KL needs the prior");
+  hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(grid_for((long)B * Z, 256)), dim3(256), 0, (hipStream_t)stream, mu_q,
+                     lv_q, mu_p, lv_p, eps, dz, dkl_row, B, Z, mode, dmu_q, dlv_q, dmu_p, dlv_p);
+  PV_LAUNCH_CHECK("reparam_kl_bwd_kernel");
+  return PV_OK;
+}
+
+int pv_gumbel_softmax_fwd(const float* logits, const float* u, int rows, int k, float tau, int hard, float* y_soft,
+                          float* y, int64_t* ids, void* stream) {
+  PV_REQUIRE(logits && u && y_soft && y && rows > 0 && k > 0 && tau > 0.f, "pv_gumbel_softmax_fwd: bad argument");
+  hipLaunchKernelGGL(gumbel_fwd_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, logits, u, rows, k,
+                     1.f / tau, hard, y_soft, y, ids);
+  PV_LAUNCH_CHECK("gumbel_fwd_kernel");
+  return PV_OK;
+}
+
+int pv_softmax_bwd_rows(const float* y_soft, const float* dy, int rows, int k, float scale, float* dlogits,
+                        void* stream) {
+  PV_REQUIRE(y_soft && dy && dlogits && rows > 0 && k > 0, "pv_softmax_bwd_rows: bad argument");
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, y_soft, dy,
+                     rows, k, scale, dlogits);
+  PV_LAUNCH_CHECK("softmax_bwd_rows_kernel");
+  return PV_OK;
+}
+
+int pv_cat_rows_fwd(const float* log_q, const float* log_p, long log_p_numel, int rows, int k, int mode, float* out,
+                    void* stream) {
+  PV_REQUIRE(log_q && out && rows > 0 && k > 0 && (mode == 1 || log_p), "pv_cat_rows_fwd: bad argument");
+  PV_REQUIRE(mode == 1 || log_p_numel == 1 || log_p_numel == (long)rows * k, "pv_cat_rows_fwd: log_p must be scalar or [rows,k]");
+  hipLaunchKernelGGL(cat_rows_fwd_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, log_q, log_p,
+                     log_p_numel, rows, k, mode, out);
+  PV_LAUNCH_CHECK("cat_rows_fwd_kernel");
+  return PV_OK;
+}
+
+int pv_cat_rows_bwd(const float* log_q, const float* log_p, long log_p_numel, const float* drow, int rows, int k,
+                    int mode, float* dlog_q, float* dlog_p, void* stream) {
+  PV_REQUIRE(log_q && drow && dlog_q && rows > 0 && k > 0 && (mode == 1 || log_p), "pv_cat_rows_bwd: bad argument");
+  PV_REQUIRE(!dlog_p || log_p_numel == (long)rows * k, "pv_cat_rows_bwd: dlog_p needs a full log_p");
+  hipLaunchKernelGGL(cat_rows_bwd_kernel, dim3(cdiv(rows * k, 256)), dim3(256), 0, (hipStream_t)stream, log_q, log_p,
+                     log_p_numel, drow, rows, k, mode, dlog_q, dlog_p);
+  PV_LAUNCH_CHECK("cat_rows_bwd_kernel");
+  return PV_OK;
+}
+
+int pv_masked_sum(const float* x, const int64_t* mask, int64_t ignore, long n, float* out2, void* stream) {
+  PV_REQUIRE(x && out2 && n >= 0, "pv_masked_sum: bad argument");
+  hipLaunchKernelGGL(masked_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, mask, ignore, n, out2);
+  PV_LAUNCH_CHECK("masked_sum_kernel");
+  return PV_OK;
+}
+
+int pv_logsoftmax_bwd_bf16(const float* logp, const float* dlogp, int T, int V, float inv_temp, void* P, int ldp,
+                           float* dbias, void* stream) {
+  PV_REQUIRE(logp && dlogp && P && T > 0 && V > 0 && ldp >= V, "pv_logsoftmax_bwd_bf16: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(T), dim3(256), 0, st, logp, dlogp, T, V, inv_temp, (bf16_t*)P, ldp,
+                     (float*)nullptr);
+  PV_LAUNCH_CHECK("logsoftmax_bwd_kernel");
+  if (dbias) {
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(V, 256)), dim3(256), 0, st, (const bf16_t*)P, T, ldp, V, dbias);
+    PV_LAUNCH_CHECK("colsum_bf16_kernel");
+  }
+  return PV_OK;
+}
+
+int pv_pick_nll_fwd(const float* logp, const int64_t* target, int64_t ignore, int T, int V, float* out,
+                    void* stream) {
+  PV_REQUIRE(logp && target && out && T > 0 && V > 0, "pv_pick_nll_fwd: bad argument");
+  hipLaunchKernelGGL(pick_nll_kernel, dim3(cdiv(T, 256)), dim3(256), 0, (hipStream_t)stream, logp, target, ignore, T,
+                     V, out);
+  PV_LAUNCH_CHECK("pick_nll_kernel");
+  return PV_OK;
+}
+
+int pv_pick_nll_bwd(const float* dout, const int64_t* target, int64_t ignore, int T, int V, float* dlogp,
+                    void* stream) {
+  PV_REQUIRE(dout && target && dlogp && T > 0 && V > 0, "pv_pick_nll_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  PV_HIP(hipMemsetAsync(dlogp, 0, (size_t)T * V * sizeof(float), st));
+  hipLaunchKernelGGL(pick_nll_bwd_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, dout, target, ignore, T, V, dlogp);
+  PV_LAUNCH_CHECK("pick_nll_bwd_kernel");
+  return PV_OK;
+}
+
+int pv_colsum_f32(const float* X, int R, long ld, int n, float* out, int accumulate, void* stream) {
+  PV_REQUIRE(X && out && R > 0 && n > 0 && ld >= n, "pv_colsum_f32: bad argument");
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, X, R, ld, n, out,
+                     accumulate);
+  PV_LAUNCH_CHECK("colsum_f32_kernel");
+  return PV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// Embedding lookup and its backward for gfx950: coalesced row gathers and an atomic-free,
+// bitwise-reproducible sorted scatter-add.
+//
+// Reference: nn.Embedding gathers at models/dialog_models.py:758-765 (user / item / rating / word) and
+// models/enc2dec/decoders.py:174 (decoder-side re-gather of the shared word table); the backward is
+// torch's embedding_dense_backward (atomics on GPU -> run-to-run bit differences).  Here the backward
+// sorts (row id, occurrence) pairs with a STABLE radix sort, then one wave per distinct table row sums
+// that row's occurrences in occurrence order: no atomics, same bits every run, same order as a CPU
+// index_add_ over the flattened ids.
+//
+// Occurrence r = i0*n1 + i1 reads ids[i0*s0 + i1*s1] and lives in row i0*n1p + i1 of the gathered matrix
+// (n1p >= n1 leaves the GRU's batch-padding rows untouched), so the same kernels serve batch-major ([B,L] ids
+// -> rows b*L+t) and time-major (rows t*Bpad+b, what the GRU wants) layouts.
+#include "common.h"
+#include "../../include/pevae_hip.h"
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+// one wave per output row; 16-byte reads when D % 4 == 0
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ table, long num_rows, int D,
+                                                      const int64_t* __restrict__ ids, int n, int n1, int n1p,
+                                                      long s0, long s1, float* __restrict__ out, int ldo,
+                                                      bf16_t* __restrict__ outb, int ldb, int* __restrict__ oob) {
+  const int lane = threadIdx.x & 63;
+  const int occ = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (occ >= n) return;
+  int64_t id = ids[(long)(occ / n1) * s0 + (long)(occ % n1) * s1];
+  const long r = (long)(occ / n1) * n1p + occ % n1;
+  if (id < 0 || id >= num_rows) {          // the reference would raise an index error here
+    if (lane == 0 && oob) atomicAdd(oob, 1);
+    id = id < 0 ? 0 : num_rows - 1;
+  }
+  const float* src = table + id * D;
+  for (int c = lane; c < D; c += 64) {
+    const float v = src[c];
+    if (out) out[(size_t)r * ldo + c] = v;
+    if (outb) outb[(size_t)r * ldb + c] = f2bf(v);
+  }
+  if (outb)
+    for (int c = D + lane; c < ldb; c += 64) outb[(size_t)r * ldb + c] = 0;   // K padding for the MFMA GEMM
+}
+
+__global__ void fill_keys_kernel(const int64_t* __restrict__ ids, int n, int n1, int n1p, long s0, long s1,
+                                 long num_rows, int* __restrict__ keys, int* __restrict__ vals) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t id = ids[(long)(r / n1) * s0 + (long)(r % n1) * s1];
+  keys[r] = (id < 0 || id >= num_rows) ? (int)num_rows : (int)id;   // out-of-range ids sort last, get no gradient
+  vals[r] = (r / n1) * n1p + r % n1;                                // row of the gradient matrix
+}
+
+// one wave per sorted position that starts a segment (key differs from its predecessor)
+__global__ __launch_bounds__(256) void segment_sum_kernel(const int* __restrict__ keys, const int* __restrict__ vals,
+                                                           int n, const float* __restrict__ grad, int ldg, int D,
+                                                           long num_rows, long padding_idx, int accumulate,
+                                                           float* __restrict__ dtable) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int key = keys[i];
+  if (i > 0 && keys[i - 1] == key) return;                 // not a segment head
+  if (key < 0 || key >= num_rows || key == padding_idx) return;
+  int end = i + 1;
+  while (end < n && keys[end] == key) ++end;
+  float* dst = dtable + (size_t)key * D;
+  for (int c = lane; c < D; c += 64) {
+    float s = accumulate ? dst[c] : 0.f;
+    for (int j = i; j < end; ++j) s += grad[(size_t)vals[j] * ldg + c];
+    dst[c] = s;
+  }
+}
+
+size_t sort_temp_bytes(int n) {
+  size_t bytes = 0;
+  hipcub::DeviceRadixSort::SortPairs((void*)nullptr, bytes, (const int*)nullptr, (int*)nullptr,
+                                     (const int*)nullptr, (int*)nullptr, n);
+  return bytes;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv_embedding_gather(const float* table, long num_rows, int D, const int64_t* ids, int n, int n1, int n1p,
+                        long s0, long s1, float* out, int ldo, void* out_bf16, int ldb, int* oob_counter,
+                        void* stream) {
+  PV_REQUIRE(table && ids && (out || out_bf16), "pv_embedding_gather: null argument");
+  PV_REQUIRE(n >= 0 && n1 > 0 && n1p >= n1 && D > 0 && num_rows > 0, "pv_embedding_gather: bad sizes");
+  PV_REQUIRE((!out || ldo >= D) && (!out_bf16 || ldb >= D), "pv_embedding_gather: leading dimension < D");
+  if (n == 0) return PV_OK;
+  hipLaunchKernelGGL(gather_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, table, num_rows, D, ids,
+                     n, n1, n1p, s0, s1, out, ldo, (bf16_t*)out_bf16, ldb, oob_counter);
+  PV_LAUNCH_CHECK("gather_kernel");
+  return PV_OK;
+}
+
+size_t pv_embedding_bwd_ws_bytes(int n) {
+  const size_t a = round_up(n, 64) * sizeof(int);
+  return 4 * a + ((sort_temp_bytes(n) + 255) & ~(size_t)255) + 256;
+}
+
+int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n, int n1, int n1p, long s0, long s1,
+                     long num_rows, int D, long padding_idx, int accumulate, float* dtable, void* workspace,
+                     size_t ws_bytes, void* stream) {
+  PV_REQUIRE(grad_rows && ids && dtable && workspace, "pv_embedding_bwd: null argument");
+  PV_REQUIRE(n >= 0 && n1 > 0 && n1p >= n1 && D > 0 && ldg >= D, "pv_embedding_bwd: bad sizes");
+  PV_REQUIRE(ws_bytes >= pv_embedding_bwd_ws_bytes(n), "pv_embedding_bwd: workspace too small");
+  PV_REQUIRE(num_rows < (1l << 30), "pv_embedding_bwd: table rows must fit int32 sort keys");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) PV_HIP(hipMemsetAsync(dtable, 0, (size_t)num_rows * D * sizeof(float), st));
+  if (n == 0) return PV_OK;
+  const size_t a = round_up(n, 64) * sizeof(int);
+  char* ws = (char*)workspace;
+  int* keys = (int*)ws;
+  int* vals = (int*)(ws + a);
+  int* skeys = (int*)(ws + 2 * a);
+  int* svals = (int*)(ws + 3 * a);
+  void* temp = ws + 4 * a;
+  size_t temp_bytes = sort_temp_bytes(n);
+  hipLaunchKernelGGL(fill_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, n, n1, n1p, s0, s1, num_rows, keys, vals);
+  PV_LAUNCH_CHECK("fill_keys_kernel");
+  int bits = 1;
+  while ((1l << bits) <= num_rows && bits < 31) ++bits;
+  PV_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, skeys, vals, svals, n, 0, bits, st));
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, skeys, svals, n, grad_rows, ldg, D,
+                     num_rows, padding_idx, accumulate, dtable);
+  PV_LAUNCH_CHECK("segment_sum_kernel");
+  return PV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,480 @@
+// bf16 MFMA "NT" GEMM core for gfx950 with pluggable epilogues.
+//
+//   C[M,N] = A[M,K] * B[N,K]^T        A, B bf16 row-major (K contiguous), fp32 accumulate
+//
+// One 256-thread workgroup (4 waves, 2x2) owns a 128x128 output tile; each wave owns 64x64 as 4x4
+// v_mfma_f32_16x16x32_bf16 accumulators.  A/B K-tiles (64 deep) are staged global->LDS with
+// global_load_lds_dwordx4 (no VGPR round trip) into a 2-deep ring; the LDS image is lane-linear, so
+// the bank-conflict XOR swizzle (16-B chunk ^= (row>>1)&7) is applied on the per-lane SOURCE address
+// and again on the ds_read_b128 fragment reads.  The block id is remapped so that the 8 XCDs (one L2
+// each) work on compact groups of neighbouring tiles.
+//
+// Epilogues (all fused, accumulators never leave registers un-reduced):
+//   EpiStore     : C (+bias) -> fp32 and/or bf16                    (GRU input projections, dH, dW ...)
+//   EpiSoftmax   : per-row (max, sum-exp) partials per 64-column slab + the target logit
+//                  -> vocabulary softmax NLL without materialising logits   (decoders.py:191-193 +
+//                  criterions.py:55-64 of the reference, fused)
+//   EpiProb      : P = (softmax - onehot) * g as bf16, written both as P[T,V] and P^T[V,T] (LDS
+//                  transposed), + column sums for the bias gradient          (backward of the above)
+//   EpiLogProb   : dense log-softmax rows (API-compat path for callers that want [B,L,V])
+#include "common.h"
+#include "../../include/pevae_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // 64 KiB -> 2 workgroups per CU
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  int M, N, K, lda, ldb;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void tile_coords(int M, int N, int& pm, int& pn) {
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN, nwg = nbm * nbn;
+  const int bid = blockIdx.x;
+  // XCD-aware remap (bijective for any nwg): blocks b and b+8 share an XCD / L2.
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  // grouped ordering: walk 8 tile-rows at a time so concurrently running tiles share A/B panels
+  const int width = 8 * nbn, grp = id / width, first_m = grp * 8;
+  const int gsz = min(nbm - first_m, 8);
+  pm = first_m + (id % width) % gsz;
+  pn = (id % width) / gsz;
+}
+
+template <class Epi>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  int pm, pn;
+  tile_coords(g.M, g.N, pm, pn);
+  const int m0 = pm * BM, n0 = pn * BN;
+
+  // --- per-lane source pointers for the 4+4 LDS-DMA pieces this wave issues per K-tile ----------
+  const bf16_t* srcA[4];
+  const bf16_t* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (w * 4 + i) * 8 + (lane >> 3);          // tile row this lane fills
+    const int c = (lane & 7) ^ ((r >> 1) & 7);            // logical 16-B chunk stored at phys lane&7
+    const int ra = min(m0 + r, g.M - 1), rb = min(n0 + r, g.N - 1);
+    srcA[i] = g.A + (size_t)ra * g.lda + c * 8;
+    srcB[i] = g.B + (size_t)rb * g.ldb + c * 8;
+  }
+  auto stage = [&](int s, int kt) {
+    char* base = smem + s * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + kt * BK),
+                                       (lptr_t)(base + (w * 4 + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + kt * BK),
+                                       (lptr_t)(base + BM * BK * 2 + (w * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (bytes) inside a stage: row*128 + ((ks*4+q4) ^ ((row>>1)&7))*16
+  int offA[4], offB[4], swz[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 64 + i * 16 + c16, rb = wn * 64 + i * 16 + c16;
+    offA[i] = ra * 128;
+    offB[i] = BM * BK * 2 + rb * 128;
+    swz[i] = (c16 >> 1) & 7;   // (row>>1)&7 : rows are 16-aligned + c16, so only c16 matters
+  }
+
+  const int nk = g.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int s = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage(s ^ 1, kt + 1);
+    const char* base = smem + s * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = ((ks * 4 + q4) ^ swz[i]) * 16;
+        af[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + offA[i] + ch));
+        bfr[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + offB[i] + ch));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // all waves done with the ring: epilogues may reuse smem
+  epi(acc, m0 + wm * 64, n0 + wn * 64, w, lane, smem);
+}
+
+// -------------------------------------------------------------------------------------------------
+// epilogues.  acc[mi][ni][j] is element (row0 + mi*16 + (lane>>4)*4 + j, col0 + ni*16 + (lane&15)).
+// -------------------------------------------------------------------------------------------------
+
+struct EpiStore {
+  float* C;
+  bf16_t* Cb;
+  const float* bias;
+  int M, N, ldc, ldcb;
+  __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
+    const int c16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int col = col0 + ni * 16 + c16;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = row0 + mi * 16 + q4 * 4 + j;
+          if (row >= M) continue;
+          const float v = acc[mi][ni][j] + bv;
+          if (C) C[(size_t)row * ldc + col] = v;
+          if (Cb) Cb[(size_t)row * ldcb + col] = f2bf(v);
+        }
+    }
+  }
+};
+
+struct EpiSoftmax {
+  const float* bias;        // [V]
+  const int64_t* target;    // [T]
+  float2* part;             // [nslab][Tpad]  (max, sumexp) of the scaled logits of a 64-column slab
+  float* tgt_logit;         // [T]
+  int T, V, Tpad;
+  float inv_temp;
+  __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
+    if (col0 >= V) return;
+    const int c16 = lane & 15, q4 = lane >> 4;
+    float bv[4];
+    bool live[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int col = col0 + ni * 16 + c16;
+      live[ni] = col < V;
+      bv[ni] = live[ni] ? bias[col] : 0.f;
+    }
+    float my_m = 0.f, my_s = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = row0 + mi * 16 + q4 * 4 + j;
+        float x[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          x[ni] = live[ni] ? (acc[mi][ni][j] + bv[ni]) * inv_temp : -INFINITY;
+          m = fmaxf(m, x[ni]);
+        }
+        if (row < T) {
+          const int tc = (int)target[row] - col0;      // target column relative to this slab
+          if (tc >= 0 && tc < 64 && (tc & 15) == c16) {
+            const int tn = tc >> 4;
+            const float xv = tn == 0 ? x[0] : tn == 1 ? x[1] : tn == 2 ? x[2] : x[3];
+            tgt_logit[row] = xv;
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float s = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) s += __expf(x[ni] - m);     // exp(-inf) = 0 for masked columns
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (c16 == mi * 4 + j) {
+          my_m = m;
+          my_s = s;
+        }
+      }
+    // lane (q4, c16) publishes row  (c16>>2)*16 + q4*4 + (c16&3)
+    const int row = row0 + (c16 >> 2) * 16 + q4 * 4 + (c16 & 3);
+    if (row < Tpad) part[(size_t)(col0 >> 6) * Tpad + row] = make_float2(my_m, my_s);
+  }
+};
+
+constexpr int EPI_LD = 144;            // bytes per staged 64-element bf16 row (128 + 16 pad)
+constexpr int EPI_WAVE_BYTES = 64 * EPI_LD;
+
+struct EpiProb {
+  const float* bias;        // [V]
+  const int64_t* target;    // [T]
+  const float* lse;         // [T]
+  const float* gscale;      // [T]  dLoss/dnll_tok (0 for ignored tokens); inv_temp applied here
+  bf16_t* P;                // [Tpad][ldp]   ldp  >= round_up(V,64)
+  bf16_t* PT;               // [Vpad][ldpt]  ldpt >= Tpad = round_up(T,64)
+  float* dbias_part;        // [Tpad/64][ldp]
+  int T, V, Tpad, Vpad, ldp, ldpt;
+  float inv_temp;
+  __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const bool slab_live = (col0 < Vpad) && (row0 < Tpad);
+    char* my = smem + w * EPI_WAVE_BYTES;
+    float bv[4];
+    bool live[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int col = col0 + ni * 16 + c16;
+      live[ni] = col < V;
+      bv[ni] = live[ni] ? bias[col] : 0.f;
+    }
+    float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = row0 + mi * 16 + q4 * 4 + j;
+        const bool rl = row < T;
+        const float l = rl ? lse[row] : 0.f;
+        const float gs = rl ? gscale[row] * inv_temp : 0.f;
+        const int tc = rl ? (int)target[row] - col0 : -1;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float p = 0.f;
+          if (live[ni] && gs != 0.f) {
+            p = __expf((acc[mi][ni][j] + bv[ni]) * inv_temp - l);
+            if (tc == ni * 16 + c16) p -= 1.f;
+            p *= gs;
+          }
+          acc[mi][ni][j] = p;
+          colsum[ni] += p;
+        }
+      }
+    if (!slab_live) {     // uniform per wave; the barriers below are workgroup-wide, keep them reachable
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();
+      return;
+    }
+    // bias-gradient partials: reduce the 4 row-groups (lanes l, l^16, l^32, l^48)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float s = colsum[ni];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (q4 == 0) dbias_part[(size_t)(row0 >> 6) * ldp + col0 + ni * 16 + c16] = s;
+    }
+    // ---- P tile, row-major image [64 rows][64 cols] ------------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *(bf16_t*)(my + (mi * 16 + q4 * 4 + j) * EPI_LD + (ni * 16 + c16) * 2) = f2bf(acc[mi][ni][j]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = i * 8 + (lane >> 3), ch = lane & 7;
+      const uint4 v = *(const uint4*)(my + r * EPI_LD + ch * 16);
+      *(uint4*)(P + (size_t)(row0 + r) * ldp + col0 + ch * 8) = v;
+    }
+    __syncthreads();
+    // ---- P^T tile: image [64 cols][64 rows]; a lane's 4 j-values are 4 consecutive rows = 8 bytes
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        uint2 v;
+        v.x = pack2bf(acc[mi][ni][0], acc[mi][ni][1]);
+        v.y = pack2bf(acc[mi][ni][2], acc[mi][ni][3]);
+        *(uint2*)(my + (ni * 16 + c16) * EPI_LD + (mi * 16 + q4 * 4) * 2) = v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = i * 8 + (lane >> 3), ch = lane & 7;
+      const uint4 v = *(const uint4*)(my + r * EPI_LD + ch * 16);
+      *(uint4*)(PT + (size_t)(col0 + r) * ldpt + row0 + ch * 8) = v;
+    }
+  }
+};
+
+struct EpiLogProb {
+  const float* bias;
+  const float* lse;   // [T]
+  float* out;         // [T][V] dense log-probs
+  int T, V;
+  float inv_temp;
+  __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
+    const int c16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int col = col0 + ni * 16 + c16;
+      if (col >= V) continue;
+      const float bv = bias[col];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = row0 + mi * 16 + q4 * 4 + j;
+          if (row < T) out[(size_t)row * V + col] = (acc[mi][ni][j] + bv) * inv_temp - lse[row];
+        }
+    }
+  }
+};
+
+// combine the per-slab (max, sumexp) partials: 64 rows per block, 4 slab-strided lanes per row
+__global__ __launch_bounds__(256) void vocab_reduce_kernel(const float2* __restrict__ part,
+                                                            const float* __restrict__ tgt_logit,
+                                                            const int64_t* __restrict__ target, int T,
+                                                            int Tpad, int nslab, int64_t ignore_index,
+                                                            float* __restrict__ lse,
+                                                            float* __restrict__ nll) {
+  __shared__ float sm[4][64], ss[4][64];
+  const int r = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int row = blockIdx.x * 64 + r;
+  float m = -INFINITY, s = 0.f;
+  if (row < T) {
+    for (int k = y; k < nslab; k += 4) {
+      const float2 p = part[(size_t)k * Tpad + row];
+      const float mn = fmaxf(m, p.x);
+      s = s * __expf(m - mn) + p.y * __expf(p.x - mn);
+      m = mn;
+    }
+  }
+  sm[y][r] = m;
+  ss[y][r] = s;
+  __syncthreads();
+  if (y == 0 && row < T) {
+    float M = sm[0][r];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) M = fmaxf(M, sm[k][r]);
+    float S = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S += ss[k][r] * __expf(sm[k][r] - M);
+    const float l = M + logf(S);
+    lse[row] = l;
+    const int64_t t = target[row];
+    nll[row] = (t == ignore_index) ? 0.f : l - tgt_logit[row];
+  }
+}
+
+// dbias[v] = sum over row-slabs of dbias_part[slab][v]   (fixed order: bitwise reproducible)
+__global__ void colsum_kernel(const float* __restrict__ part, int nrows, int ld, int n,
+                              float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < nrows; ++r) s += part[(size_t)r * ld + c];
+  out[c] = s;
+}
+
+int check_gemm(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const char* who) {
+  PV_REQUIRE(A && B, "%s: null operand", who);
+  PV_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty problem M=%d N=%d K=%d", who, M, N, K);
+  PV_REQUIRE(K % BK == 0, "%s: K=%d must be a multiple of %d (pad with zeros)", who, K, BK);
+  PV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K,
+             "%s: lda=%d ldb=%d must be multiples of 8 and >= K=%d", who, lda, ldb, K);
+  PV_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "%s: operands must be 16-byte aligned", who);
+  return PV_OK;
+}
+
+template <class Epi>
+int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    PV_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SMEM_BYTES));
+    attr_done = true;
+  }
+  const int nwg = cdiv(g.M, BM) * cdiv(g.N, BN);
+  hipLaunchKernelGGL(gemm_nt_kernel<Epi>, dim3(nwg), dim3(NTHREADS), SMEM_BYTES, st, g, epi);
+  PV_LAUNCH_CHECK(who);
+  return PV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                    const float* bias, float* C, int ldc, void* Cb, int ldcb, void* stream) {
+  int rc = check_gemm(A, B, M, N, K, lda, ldb, "pv_gemm_bf16_nt");
+  if (rc) return rc;
+  PV_REQUIRE(C || Cb, "pv_gemm_bf16_nt: no output given");
+  PV_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N), "pv_gemm_bf16_nt: output leading dimension < N");
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb};
+  EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb};
+  return launch(g, e, (hipStream_t)stream, "pv_gemm_bf16_nt");
+}
+
+size_t pv_vocab_nll_fwd_ws_bytes(int T, int V) {
+  return (size_t)cdiv(V, 64) * round_up(T, 64) * sizeof(float2) + (size_t)round_up(T, 64) * sizeof(float);
+}
+
+int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float* bias,
+                     const int64_t* target, int T, int V, int H, float inv_temp, int64_t ignore_index,
+                     void* workspace, float* lse, float* nll, void* stream) {
+  int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_nll_fwd");
+  if (rc) return rc;
+  PV_REQUIRE(bias && target && workspace && lse && nll, "pv_vocab_nll_fwd: null argument");
+  const int Tpad = round_up(T, 64), nslab = cdiv(V, 64);
+  float2* part = (float2*)workspace;
+  float* tgt_logit = (float*)(part + (size_t)nslab * Tpad);
+  hipStream_t st = (hipStream_t)stream;
+  // rows whose target is out of range (e.g. ignore_index < 0) never get a target logit written
+  PV_HIP(hipMemsetAsync(tgt_logit, 0, (size_t)Tpad * sizeof(float), st));
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw};
+  EpiSoftmax e{bias, target, part, tgt_logit, T, V, Tpad, inv_temp};
+  rc = launch(g, e, st, "pv_vocab_nll_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(vocab_reduce_kernel, dim3(cdiv(T, 64)), dim3(256), 0, st, part, tgt_logit, target, T,
+                     Tpad, nslab, ignore_index, lse, nll);
+  PV_LAUNCH_CHECK("vocab_reduce_kernel");
+  return PV_OK;
+}
+
+int pv_vocab_nll_bwd_prob(const void* h, int ldh, const void* W, int ldw, const float* bias,
+                          const int64_t* target, const float* lse, const float* gscale, int T, int V,
+                          int H, float inv_temp, void* P, int ldp, void* PT, int ldpt,
+                          float* dbias_part, float* dbias, void* stream) {
+  int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_nll_bwd_prob");
+  if (rc) return rc;
+  const int Tpad = round_up(T, 64), Vpad = round_up(V, 64);
+  PV_REQUIRE(bias && target && lse && gscale && P && PT && dbias_part && dbias, "pv_vocab_nll_bwd_prob: null argument");
+  PV_REQUIRE(ldp >= Vpad && ldp % 8 == 0 && ldpt >= Tpad && ldpt % 8 == 0,
+             "pv_vocab_nll_bwd_prob: need ldp >= %d and ldpt >= %d (multiples of 8)", Vpad, Tpad);
+  PV_REQUIRE(((uintptr_t)P & 15) == 0 && ((uintptr_t)PT & 15) == 0, "pv_vocab_nll_bwd_prob: P/PT must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw};
+  EpiProb e{bias, target, lse, gscale, (bf16_t*)P, (bf16_t*)PT, dbias_part, T, V, Tpad, Vpad, ldp, ldpt, inv_temp};
+  rc = launch(g, e, st, "pv_vocab_nll_bwd_prob");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(V, 256)), dim3(256), 0, st, dbias_part, Tpad / 64, ldp, V, dbias);
+  PV_LAUNCH_CHECK("colsum_kernel");
+  return PV_OK;
+}
+
+int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const float* bias,
+                           const float* lse, int T, int V, int H, float inv_temp, float* out, void* stream) {
+  int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_logprob_dense");
+  if (rc) return rc;
+  PV_REQUIRE(bias && lse && out, "pv_vocab_logprob_dense: null argument");
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw};
+  EpiLogProb e{bias, lse, out, T, V, inv_temp};
+  return launch(g, e, (hipStream_t)stream, "pv_vocab_logprob_dense");
+}
+
+}  // extern "C"

@@ -1,0 +1,699 @@
+"""Tensor-level wrappers and autograd Functions over the C ABI (include/pevae_hip.h).
+
+PyTorch is used here for device memory, streams and autograd bookkeeping only: every arithmetic op below
+is a hand-written HIP kernel from libpevae_hip.so, launched on torch's current stream.  Nothing in this file
+has a CPU path -- CPU tensors raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pevae_amd kernels need tensors on an MI355X device (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+_WS = {}
+
+
+def workspace(tag, numel, dtype, device, zero=False):
+    """Persistent scratch (reused every step, stream-ordered).  Never handed to autograd as saved state."""
+    key = (tag, dtype, device)
+    t = _WS.get(key)
+    if t is None or t.numel() < numel:
+        t = torch.zeros(numel, dtype=dtype, device=device) if zero else torch.empty(numel, dtype=dtype, device=device)
+        _WS[key] = t
+    return t[:numel]
+
+
+def device_info():
+    cu, lds = C.c_int(0), C.c_int(0)
+    arch = C.create_string_buffer(64)
+    _lib.call("pv_device_info", C.byref(cu), C.byref(lds), arch, 64)
+    return dict(cu_count=cu.value, lds_bytes=lds.value, arch=arch.value.decode())
+
+
+def gru_geometry(B, H):
+    hk, k3, bp, ng = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    _lib.call("pv_gru_geometry", B, H, C.byref(hk), C.byref(k3), C.byref(bp), C.byref(ng))
+    return hk.value, k3.value, bp.value, ng.value
+
+
+# ------------------------------------------------------------------------------------------------------------
+# layout helpers
+# ------------------------------------------------------------------------------------------------------------
+
+def cast_pack(src, n0, n1, n1p, ncol, s0, s1, sc, ldd, out=None):
+    """bf16 [n0*n1p][ldd] with out[(i0*n1p+i1), c] = src[i0*s0 + i1*s1 + c*sc] (zero K padding)."""
+    _need_cuda(src)
+    if out is None:
+        out = (torch.zeros if n1p != n1 else torch.empty)((n0 * n1p, ldd), dtype=BF16, device=src.device)
+    _lib.call("pv_cast_pack_bf16", _p(src), n0, n1, n1p, ncol, s0, s1, sc, _p(out), ldd, _stream())
+    return out
+
+
+def pack_matrix(w, ld=None):
+    """fp32 [R,C] contiguous -> bf16 [R][ld] (ld = round_up(C,64) by default)."""
+    R, Cc = w.shape
+    ld = round_up(Cc, 64) if ld is None else ld
+    return cast_pack(w.contiguous(), 1, R, R, Cc, 0, Cc, 1, ld)
+
+
+def transpose_to_bf16(src, R, Cc, lds, rpad, out=None):
+    """bf16 [Cc][rpad] = src[R][lds]^T (src fp32 or bf16), columns R..rpad zero."""
+    _need_cuda(src)
+    if out is None:
+        out = torch.empty((Cc, rpad), dtype=BF16, device=src.device)
+    _lib.call("pv_transpose_to_bf16", _p(src), 1 if src.dtype == torch.float32 else 0, R, Cc, lds, _p(out), rpad,
+              rpad, _stream())
+    return out
+
+
+def gemm_nt(A, lda, Bm, ldb, M, N, K, bias=None, out=None, out_bf16=None):
+    """C[M,N] = A[M,K] B[N,K]^T (+bias) with bf16 operands on the MFMA core."""
+    _need_cuda(A, Bm)
+    if out is None and out_bf16 is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    _lib.call("pv_gemm_bf16_nt", _p(A), lda, _p(Bm), ldb, M, N, K, _p(bias), _p(out),
+              0 if out is None else out.stride(0), _p(out_bf16), 0 if out_bf16 is None else out_bf16.stride(0),
+              _stream())
+    return out if out is not None else out_bf16
+
+
+def masked_sum(x, mask=None, ignore=0):
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    _lib.call("pv_masked_sum", _p(x), _p(mask), ignore, x.numel(), _p(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fused vocabulary projection + log-softmax + NLL
+# ------------------------------------------------------------------------------------------------------------
+
+def _vocab_operands(hid, weight):
+    T, H = hid.shape
+    V = weight.shape[0]
+    Hp = round_up(H, 64)
+    if hid.dtype == BF16:
+        assert hid.stride(1) == 1 and hid.stride(0) % 8 == 0 and hid.stride(0) >= Hp
+        h_bf, ldh = hid, hid.stride(0)
+    else:
+        h_bf, ldh = cast_pack(hid.contiguous(), 1, T, T, H, 0, H, 1, Hp), Hp
+    w_bf = pack_matrix(weight, Hp)
+    return T, H, V, Hp, h_bf, ldh, w_bf
+
+
+class VocabNLL(torch.autograd.Function):
+    """nll_tok[t] = -log_softmax((h W^T + b) / temperature)[target[t]], 0 for ignored targets; the [T,V]
+    log-prob tensor is never built (decoders.py:191-193 + criterions.py:55-64 of the reference, fused)."""
+
+    @staticmethod
+    def forward(ctx, hid, weight, bias, target, inv_temp, ignore_index, hid_bf16, layout):
+        # hid: fp32 [T,H] -- or, with `hid_bf16` ([L*Bpad, ld] time-major bf16 rows from the GRU kernel) and
+        # layout=(L,B,Bpad), the batch-first [B,L,H] tensor the gradient is returned for.  `target` follows
+        # the row order of the bf16 operand.
+        _need_cuda(hid, weight, bias, target)
+        T, H, V, Hp, h_bf, ldh, w_bf = _vocab_operands(hid if hid_bf16 is None else hid_bf16[:, :weight.shape[1]], weight)
+        dev = weight.device
+        ctx.layout = layout
+        target = target.contiguous()
+        ws = workspace("vocab_fwd", _lib.load().pv_vocab_nll_fwd_ws_bytes(T, V), torch.uint8, dev)
+        lse = torch.empty(T, dtype=torch.float32, device=dev)
+        nll = torch.empty(T, dtype=torch.float32, device=dev)
+        bias_c = bias.contiguous()
+        _lib.call("pv_vocab_nll_fwd", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(target), T, V, Hp, inv_temp,
+                  ignore_index, _p(ws), _p(lse), _p(nll), _stream())
+        ctx.save_for_backward(h_bf, w_bf, bias_c, target, lse)
+        ctx.dims = (T, H, V, Hp, ldh, inv_temp, ignore_index)
+        ctx.hid_dtype = hid.dtype
+        ctx.mark_non_differentiable(lse)
+        return nll, lse
+
+    @staticmethod
+    def backward(ctx, dnll, _dlse):
+        h_bf, w_bf, bias, target, lse = ctx.saved_tensors
+        T, H, V, Hp, ldh, inv_temp, ignore_index = ctx.dims
+        dev = w_bf.device
+        Tp, Vp = round_up(T, 64), round_up(V, 64)
+        gscale = (dnll.to(torch.float32) * (target != ignore_index)).contiguous()
+        P = workspace("vocab_P", Tp * Vp, BF16, dev)
+        PT = workspace("vocab_PT", Vp * Tp, BF16, dev)
+        dbp = workspace("vocab_dbias_part", (Tp // 64) * Vp, torch.float32, dev)
+        dbias = torch.empty(V, dtype=torch.float32, device=dev)
+        _lib.call("pv_vocab_nll_bwd_prob", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(target), _p(lse), _p(gscale),
+                  T, V, Hp, inv_temp, _p(P), Vp, _p(PT), Tp, _p(dbp), _p(dbias), _stream())
+        dH, dW = _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp)
+        if ctx.layout is not None:
+            L, B, Bpad = ctx.layout
+            dH = dH.view(L, Bpad, H)[:, :B].transpose(0, 1)
+        return dH, dW, dbias, None, None, None, None, None
+
+
+def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp):
+    dev = w_bf.device
+    wT = transpose_to_bf16(w_bf, V, H, Hp, Vp, out=workspace("vocab_WT", H * Vp, BF16, dev).view(H, Vp))
+    dH = gemm_nt(P, Vp, wT, Vp, T, H, Vp)
+    hT = transpose_to_bf16(h_bf, T, H, ldh, Tp, out=workspace("vocab_hT", H * Tp, BF16, dev).view(H, Tp))
+    dW = gemm_nt(PT, Tp, hT, Tp, V, H, Tp)
+    return dH, dW
+
+
+class VocabLogProbDense(torch.autograd.Function):
+    """Dense [T,V] log-softmax rows: the reference's DecoderRNN return value (decoders.py:193) for callers
+    that want it as a tensor.  Costs the 4 B x T x V write the fused path avoids."""
+
+    @staticmethod
+    def forward(ctx, hid, weight, bias, inv_temp):
+        _need_cuda(hid, weight, bias)
+        T, H, V, Hp, h_bf, ldh, w_bf = _vocab_operands(hid, weight)
+        dev = weight.device
+        ws = workspace("vocab_fwd", _lib.load().pv_vocab_nll_fwd_ws_bytes(T, V), torch.uint8, dev)
+        lse = torch.empty(T, dtype=torch.float32, device=dev)
+        nll = workspace("vocab_nll_scratch", T, torch.float32, dev)
+        tgt = torch.zeros(T, dtype=torch.int64, device=dev)
+        bias_c = bias.contiguous()
+        _lib.call("pv_vocab_nll_fwd", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(tgt), T, V, Hp, inv_temp, -1,
+                  _p(ws), _p(lse), _p(nll), _stream())
+        logp = torch.empty((T, V), dtype=torch.float32, device=dev)
+        _lib.call("pv_vocab_logprob_dense", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(lse), T, V, Hp, inv_temp,
+                  _p(logp), _stream())
+        ctx.save_for_backward(h_bf, w_bf, logp)
+        ctx.dims = (T, H, V, Hp, ldh, inv_temp)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        h_bf, w_bf, logp = ctx.saved_tensors
+        T, H, V, Hp, ldh, inv_temp = ctx.dims
+        dev = w_bf.device
+        Tp, Vp = round_up(T, 64), round_up(V, 64)
+        P = workspace("vocab_P", Tp * Vp, BF16, dev)
+        dbias = torch.empty(V, dtype=torch.float32, device=dev)
+        _lib.call("pv_logsoftmax_bwd_bf16", _p(logp), _p(dlogp.contiguous()), T, V, inv_temp, _p(P), Vp, _p(dbias),
+                  _stream())
+        PT = transpose_to_bf16(P, T, V, Vp, Tp, out=workspace("vocab_PT", Vp * Tp, BF16, dev)[:V * Tp].view(V, Tp))
+        dH, dW = _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp)
+        return dH, dW, dbias, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# GRU (input projection GEMM + persistent recurrence)
+# ------------------------------------------------------------------------------------------------------------
+
+GRU_MAX_WGS = 0     # 0 = one workgroup per CU of the current device
+LAST_GRU_SYNC = []  # (sync buffer, NG, tag) of recent launches, for gru_check_all() in tests / smoke
+
+
+def gru_check_all():
+    """Raise if any recent persistent-GRU launch reported a timed-out wait (synchronises the device)."""
+    while LAST_GRU_SYNC:
+        sync, NG, tag = LAST_GRU_SYNC.pop()
+        gru_check_sync(sync, NG, tag)
+
+
+def gru_check_sync(sync, NG, what):
+    """Raise if the persistent kernel reported a timed-out spin (debug / tests; forces a device sync)."""
+    flag = int(sync.view(torch.int32)[NG].item())
+    if flag != 0:
+        raise _lib.PevaeHipError("%s: a bounded inter-workgroup wait timed out (err=%d)" % (what, flag))
+
+
+class GRULayer(torch.autograd.Function):
+    """One unidirectional GRU layer over x [B,L,E] (batch_first), torch.nn.GRU semantics
+    (base_modules.py:42; encoders.py:59-62; decoders.py:182).  Returns (out [B,L,H], h_n [B,H],
+    hseq bf16 [(L+1)*Bpad, Hk] = every state in time-major order, reusable as a GEMM operand)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, save):
+        _need_cuda(x, w_ih, w_hh, b_ih, b_hh, h0)
+        B, L, E = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        Hk, K3, Bpad, NG = gru_geometry(B, H)
+        Ep = round_up(E, 64)
+        x_bf = cast_pack(x, L, B, Bpad, E, x.stride(1), x.stride(0), x.stride(2), Ep)
+        wih_bf = pack_matrix(w_ih, Ep)
+        whh_bf = pack_matrix(w_hh, Hk)
+        xproj = gemm_nt(x_bf, Ep, wih_bf, Ep, L * Bpad, 3 * H, Ep, bias=b_ih.contiguous(),
+                        out=workspace("gru_xproj", L * Bpad * 3 * H, torch.float32, dev).view(L * Bpad, 3 * H))
+        out = torch.empty((B, L, H), dtype=torch.float32, device=dev)
+        hseq = torch.empty(((L + 1) * Bpad, Hk), dtype=BF16, device=dev)
+        hn = torch.empty((B, H), dtype=torch.float32, device=dev)
+        gsave = torch.empty((L * Bpad, 4 * H), dtype=torch.float32, device=dev) if save else None
+        hall = torch.empty(((L + 1) * Bpad, H), dtype=torch.float32, device=dev) if save else None
+        sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
+        h0c = None if h0 is None else h0.contiguous()
+        _lib.call("pv_gru_fwd", _p(xproj), _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), L, B, H, 0, _p(out), L * H, H,
+                  _p(hseq), _p(gsave), _p(hall), _p(hn), _p(sync), GRU_MAX_WGS, _stream())
+        if save:
+            ctx.save_for_backward(x_bf, hseq, gsave, hall, w_ih, w_hh)
+        if len(LAST_GRU_SYNC) < 64:
+            LAST_GRU_SYNC.append((sync, NG, "pv_gru_fwd"))
+        ctx.dims = (B, L, E, H, Hk, K3, Bpad, NG, Ep)
+        ctx.has_h0 = h0 is not None
+        ctx.sync = sync
+        ctx.mark_non_differentiable(hseq)
+        return out, hn, hseq
+
+    @staticmethod
+    def backward(ctx, dout, dhn, _dhseq):
+        x_bf, hseq, gsave, hall, w_ih, w_hh = ctx.saved_tensors
+        B, L, E, H, Hk, K3, Bpad, NG, Ep = ctx.dims
+        dev = x_bf.device
+        whhT = transpose_to_bf16(w_hh.contiguous(), 3 * H, H, H, K3)
+        dgi = torch.empty((L * Bpad, K3), dtype=BF16, device=dev)
+        dgh = torch.empty((L * Bpad, K3), dtype=BF16, device=dev)
+        dh0 = torch.empty((B, H), dtype=torch.float32, device=dev)
+        dbp = workspace("gru_dbias_part", NG * 4 * H, torch.float32, dev)
+        db_ih = torch.empty(3 * H, dtype=torch.float32, device=dev)
+        db_hh = torch.empty(3 * H, dtype=torch.float32, device=dev)
+        sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
+        if dout is not None:
+            dout = dout if dout.stride(2) == 1 else dout.contiguous()
+        dhn_c = None if dhn is None else dhn.contiguous()
+        _lib.call("pv_gru_bwd", _p(dout), 0 if dout is None else dout.stride(0), 0 if dout is None else dout.stride(1),
+                  _p(dhn_c), _p(gsave), _p(hall), _p(whhT), L, B, H, 0, _p(dgi), _p(dgh), _p(dh0), _p(dbp), _p(db_ih),
+                  _p(db_hh), _p(sync), GRU_MAX_WGS, _stream())
+        if len(LAST_GRU_SYNC) < 64:
+            LAST_GRU_SYNC.append((sync, NG, "pv_gru_bwd"))
+        Tt = L * Bpad
+        Tp = round_up(Tt, 64)
+        # dx = dgi W_ih  (time-major rows), then back to [B,L,E]
+        wihT = transpose_to_bf16(w_ih.contiguous(), 3 * H, E, E, K3)
+        dx_tm = gemm_nt(dgi, K3, wihT, K3, Tt, E, K3)
+        dx = dx_tm.view(L, Bpad, E)[:, :B].transpose(0, 1)
+        # dW_ih = dgi^T x ; dW_hh = dgh^T h_prev   (K = all time-major rows)
+        dgiT = transpose_to_bf16(dgi, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
+        xT = transpose_to_bf16(x_bf, Tt, E, Ep, Tp, out=workspace("gru_xT", E * Tp, BF16, dev).view(E, Tp))
+        dw_ih = gemm_nt(dgiT, Tp, xT, Tp, 3 * H, E, Tp)
+        dghT = transpose_to_bf16(dgh, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
+        hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
+        dw_hh = gemm_nt(dghT, Tp, hpT, Tp, 3 * H, H, Tp)
+        return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# embedding
+# ------------------------------------------------------------------------------------------------------------
+
+class EmbeddingLookup(torch.autograd.Function):
+    """nn.Embedding forward/backward (dialog_models.py:758-765, decoders.py:174): coalesced row gather;
+    backward = stable sort + segmented sum (no atomics, bitwise reproducible); padding row gets zero grad."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, padding_idx):
+        _need_cuda(weight, ids)
+        ids_c = ids.contiguous()
+        n, D = ids_c.numel(), weight.shape[1]
+        w = weight.contiguous()
+        out = torch.empty(tuple(ids.shape) + (D,), dtype=torch.float32, device=weight.device)
+        if n:
+            _lib.call("pv_embedding_gather", _p(w), w.shape[0], D, _p(ids_c), n, n, n, 0, 1, _p(out), D, None, 0,
+                      None, _stream())
+        ctx.save_for_backward(ids_c)
+        ctx.meta = (w.shape[0], D, -1 if padding_idx is None else padding_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids_c,) = ctx.saved_tensors
+        rows, D, pad = ctx.meta
+        n = ids_c.numel()
+        dev = dout.device
+        dw = torch.empty((rows, D), dtype=torch.float32, device=dev)
+        nbytes = _lib.load().pv_embedding_bwd_ws_bytes(max(n, 1))
+        ws = workspace("emb_bwd", nbytes, torch.uint8, dev)
+        g = dout.contiguous().view(-1, D)
+        _lib.call("pv_embedding_bwd", _p(g), D, _p(ids_c), n, max(n, 1), max(n, 1), 0, 1, rows, D, pad, 0, _p(dw),
+                  _p(ws), nbytes, _stream())
+        return dw, None, None
+
+
+def embedding(weight, ids, padding_idx=None):
+    return EmbeddingLookup.apply(weight, ids, padding_idx)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# small exact-fp32 linear
+# ------------------------------------------------------------------------------------------------------------
+
+def _lin(A, sam, sak, Bm, sbk, sbn, bias, Cm, ldc, M, N, K, accumulate=0, alpha=1.0, batch=1, bsa=0, bsb=0, bsc=0):
+    _lib.call("pv_linear_f32", _p(A), sam, sak, _p(Bm), sbk, sbn, _p(bias), _p(Cm), ldc, M, N, K, alpha, accumulate,
+              batch, bsa, bsb, bsc, _stream())
+
+
+class LinearF32(torch.autograd.Function):
+    """y = x W^T + b in exact fp32 (Hidden2Gaussian nn_lib.py:198-199, LinearConnector nn_lib.py:143,
+    Block linears dialog_models.py:258-263)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_cuda(x, weight, bias)
+        K = x.shape[-1]
+        N = weight.shape[0]
+        x2 = x.reshape(-1, K).contiguous()
+        M = x2.shape[0]
+        w = weight.contiguous()
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _lin(x2, K, 1, w, 1, K, None if bias is None else bias.contiguous(), y, N, M, N, K)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return y.view(tuple(x.shape[:-1]) + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = dy.reshape(M, N).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            _lin(dy2, N, 1, w, K, 1, None, dx, K, M, K, N)                 # dx = dy W
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            _lin(dy2, 1, N, x2, K, 1, None, dw, K, N, K, M)                # dW = dy^T x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, dtype=torch.float32, device=dy.device)
+            _lib.call("pv_colsum_f32", _p(dy2), M, N, N, _p(db), 0, _stream())
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return LinearF32.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# latent connectors
+# ------------------------------------------------------------------------------------------------------------
+
+class ReparamKL(torch.autograd.Function):
+    """z = mu_q + exp(lv_q) * eps and the row-wise Gaussian KL in one pass (mode 0: NormKLLoss
+    criterions.py:145-155; mode 1: gaussian_analytical_kl dialog_models.py:3215-3217)."""
+
+    @staticmethod
+    def forward(ctx, mu_q, lv_q, mu_p, lv_p, eps, mode, want_z, want_kl):
+        _need_cuda(mu_q, lv_q, mu_p, lv_p, eps)
+        B, Z = mu_q.shape
+        ts = [None if t is None else t.contiguous() for t in (mu_q, lv_q, mu_p, lv_p, eps)]
+        dev = mu_q.device
+        z = torch.empty((B, Z), dtype=torch.float32, device=dev) if want_z else None
+        kl = torch.empty(B, dtype=torch.float32, device=dev) if want_kl else None
+        _lib.call("pv_reparam_kl_fwd", _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), _p(ts[4]), B, Z, mode, _p(z),
+                  _p(kl), _stream())
+        ctx.ts = ts
+        ctx.mode = mode
+        outs = (z if want_z else torch.empty(0, device=dev), kl if want_kl else torch.empty(0, device=dev))
+        return outs
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        mq, lq, mp, lp, eps = ctx.ts
+        B, Z = mq.shape
+        dev = mq.device
+        dz = None if (dz is None or dz.numel() == 0) else dz.contiguous()
+        dkl = None if (dkl is None or dkl.numel() == 0) else dkl.contiguous()
+        dmq = torch.empty_like(mq)
+        dlq = torch.empty_like(lq)
+        dmp = torch.empty_like(mp) if mp is not None else None
+        dlp = torch.empty_like(lp) if lp is not None else None
+        _lib.call("pv_reparam_kl_bwd", _p(mq), _p(lq), _p(mp), _p(lp), _p(eps), _p(dz), _p(dkl), B, Z, ctx.mode,
+                  _p(dmq), _p(dlq), _p(dmp), _p(dlp), _stream())
+        return dmq, dlq, dmp, dlp, None, None, None, None
+
+
+def reparam_kl(mu_q, lv_q, mu_p=None, lv_p=None, eps=None, mode=0, want_z=True, want_kl=True):
+    z, kl = ReparamKL.apply(mu_q, lv_q, mu_p, lv_p, eps, mode, want_z, want_kl)
+    return (z if want_z else None), (kl if want_kl else None)
+
+
+class GumbelSoftmax(torch.autograd.Function):
+    """nn_lib.py:226-265 with the uniform noise `u` supplied (the reference draws it with CPU torch.rand)."""
+
+    @staticmethod
+    def forward(ctx, logits, u, tau, hard):
+        _need_cuda(logits, u)
+        rows, k = logits.shape
+        lg, uu = logits.contiguous(), u.contiguous()
+        dev = logits.device
+        y_soft = torch.empty((rows, k), dtype=torch.float32, device=dev)
+        y = torch.empty((rows, k), dtype=torch.float32, device=dev)
+        ids = torch.empty((rows, 1), dtype=torch.int64, device=dev)
+        _lib.call("pv_gumbel_softmax_fwd", _p(lg), _p(uu), rows, k, tau, 1 if hard else 0, _p(y_soft), _p(y),
+                  _p(ids), _stream())
+        ctx.save_for_backward(y_soft)
+        ctx.tau = tau
+        ctx.mark_non_differentiable(ids)
+        return y, ids
+
+    @staticmethod
+    def backward(ctx, dy, _dids):
+        (y_soft,) = ctx.saved_tensors
+        rows, k = y_soft.shape
+        dl = torch.empty_like(y_soft)
+        _lib.call("pv_softmax_bwd_rows", _p(y_soft), _p(dy.contiguous()), rows, k, 1.0 / ctx.tau, _p(dl), _stream())
+        return dl, None, None, None
+
+
+class CatRows(torch.autograd.Function):
+    """Per-row sum_j q (log q - log p) (mode 0, criterions.py:168-169) or -sum_j q log q (mode 1, :206-207)."""
+
+    @staticmethod
+    def forward(ctx, log_q, log_p, mode):
+        _need_cuda(log_q, log_p)
+        k = log_q.shape[-1]
+        lq = log_q.reshape(-1, k).contiguous()
+        rows = lq.shape[0]
+        lp = None
+        lp_n = 0
+        if mode == 0:
+            if log_p.numel() == 1:
+                lp, lp_n = log_p.reshape(1).contiguous().to(torch.float32), 1
+            else:
+                lp = log_p.expand_as(log_q).reshape(-1, k).contiguous()
+                lp_n = lp.numel()
+        out = torch.empty(rows, dtype=torch.float32, device=log_q.device)
+        _lib.call("pv_cat_rows_fwd", _p(lq), _p(lp), lp_n, rows, k, mode, _p(out), _stream())
+        ctx.save_for_backward(lq, lp if lp is not None else lq)
+        ctx.meta = (mode, lp_n, log_q.shape, None if log_p is None else log_p.shape)
+        return out.view(log_q.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, drow):
+        lq, lp = ctx.saved_tensors
+        mode, lp_n, qshape, pshape = ctx.meta
+        rows, k = lq.shape
+        dlq = torch.empty_like(lq)
+        want_p = mode == 0 and ctx.needs_input_grad[1] and lp_n == rows * k
+        dlp = torch.empty_like(lq) if want_p else None
+        _lib.call("pv_cat_rows_bwd", _p(lq), _p(lp) if mode == 0 else None, lp_n, _p(drow.contiguous().view(-1)), rows,
+                  k, mode, _p(dlq), _p(dlp), _stream())
+        if want_p:
+            dlp = dlp.view(qshape)
+            if tuple(pshape) != tuple(qshape):
+                dlp = dlp.sum_to_size(pshape)
+        return dlq.view(qshape), dlp, None
+
+
+class BMM(torch.autograd.Function):
+    """C[b] = A[b] @ B[b] in exact fp32 for [Bt,M,K] x [Bt,K,N] (any strides): the attention bmm's of
+    decoders.py:85-107."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_cuda(a, b)
+        Bt, M, K = a.shape
+        N = b.shape[2]
+        c = torch.empty((Bt, M, N), dtype=torch.float32, device=a.device)
+        _lin(a, a.stride(1), a.stride(2), b, b.stride(1), b.stride(2), None, c, N, M, N, K, batch=Bt,
+             bsa=a.stride(0), bsb=b.stride(0), bsc=M * N)
+        ctx.save_for_backward(a, b)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        Bt, M, K = a.shape
+        N = b.shape[2]
+        dc = dc.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:      # dA = dC B^T
+            da = torch.empty((Bt, M, K), dtype=torch.float32, device=a.device)
+            _lin(dc, N, 1, b, b.stride(2), b.stride(1), None, da, K, M, K, N, batch=Bt, bsa=M * N, bsb=b.stride(0),
+                 bsc=M * K)
+        if ctx.needs_input_grad[1]:      # dB = A^T dC
+            db = torch.empty((Bt, K, N), dtype=torch.float32, device=a.device)
+            _lin(a, a.stride(2), a.stride(1), dc, N, 1, None, db, N, K, N, M, batch=Bt, bsa=a.stride(0), bsb=M * N,
+                 bsc=K * N)
+        return da, db
+
+
+def bmm(a, b):
+    return BMM.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# decoder attention pieces
+# ------------------------------------------------------------------------------------------------------------
+
+class AdditiveScores(torch.autograd.Function):
+    """score[b,i,j] = qw . tanh(k[b,j] + q[b,i]) + qb (decoders.py:89-95) without the 4-D intermediate."""
+
+    @staticmethod
+    def forward(ctx, q, k, qw, qb):
+        _need_cuda(q, k, qw, qb)
+        q, k, qw = q.contiguous(), k.contiguous(), qw.contiguous()
+        B, Lo, D = q.shape
+        Li = k.shape[1]
+        score = torch.empty((B, Lo, Li), dtype=torch.float32, device=q.device)
+        _lib.call("pv_additive_scores_fwd", _p(q), _p(k), _p(qw), _p(qb), B, Lo, Li, D, _p(score), _stream())
+        ctx.save_for_backward(q, k, qw)
+        ctx.has_qb = qb is not None
+        return score
+
+    @staticmethod
+    def backward(ctx, ds):
+        q, k, qw = ctx.saved_tensors
+        B, Lo, D = q.shape
+        Li = k.shape[1]
+        ds = ds.contiguous()
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        dqw = torch.empty_like(qw)
+        part = workspace("attn_dqw_part", B * Lo * D, torch.float32, q.device)
+        _lib.call("pv_additive_scores_bwd", _p(q), _p(k), _p(qw), _p(ds), B, Lo, Li, D, _p(dq), _p(dk), _p(part),
+                  _p(dqw), _stream())
+        dqb = masked_sum(ds.view(-1))[0:1] if ctx.has_qb else None
+        return dq, dk, dqw, dqb
+
+
+def additive_scores(q, k, qw, qb=None):
+    return AdditiveScores.apply(q, k, qw, qb)
+
+
+class SoftmaxLastDim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        n = x.shape[-1]
+        x2 = x.contiguous().view(-1, n)
+        y = torch.empty_like(x2)
+        _lib.call("pv_softmax_rows", _p(x2), x2.shape[0], n, _p(y), _stream())
+        ctx.save_for_backward(y)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        _lib.call("pv_softmax_rows_bwd", _p(y), _p(dy.contiguous()), y.shape[0], y.shape[1], _p(dx), _stream())
+        return dx.view(dy.shape)
+
+
+def softmax_lastdim(x):
+    return SoftmaxLastDim.apply(x)
+
+
+class _Unary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        _need_cuda(x)
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        _lib.call("pv_unary_f32", _p(xc), None, xc.numel(), op, _p(y), _stream())
+        ctx.save_for_backward(y if op == 0 else xc)
+        ctx.op = op
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (s,) = ctx.saved_tensors
+        dx = torch.empty_like(s)
+        _lib.call("pv_unary_f32", _p(s), _p(dy.contiguous()), s.numel(), ctx.op + 1, _p(dx), _stream())
+        return dx, None
+
+
+def tanh(x):
+    return _Unary.apply(x, 0)
+
+
+def gelu(x):
+    return _Unary.apply(x, 2)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# loss assembly helpers
+# ------------------------------------------------------------------------------------------------------------
+
+class MaskedSum(torch.autograd.Function):
+    """[sum_i x[i] over mask[i] != ignore, count] as a 2-element device tensor (single fixed-order reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, ignore):
+        _need_cuda(x, mask)
+        xc = x.contiguous().view(-1)
+        mc = None if mask is None else mask.contiguous().view(-1)
+        out = masked_sum(xc, mc, ignore)
+        ctx.save_for_backward(mc if mc is not None else xc)
+        ctx.meta = (mask is not None, ignore, x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (m,) = ctx.saved_tensors
+        has_mask, ignore, shape = ctx.meta
+        g = dout[0]
+        dx = (m != ignore).to(torch.float32) * g if has_mask else g.expand(m.shape).clone()
+        return dx.view(shape), None, None
+
+
+def sum(x):
+    return MaskedSum.apply(x, None, 0)[0]
+
+
+def mean(x):
+    return MaskedSum.apply(x, None, 0)[0] / x.numel()
+
+
+class GatherNLL(torch.autograd.Function):
+    """Dense-input path of NLLEntropy/Perplexity (criterions.py:57-63): -logp[t, target[t]], 0 for pads."""
+
+    @staticmethod
+    def forward(ctx, logp, target, ignore):
+        _need_cuda(logp, target)
+        lp = logp.contiguous()
+        T, V = lp.shape
+        tgt = target.contiguous()
+        out = torch.empty(T, dtype=torch.float32, device=lp.device)
+        _lib.call("pv_pick_nll_fwd", _p(lp), _p(tgt), ignore, T, V, _p(out), _stream())
+        ctx.save_for_backward(tgt)
+        ctx.meta = (T, V, ignore)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tgt,) = ctx.saved_tensors
+        T, V, ignore = ctx.meta
+        dl = torch.empty((T, V), dtype=torch.float32, device=dout.device)
+        _lib.call("pv_pick_nll_bwd", _p(dout.contiguous()), _p(tgt), ignore, T, V, _p(dl), _stream())
+        return dl, None, None

@@ -1,0 +1,62 @@
+"""Optimizer tail of the training step on device: global-norm clip, the reference's skip guards and Adam over
+ONE flat buffer (main_pretrain.py:207-225,268-269; dialog_models.py:122-131), two kernel launches + one small
+guard kernel per step and no host synchronisation."""
+import struct
+
+import torch
+
+from . import _lib
+from .ops import _p, _stream
+
+
+class FlatAdam(object):
+    """Re-homes every parameter (and its .grad) as a view into flat fp32 buffers, then steps them with
+    pv_grad_guard + pv_adam_step.  torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay.
+
+    lr schedule: transformers.get_constant_schedule_with_warmup -- the k-th applied step (k = 0, 1, ...) runs
+    at lr * min(1, k / warmup_steps).  `guards=True` adds the reference's skip rules (non-finite norm, up to 5
+    in a row; norm > 3x its running mean)."""
+
+    def __init__(self, params, lr, max_norm, warmup_steps=0, betas=(0.9, 0.999), eps=1e-8, guards=True):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdam: no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam needs parameters on an MI355X device; there is no CPU fallback")
+        self.lr, self.max_norm, self.warmup, self.betas, self.eps, self.guards = lr, max_norm, warmup_steps, betas, eps, guards
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4            # keep every view 16-byte aligned
+        self.n = n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, offs):
+            self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+            p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self.offsets = offs
+        self.state = torch.zeros(_lib.load().pv_optim_state_bytes(), dtype=torch.uint8, device=dev)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-attach the view
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def step(self):
+        st = _stream()
+        _lib.call("pv_grad_guard", _p(self.flat_g), self.n, _p(self.state), self.max_norm, self.lr, self.warmup,
+                  self.betas[0], self.betas[1], 1 if self.guards else 0, st)
+        _lib.call("pv_adam_step", _p(self.flat_p), _p(self.flat_g), _p(self.exp_avg), _p(self.exp_avg_sq), self.n,
+                  _p(self.state), self.betas[0], self.betas[1], self.eps, st)
+
+    def state_dict_host(self):
+        """Copy the device-side guard state to the host (synchronises; logging / tests only)."""
+        raw = bytes(self.state[:48].cpu().numpy())
+        avg, have, jump, cnt, t, norm, coef, skip, lr, bc1, bc2, skipped = struct.unpack("fiiiiffifffi", raw)
+        return dict(avg_norm=avg, jump_cnt=jump, batch_cnt=cnt, adam_step=t, last_norm=norm, clip_coef=coef,
+                    skip=skip, lr=lr, skipped_total=skipped)

@@ -1,0 +1,284 @@
+"""GPU parity tests, kernel level: every call goes through the C ABI (ctypes) and is checked against the CPU
+oracle (oracle/ref_modules.py) or an exact integer / sequential-order reference on the same seeded inputs.
+
+Tolerances (stated per test): integer / index / byte work is bit-exact; fp32 kernels 1e-5; kernels that round
+operands to bf16 for the MFMA are compared (a) tightly against the oracle evaluated on the SAME bf16-rounded
+operands and (b) loosely against the pure-fp32 oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_modules as R
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pevae_amd import ops
+    info = ops.device_info()
+    assert "gfx950" in info["arch"], info
+    return torch.device("cuda:0")
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def test_gemm_exact_integers(dev):
+    """A = small integers (exact in bf16), asymmetric B: catches row/col swaps and fragment-map mistakes."""
+    from pevae_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for (M, N, K) in [(128, 128, 64), (200, 300, 128), (77, 513, 192), (1, 5, 64)]:
+        A = torch.randint(-3, 4, (M, K), generator=g).float()
+        Bm = (torch.randint(-3, 4, (N, K), generator=g) + torch.arange(N).view(-1, 1) % 3).float()
+        bias = torch.randint(-5, 6, (N,), generator=g).float()
+        want = A @ Bm.t() + bias
+        out = ops.gemm_nt(A.to(dev).to(torch.bfloat16), K, Bm.to(dev).to(torch.bfloat16), K, M, N, K,
+                          bias=bias.to(dev))
+        outb = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt(A.to(dev).to(torch.bfloat16), K, Bm.to(dev).to(torch.bfloat16), K, M, N, K, out_bf16=outb)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), want), (M, N, K)
+        assert torch.equal(outb.float().cpu(), bf(A @ Bm.t())), (M, N, K)
+    # A = I with asymmetric B
+    K = 64
+    A = torch.eye(K)
+    Bm = torch.arange(K * K).view(K, K).float() % 17
+    out = ops.gemm_nt(A.to(dev).to(torch.bfloat16), K, Bm.to(dev).to(torch.bfloat16), K, K, K, K)
+    assert torch.equal(out.cpu(), Bm.t().contiguous())
+
+
+@pytest.mark.parametrize("T,V,H,temp", [(300, 1000, 64, 1.0), (130, 37, 16, 0.7), (64, 20004, 128, 1.0)])
+def test_vocab_nll_fused(dev, T, V, H, temp):
+    from pevae_amd import ops
+    torch.manual_seed(2)
+    hid = torch.randn(T, H) * 0.7
+    W = torch.randn(V, H) * 0.2
+    b = torch.randn(V) * 0.1
+    tgt = torch.randint(1, V, (T,))
+    tgt[::7] = 0                                     # ignored (pad) tokens
+    wtok = torch.rand(T) + 0.5
+    # oracle on bf16-rounded operands (what the MFMA sees), fp32 math
+    hr, Wr = bf(hid).requires_grad_(), bf(W).requires_grad_()
+    br = b.clone().requires_grad_()
+    logp = R.log_softmax_rows((hr @ Wr.t() + br) / temp)
+    nll_ref = -(logp.gather(1, tgt.unsqueeze(1)).squeeze(1)) * (tgt != 0)
+    (nll_ref * wtok).sum().backward()
+    hd, Wd, bd = hid.to(dev).requires_grad_(), W.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    nll, lse = ops.VocabNLL.apply(hd, Wd, bd, tgt.to(dev), 1.0 / temp, 0, None, None)
+    (nll * wtok.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nll.detach().cpu().numpy(), nll_ref.detach().numpy(), rtol=2e-4, atol=2e-4)
+    lse_ref = torch.logsumexp((hr @ Wr.t() + br) / temp, dim=1)
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.detach().numpy(), rtol=2e-4, atol=2e-4)
+    # gradients: P is rounded to bf16 before the two gradient GEMMs -> 1e-2 of the largest entry
+    assert relerr(hd.grad, hr.grad) < 1.5e-2
+    assert relerr(Wd.grad, Wr.grad) < 1.5e-2
+    assert relerr(bd.grad, br.grad) < 1.5e-2
+    # dense path: same numbers as a tensor
+    dense = ops.VocabLogProbDense.apply(hid.to(dev), W.to(dev), b.to(dev), 1.0 / temp)
+    np.testing.assert_allclose(dense.cpu().numpy(), logp.detach().numpy(), rtol=2e-4, atol=3e-4)
+    # pure fp32 oracle, loose: bf16 operand rounding only
+    logp32 = R.log_softmax_rows((hid @ W.t() + b) / temp)
+    nll32 = -(logp32.gather(1, tgt.unsqueeze(1)).squeeze(1)) * (tgt != 0)
+    assert float((nll.detach().cpu() - nll32).abs().max()) < 0.05
+
+
+def gru_ref(x, h0, w_ih, w_hh, b_ih, b_hh, emulate_bf16):
+    """oracle GRU (R.gru_cell arithmetic) with optional bf16 rounding of the MFMA operands (straight-through)."""
+    def q(t):
+        return t + (bf(t) - t).detach() if emulate_bf16 else t
+    B, L, _ = x.shape
+    H = w_hh.shape[1]
+    h = h0
+    outs = []
+    xp = q(x) @ q(w_ih).t() + b_ih
+    for t in range(L):
+        gh = q(h) @ q(w_hh).t() + b_hh
+        r = torch.sigmoid(xp[:, t, :H] + gh[:, :H])
+        z = torch.sigmoid(xp[:, t, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(xp[:, t, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        outs.append(h)
+    return torch.stack(outs, 1), h
+
+
+@pytest.mark.parametrize("B,L,E,H", [(4, 7, 12, 16), (37, 5, 20, 32), (64, 6, 100, 128), (256, 4, 100, 512)])
+def test_gru_layer(dev, B, L, E, H):
+    from pevae_amd import ops
+    torch.manual_seed(3)
+    s = 1.0 / np.sqrt(H)
+    x = torch.randn(B, L, E)
+    h0 = torch.randn(B, H) * 0.5
+    w_ih, w_hh = (torch.rand(3 * H, E) * 2 - 1) * s, (torch.rand(3 * H, H) * 2 - 1) * s
+    b_ih, b_hh = (torch.rand(3 * H) * 2 - 1) * s, (torch.rand(3 * H) * 2 - 1) * s
+    w_out, w_hn = torch.randn(B, L, H), torch.randn(B, H)
+    cpu = [t.clone().requires_grad_() for t in (x, h0, w_ih, w_hh, b_ih, b_hh)]
+    out_r, hn_r = gru_ref(*cpu, emulate_bf16=True)
+    ((out_r * w_out).sum() + (hn_r * w_hn).sum()).backward()
+    gpu = [t.to(dev).requires_grad_() for t in (x, h0, w_ih, w_hh, b_ih, b_hh)]
+    out, hn, hseq = ops.GRULayer.apply(*gpu, True)
+    ((out * w_out.to(dev)).sum() + (hn * w_hn.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    # (a) vs the oracle on bf16-rounded MFMA operands: only summation order differs
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_r.detach().numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(hn.detach().cpu().numpy(), hn_r.detach().numpy(), rtol=0, atol=2e-3)
+    # (b) vs the pure fp32 oracle (R.run_rnn through EncoderRNN arithmetic)
+    out32, hn32 = gru_ref(x, h0, w_ih, w_hh, b_ih, b_hh, emulate_bf16=False)
+    assert float((out.detach().cpu() - out32).abs().max()) < 3e-2
+    # state sequence handed to downstream GEMMs is the bf16 image of `out`, time-major
+    Hk, K3, Bpad, NG = ops.gru_geometry(B, H)
+    hs = hseq.float().cpu().view(L + 1, Bpad, Hk)
+    assert torch.equal(hs[1:, :B, :H], bf(out.detach().cpu()).transpose(0, 1))
+    assert torch.equal(hs[0, :B, :H], bf(h0))
+    # gradients: gate gradients are rounded to bf16 for the MFMA GEMMs
+    names = ("x", "h0", "w_ih", "w_hh", "b_ih", "b_hh")
+    for n, a, b in zip(names, gpu, cpu):
+        assert relerr(a.grad, b.grad) < 2.5e-2, n
+
+
+def test_gru_no_h0_and_nograd(dev):
+    from pevae_amd import ops
+    torch.manual_seed(4)
+    B, L, E, H = 5, 3, 8, 16
+    x = torch.randn(B, L, E)
+    w = [torch.randn(3 * H, E) * .2, torch.randn(3 * H, H) * .2, torch.randn(3 * H) * .1, torch.randn(3 * H) * .1]
+    with torch.no_grad():
+        out, hn, _ = ops.GRULayer.apply(x.to(dev), None, *[t.to(dev) for t in w], False)
+    out_r, hn_r = gru_ref(x, torch.zeros(B, H), *w, emulate_bf16=True)
+    ops.gru_check_all()
+    np.testing.assert_allclose(out.cpu().numpy(), out_r.numpy(), atol=2e-3, rtol=0)
+
+
+def test_embedding_gather_scatter_bit_exact(dev):
+    from pevae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for rows, D, shape in [(50, 100, (16, 9)), (7, 256, (33,)), (20004, 100, (8, 50))]:
+        table = torch.randn(rows, D, generator=g)
+        ids = torch.randint(0, rows, shape, generator=g)
+        ids.view(-1)[::3] = ids.view(-1)[0]                # heavy duplicates
+        ids.view(-1)[1::5] = 0                             # padding rows
+        grad = torch.randn(*shape, D, generator=g)
+        tw = table.to(dev).requires_grad_()
+        out = ops.embedding(tw, ids.to(dev), 0)
+        out.backward(grad.to(dev))
+        torch.cuda.synchronize()
+        assert torch.equal(out.detach().cpu(), table[ids])                    # gather: bit-exact
+        want = np.zeros((rows, D), dtype=np.float32)
+        gf = grad.view(-1, D).numpy()
+        for r, i in enumerate(ids.view(-1).tolist()):                        # occurrence order, fp32
+            if i != 0:
+                want[i] += gf[r]
+        assert np.array_equal(tw.grad.cpu().numpy(), want)                   # scatter-add: bit-exact
+        tw.grad = None
+        out = ops.embedding(tw, ids.to(dev), 0)
+        out.backward(grad.to(dev))
+        assert np.array_equal(tw.grad.cpu().numpy(), want)                   # and run-to-run identical
+    # empty input
+    e = ops.embedding(table.to(dev), torch.zeros((0, 4), dtype=torch.long, device=dev), 0)
+    assert e.shape == (0, 4, D)
+
+
+def test_reparam_kl(dev):
+    from pevae_amd import ops
+    torch.manual_seed(6)
+    B, Z = 37, 24
+    for mode in (0, 1):
+        cpu = [torch.randn(B, Z).requires_grad_() for _ in range(4)]
+        eps = torch.rand(B, Z)
+        wz, wk = torch.randn(B, Z), torch.randn(B)
+        mq, lq, mp, lp = cpu
+        z_r = R.reparameterization(mq, lq * 0.3, eps)
+        if mode == 0:
+            t = 1.0 + (lq * 0.3 - lp * 0.3) - (mp - mq) ** 2 / torch.exp(lp * 0.3) - torch.exp(lq * 0.3) / torch.exp(lp * 0.3)
+            kl_r = -0.5 * t.sum(1)
+        else:
+            l1, l2 = lq * 0.3, lp * 0.3
+            kl_r = (-0.5 + l2 - l1 + 0.5 * (torch.exp(2 * l1) + (mq - mp) ** 2) / torch.exp(2 * l2)).sum(1)
+        ((z_r * wz).sum() + (kl_r * wk).sum()).backward()
+        gpu = [t.detach().to(dev).requires_grad_() for t in cpu]
+        z, kl = ops.reparam_kl(gpu[0], gpu[1] * 0.3, gpu[2], gpu[3] * 0.3, eps.to(dev), mode=mode)
+        ((z * wz.to(dev)).sum() + (kl * wk.to(dev)).sum()).backward()
+        np.testing.assert_allclose(z.detach().cpu().numpy(), z_r.detach().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(kl.detach().cpu().numpy(), kl_r.detach().numpy(), rtol=2e-5, atol=1e-4)
+        for a, b in zip(gpu, cpu):
+            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_linear_and_bmm(dev):
+    from pevae_amd import ops
+    torch.manual_seed(7)
+    for M, K, N in [(256, 512, 64), (6, 16, 8), (100, 768, 300)]:
+        x, w, b = torch.randn(M, K), torch.randn(N, K) * 0.1, torch.randn(N)
+        g = torch.randn(M, N)
+        c = [t.clone().requires_grad_() for t in (x, w, b)]
+        (c[0] @ c[1].t() + c[2]).backward(g)
+        d = [t.to(dev).requires_grad_() for t in (x, w, b)]
+        y = ops.linear(*d)
+        y.backward(g.to(dev))
+        np.testing.assert_allclose(y.detach().cpu().numpy(), (x @ w.t() + b).numpy(), rtol=1e-5, atol=2e-5)
+        for a, r in zip(d, c):
+            np.testing.assert_allclose(a.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-4, atol=1e-4)
+    a, b2 = torch.randn(3, 5, 16), torch.randn(3, 6, 16)
+    ca, cb = a.clone().requires_grad_(), b2.clone().requires_grad_()
+    g = torch.randn(3, 5, 6)
+    torch.bmm(ca, cb.transpose(1, 2)).backward(g)
+    da, db = a.to(dev).requires_grad_(), b2.to(dev).requires_grad_()
+    y = ops.bmm(da, db.transpose(1, 2))
+    y.backward(g.to(dev))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), torch.bmm(a, b2.transpose(1, 2)).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(da.grad.cpu().numpy(), ca.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(db.grad.cpu().numpy(), cb.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_adam_clip_guard_matches_torch(dev):
+    """pv_grad_guard + pv_adam_step vs clip_grad_norm_ + torch.optim.Adam + constant-with-warmup LambdaLR."""
+    from pevae_amd.optim import FlatAdam
+    torch.manual_seed(8)
+    shapes = [(33, 7), (129,), (5, 5, 3)]
+    ps = [torch.randn(*s) for s in shapes]
+    ref = [p.clone().requires_grad_() for p in ps]
+    opt = torch.optim.Adam(ref, lr=1e-2)
+    warm = 3
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: k / max(1.0, warm) if k < warm else 1.0)
+    mine = [torch.nn.Parameter(p.clone().to(dev)) for p in ps]
+    fa = FlatAdam(mine, lr=1e-2, max_norm=1.0, warmup_steps=warm, guards=False)
+    for step in range(6):
+        grads = [torch.randn(*s) * (3.0 if step % 2 else 0.05) for s in shapes]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        norm = torch.nn.utils.clip_grad_norm_(ref, 1.0, 2)
+        opt.step()
+        sched.step()
+        fa.zero_grad()
+        for p, g in zip(mine, grads):
+            p.grad.copy_(g.to(dev))
+        fa.step()
+        st = fa.state_dict_host()
+        assert abs(st["last_norm"] - float(norm)) < 1e-4 * float(norm)
+        for a, b in zip(mine, ref):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_guard_skips_nonfinite_and_spikes(dev):
+    from pevae_amd.optim import FlatAdam
+    p = torch.nn.Parameter(torch.ones(64, device=dev))
+    fa = FlatAdam([p], lr=0.1, max_norm=5.0, warmup_steps=0, guards=True)
+    fa.zero_grad(); p.grad.fill_(0.1); fa.step()
+    after1 = p.detach().clone()
+    assert not torch.equal(after1, torch.ones(64, device=dev))
+    fa.zero_grad(); p.grad.fill_(float("nan")); fa.step()            # main_pretrain.py:213-217
+    assert torch.equal(p.detach(), after1) and fa.state_dict_host()["skip"] == 1
+    fa.zero_grad(); p.grad.fill_(10.0); fa.step()                    # > 3x running mean, :219-222
+    assert torch.equal(p.detach(), after1) and fa.state_dict_host()["skipped_total"] == 2
+    fa.zero_grad(); p.grad.fill_(0.1); fa.step()
+    assert not torch.equal(p.detach(), after1)

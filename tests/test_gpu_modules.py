@@ -1,0 +1,258 @@
+"""GPU parity tests, module level: the drop-in classes (same constructors / forward signatures / state_dict
+keys as the reference) are loaded with the parameters exported from the reference and compared with the golden
+outputs and gradients the reference produced (tests/golden/*.npz, made by oracle/make_golden.py).
+
+Tolerances: fp32 kernels (connectors, criterions, attention) 1e-4; modules whose MFMA operands are bf16
+(GRU recurrence, vocabulary projection) 3e-2 absolute on O(1) activations / log-probs and 4e-2 of the largest
+entry on gradients; symbols / indices / lengths bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, load_params
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def T(a, dev=None):
+    t = torch.from_numpy(np.array(a))
+    return t if dev is None else t.to(dev)
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), np.asarray(b), rtol=rtol, atol=atol)
+
+
+def relmax(a, b):
+    a = a.detach().cpu().double().numpy()
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def check_grads(module, g, tol):
+    n = 0
+    for k, p in module.named_parameters():
+        if "g." + k in g:
+            assert relmax(p.grad, g["g." + k]) < tol, k
+            n += 1
+    assert n > 0
+
+
+@pytest.mark.parametrize("tag,kw", [("gru", {}), ("gru_mid", {}), ("gru_bi", dict(bidirection=True)),
+                                    ("gru_2l", dict(n_layers=2))])
+def test_encoder_rnn(dev, tag, kw):
+    from pevae_amd.enc2dec.encoders import EncoderRNN
+    from pevae_amd import ops
+    g = load_golden("encoder_" + tag)
+    B, L, E = g["x"].shape
+    H = g["h0"].shape[-1]
+    enc = load_params(EncoderRNN(E, H, **kw), g).to(dev)
+    x = T(g["x"], dev).requires_grad_()
+    out, hn = enc(x, init_state=T(g["h0"], dev))
+    ((out * T(g["w_out"], dev)).sum() + (hn * T(g["w_hid"], dev)).sum()).backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    close(out, g["out"], rtol=0, atol=3e-2)
+    close(hn, g["hn"], rtol=0, atol=3e-2)
+    assert relmax(x.grad, g["dx"]) < 4e-2
+    check_grads(enc, g, 4e-2)
+    out0, hn0 = enc(T(g["x"], dev))
+    close(out0, g["out_nostate"], rtol=0, atol=3e-2)
+    close(hn0, g["hn_nostate"], rtol=0, atol=3e-2)
+
+
+def test_encoder_errors(dev):
+    from pevae_amd.enc2dec.encoders import EncoderRNN
+    with pytest.raises(ValueError):
+        EncoderRNN(8, 16, rnn_cell="rnn")                       # base_modules.py:39
+    enc = EncoderRNN(8, 16)
+    with pytest.raises(RuntimeError):                            # CPU tensors: no fallback
+        enc(torch.randn(2, 3, 8))
+
+
+@pytest.mark.parametrize("tag,kw,lat", [("gru", {}, 0), ("gru_latent", {}, 5),
+                                        ("gru_temp", dict(softmax_temperature=0.7), 0)])
+def test_decoder_teacher_forcing(dev, tag, kw, lat):
+    from pevae_amd.enc2dec import decoders as D
+    from pevae_amd import criterions, ops
+    from oracle import ref_modules as R
+    g = load_golden("decoder_tf_" + tag)
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E + lat, H, 1, 2, 3, rnn_cell="gru", use_gpu=True, embedding=emb, **kw), g).to(dev)
+    h0 = T(g["h0"], dev).requires_grad_()
+    latent = T(g["latent"], dev) if lat else None
+    outs, hid, ret = dec(B, T(g["ids"], dev), h0, mode=D.TEACH_FORCE, latent_variable=latent)
+    assert isinstance(outs, D.DeferredLogProbs) and tuple(outs.size()) == (B, L, V)
+    assert ret["length"] == g["length"].tolist() and ret["sequence"] == []
+    # dense view == the reference's returned tensor; gradient of sum(logp * w) as in the golden
+    logp = outs.materialize()
+    (logp * T(g["w"], dev)).sum().backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    close(logp, g["logp"], rtol=0, atol=3e-2)
+    close(hid, g["hid"], rtol=0, atol=3e-2)
+    assert relmax(h0.grad, g["dh0"]) < 4e-2
+    check_grads(dec, g, 4e-2)
+    # fused path (no logits): NLLEntropy / Perplexity on the deferred object vs the oracle criterions on the golden
+    labels = T(g["ids"])[:, 1:]
+    labels = torch.cat([labels, torch.zeros(B, 1, dtype=torch.long)], 1)
+    dec.zero_grad()
+    outs2, _, _ = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.TEACH_FORCE, latent_variable=latent)
+    nll = criterions.NLLEntropy(0, None)(outs2, labels.to(dev))
+    ppl = criterions.Perplexity(0, None)(outs2, labels.to(dev))
+    nllw = criterions.NLLEntropy(0, None, avg_type="word")(outs2, labels.to(dev))
+    nll.backward()
+    want = R.NLLEntropy(0, None)(T(g["logp"]), labels)
+    assert abs(float(nll) - float(want)) < 2e-2 * abs(float(want))
+    assert abs(float(ppl) - float(R.Perplexity(0, None)(T(g["logp"]), labels))) < 3e-2 * float(ppl)
+    assert abs(float(torch.log(ppl)) - float(nllw)) < 1e-5
+    assert outs2._dense is None                                   # the fused path never built [B,L,V]
+    # gradient of the fused NLL vs autograd through the oracle decoder with the same parameters
+    ref = load_params(R.DecoderRNN(V, L, E + lat, H, 1, 2, 3, rnn_cell="gru", use_gpu=False,
+                                   embedding=torch.nn.Embedding(V, E, padding_idx=0), **kw), g)
+    lp_ref, _, _ = ref(B, T(g["ids"]), T(g["h0"]), mode=R.TEACH_FORCE, latent_variable=T(g["latent"]) if lat else None)
+    R.NLLEntropy(0, None)(lp_ref, labels).backward()
+    for (k, p), (k2, p2) in zip(dec.named_parameters(), ref.named_parameters()):
+        assert k == k2
+        assert relmax(p.grad, p2.grad.numpy()) < 5e-2, k
+
+
+@pytest.mark.parametrize("tag,mask_unk", [("greedy", False), ("greedy_maskunk", True)])
+def test_decoder_gen_greedy(dev, tag, mask_unk):
+    from pevae_amd.enc2dec import decoders as D
+    g = load_golden("decoder_gen_" + tag)
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb, mask_unk=mask_unk), g).to(dev)
+    dec.eval()
+    with torch.no_grad():
+        logp, hid, ret = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="greedy")
+    seq = torch.cat(ret["sequence"], dim=1).cpu()
+    want = T(g["seq"])
+    # a token may legitimately flip only where the reference's top-2 log-probs are within bf16 noise
+    ref_lp = T(g["logp"])
+    for b in range(B):
+        for t in range(L):
+            if seq[b, t] != want[b, t]:
+                top2 = ref_lp[b, t].topk(2)[0]
+                assert float(top2[0] - top2[1]) < 3e-2, (b, t)
+                break                                           # later steps diverge after a flip
+        else:
+            assert ret["length"][b] == int(g["length"][b])
+    close(logp[:, 0], g["logp"][:, 0], rtol=0, atol=3e-2)
+    with pytest.raises(ValueError):
+        dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="bogus")
+
+
+@pytest.mark.parametrize("mode", ["dot", "general", "cat"])
+def test_attention(dev, mode):
+    from pevae_amd.enc2dec.decoders import Attention
+    g = load_golden("attention_" + mode)
+    att = load_params(Attention(16, 16, mode, project=True), g).to(dev)
+    out, ctx = T(g["out"], dev).requires_grad_(), T(g["ctx"], dev).requires_grad_()
+    y, a = att(out, ctx)
+    (y * T(g["w"], dev)).sum().backward()
+    close(y, g["y"]); close(a, g["attn"])
+    close(out.grad, g["dout"], rtol=1e-4, atol=2e-5); close(ctx.grad, g["dctx"], rtol=1e-4, atol=2e-5)
+    for k, p in att.named_parameters():
+        close(p.grad, g["g." + k], rtol=2e-4, atol=2e-5)
+    with pytest.raises(ValueError):
+        Attention(16, 16, "nope").to(dev)(out, ctx)
+
+
+def test_connectors(dev):
+    from pevae_amd import nn_lib
+    g = load_golden("hidden2gaussian")
+    m = load_params(nn_lib.Hidden2Gaussian(16, 8), g).to(dev)
+    x = T(g["x"], dev).requires_grad_()
+    mu, lv = m(x)
+    ((mu * T(g["wm"], dev)).sum() + (lv * T(g["wl"], dev)).sum()).backward()
+    close(mu, g["mu"]); close(lv, g["logvar"]); close(x.grad, g["dx"])
+    for k, p in m.named_parameters():
+        close(p.grad, g["g." + k])
+    g = load_golden("hidden2gaussian_lstm")
+    m = load_params(nn_lib.Hidden2Gaussian(16, 8, is_lstm=True), g).to(dev)
+    mu, lv = m((T(g["h"], dev), T(g["c"], dev)))
+    close(mu, g["mu"]); close(lv, g["logvar"])
+    g = load_golden("linear_connector")
+    m = load_params(nn_lib.LinearConnector(8, 16, False), g).to(dev)
+    z = T(g["z"], dev).requires_grad_()
+    y = m(z)
+    (y * T(g["w"], dev)).sum().backward()
+    close(y, g["y"]); close(z.grad, g["dz"])
+    g = load_golden("linear_connector_lstm")
+    m = load_params(nn_lib.LinearConnector(8, 16, True), g).to(dev)
+    yh, yc = m(T(g["z"], dev))
+    close(yh, g["yh"]); close(yc, g["yc"])
+    g = load_golden("greedy_connector")
+    y, ids = nn_lib.GreedyConnector()(T(g["logits"], dev), True, return_max_id=True)
+    assert torch.equal(ids.cpu(), T(g["ids"])); close(y, g["y"])
+
+
+@pytest.mark.parametrize("tag,kw", [("soft", {}), ("hard", dict(hard=True, return_max_id=True)),
+                                    ("st", dict(straight_through=True))])
+def test_gumbel_connector(dev, tag, kw):
+    from pevae_amd import nn_lib
+    g = load_golden("gumbel_" + tag)
+    logits = T(g["logits"], dev).requires_grad_()
+    res = nn_lib.GumbelConnector()(logits, float(g["tau"]), True, u=T(g["u"], dev), **kw)
+    y, ids = res if isinstance(res, tuple) else (res, None)
+    (y * T(g["w"], dev)).sum().backward()
+    close(y, g["y"], rtol=1e-5, atol=2e-6)
+    close(logits.grad, g["dlogits"], rtol=1e-4, atol=2e-6)
+    if ids is not None:
+        assert torch.equal(ids.cpu(), T(g["ids"]))             # arg-max ids: bit-exact
+    torch.manual_seed(42)                                       # the reference's own CPU draw (nn_lib.py:231)
+    res2 = nn_lib.GumbelConnector()(T(g["logits"], dev), float(g["tau"]), True, **kw)
+    close(res2[0] if isinstance(res2, tuple) else res2, g["y"], rtol=1e-5, atol=2e-6)
+
+
+def test_criterions_dense_and_kl(dev):
+    from pevae_amd import criterions as C
+    g = load_golden("criterions_nll")
+    labels = T(g["labels"], dev)
+    for avg in ("seq", "word", None):
+        logp = T(g["logp"], dev).requires_grad_()
+        v = C.NLLEntropy(0, None, avg_type=avg)(logp, labels)
+        v.backward()
+        close(v, g["nll_%s" % avg], rtol=1e-5); close(logp.grad, g["dlogp_%s" % avg], rtol=1e-5, atol=1e-7)
+    logp = T(g["logp"], dev).requires_grad_()
+    v = C.Perplexity(0, None)(logp, labels)
+    v.backward()
+    close(v, g["ppl"], rtol=1e-5); close(logp.grad, g["dlogp_ppl"], rtol=1e-4, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        C.NLLEntropy(0, None, avg_type="bogus")                 # criterions.py:52
+
+    g = load_golden("criterions_normkl")
+    for ua in (False, True):
+        ts = [T(g[k], dev).requires_grad_() for k in ("mq", "lq", "mp", "lp")]
+        v = C.NormKLLoss(unit_average=ua)(ts[0], ts[1] * 0.5, ts[2], ts[3] * 0.5)
+        v.backward()
+        close(v, g["kl_ua%d" % ua], rtol=2e-5)
+        for n, t in zip(("mq", "lq", "mp", "lp"), ts):
+            close(t.grad, g["d%s_ua%d" % (n, ua)], rtol=1e-4, atol=1e-6)
+    same = C.NormKLLoss()(T(g["mq"], dev), T(g["lq"], dev), T(g["mq"], dev), T(g["lq"], dev))
+    assert abs(float(same)) < 1e-6
+
+    g = load_golden("criterions_cat")
+    lpy = T(g["log_py"], dev)
+    ck = C.CatKLLoss()
+    for tag, kw in (("bs", dict(batch_size=4)), ("ua", dict(unit_average=True)), ("rows", dict(average=False))):
+        lq = T(g["log_qy"], dev).requires_grad_()
+        v = ck(lq, lpy, **kw)
+        v.sum().backward()
+        close(v, g["catkl_" + tag], rtol=1e-5, atol=1e-6); close(lq.grad, g["dlq_" + tag], rtol=1e-5, atol=1e-6)
+    lq = T(g["log_qy"], dev)
+    close(ck(lq, torch.log(torch.ones(1) / 5).to(dev), batch_size=4), g["catkl_uniform"], rtol=1e-5, atol=1e-6)
+    close(ck(lq.view(1, 12, 5), lpy, batch_size=4), g["catkl_3d"], rtol=1e-5, atol=1e-6)
+    assert abs(float(ck(lq, lq, batch_size=4))) < 1e-6
+    close(C.Entropy()(lq, batch_size=4), g["ent_bs"], rtol=1e-5)
+    close(C.Entropy()(lq, unit_average=True), g["ent_ua"], rtol=1e-5)
