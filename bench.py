@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- training samples/sec of the DLS_VAE step (Yelp shape, bs=256 per GPU) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = zero_grad + forward + backward + (gradient all-reduce) + clip/guards + Adam on ONE synthetic batch
+that is already resident in HBM.  Forward+backward and the optimizer tail are replayed from HIP graphs; the
+RCCL gradient all-reduce runs eagerly between them.  Rank 0 prints ONE JSON line with the whole-job rate, the
+roofline of the dominant kernel group (vocabulary projection + softmax + NLL, forward and backward; HIP-event
+timed in an instrumented eager pass right after the timed region) and the CPU baseline (the oracle's composed
+step on stock ATen fp32 kernels, rank 0 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X bf16 MFMA, dense (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--graph", type=int, default=1, help="replay fwd+bwd / optimizer from HIP graphs")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--dropout", type=float, default=0.3)
+    ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for per-kernel times")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, batch, steps):
+    """The oracle's composed step (oracle/ref_step.py) on the host cores: forward + backward + clip + Adam."""
+    from oracle.ref_step import RefDLSVAE
+    from pevae_amd.dls_vae import synthetic_batch
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = RefDLSVAE(cfg).use_aten_rnn(True)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.init_lr)
+    feed = synthetic_batch(cfg, batch, 1234)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = model(feed)
+        model.valid_loss(loss).backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.grad_clip, 2)
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    sec = sum(times) / len(times)
+    return dict(value=batch / sec, unit="samples/s", cores=cores, kind="port",
+                sample="%d full steps of the same workload (bs=%d, L=%d, V=%d) after 1 warm-up; %.2f s/step"
+                       % (steps, batch, cfg.max_seq_len, cfg.vocab_size, sec))
+
+
+def main():
+    args = parse()
+    from pevae_amd import dp, ops
+    from pevae_amd.dls_vae import DLSVAE, default_config, synthetic_batch
+    from pevae_amd.optim import FlatAdam
+    rank, world, local = dp.init_from_env()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    cfg = default_config(dropout=args.dropout, batch_size=args.batch)
+    torch.manual_seed(0)                                    # identical initial weights on every rank
+    model = DLSVAE(cfg).to(dev)
+    model.train()
+    opt = FlatAdam(model.parameters(), lr=cfg.init_lr, max_norm=cfg.grad_clip, warmup_steps=cfg.warmup_steps)
+    dp.broadcast_parameters(opt.flat_p)
+    reducer = dp.FlatGradReducer(opt.flat_g, world)
+    feed = synthetic_batch(cfg, args.batch, 1234 + rank, dev)
+    n_params = sum(p.numel() for p in model.parameters())
+
+    def fwd_bwd():
+        opt.zero_grad()
+        loss = model(feed)
+        model.valid_loss(loss).backward()
+        return loss
+
+    def eager_step():
+        loss = fwd_bwd()
+        reducer.reduce()
+        opt.step()
+        return loss
+
+    # warm-up (eager): allocates every workspace, sets kernel attributes
+    for _ in range(max(2, args.warmup if not args.graph else 2)):
+        loss = eager_step()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+
+    step = eager_step
+    if args.graph:
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g1):
+            static_loss = fwd_bwd()
+        with torch.cuda.graph(g2):
+            opt.step()
+        ops.LAST_GRU_SYNC.clear()
+
+        def step():
+            g1.replay()
+            reducer.reduce()
+            g2.replay()
+            return static_loss
+        for _ in range(args.warmup):
+            loss = step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+    final_nll = float(loss.vae_nll)
+
+    # ---- instrumented eager pass: HIP events on the launch stream around the dominant kernels ---------------
+    roof, kern_ms = None, {}
+    if rank == 0:
+        ops.TIMERS = {}
+        for _ in range(args.profile_steps):
+            fwd_bwd()
+        torch.cuda.synchronize()
+        for tag, evs in ops.TIMERS.items():
+            per_step = len(evs) // args.profile_steps
+            tot = sum(a.elapsed_time(b) for a, b in evs) / args.profile_steps
+            kern_ms[tag] = dict(ms_per_step=round(tot, 4), launches_per_step=per_step)
+        ops.TIMERS = None
+        T, H, V = args.batch * cfg.max_seq_len, cfg.dec_cell_size, cfg.vocab_size
+        alg_flop = 6.0 * T * H * V                       # fwd + dH + dW; the backward's logit recompute is NOT credited
+        vocab_ms = sum(kern_ms[k]["ms_per_step"] for k in ("vocab_fwd", "vocab_bwd_prob", "vocab_dH", "vocab_dW"))
+        ach = alg_flop / (vocab_ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=None,
+                    kernel="gemm_nt_kernel<EpiSoftmax|EpiProb|EpiStore> (vocab projection+softmax+NLL fwd+bwd group)",
+                    algorithmic_gflop_per_step=round(alg_flop / 1e9, 1), group_ms_per_step=round(vocab_ms, 4),
+                    fwd_kernel_tflops=round(2.0 * T * H * V / (kern_ms["vocab_fwd"]["ms_per_step"] * 1e-3) / 1e12, 2))
+
+    if rank == 0:
+        cpu = cpu_baseline(cfg, args.batch, args.cpu_steps) if (args.cpu_baseline and world == 1) else None
+        out = {
+            "metric": "training samples/sec (whole node) DLS_VAE Yelp-shape bs256", "value": round(value, 2),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "DLS_VAE Yelp-shape bs=256/GPU bf16 (configs[1]): embed=100 dec_cell=512 L=50 "
+                                   "V=20004 NU=30000 NI=20000 Z=64, dropout=%.1f, Adam lr=1e-4 clip=5, flat Gaussian "
+                                   "latent stack" % args.dropout,
+                       "global_batch": args.batch * world, "seq_len": cfg.max_seq_len, "params": n_params,
+                       "parallelism": "dp%d" % world, "hip_graph": bool(args.graph)},
+            "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kern_ms, "final_vae_nll": round(final_nll, 4),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

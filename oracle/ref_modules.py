@@ -109,6 +109,21 @@ class RNNParams(nn.Module):
         sfx = "_l%d%s" % (layer, "_reverse" if direction == 1 else "")
         return tuple(getattr(self, n + sfx) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
 
+    use_aten = False      # True: run through stock torch.nn.GRU/LSTM kernels (what the reference calls,
+                          # base_modules.py:42) sharing these Parameters -- the bench's CPU-baseline leg
+
+    def aten_module(self):
+        mod = self.__dict__.get("_aten")
+        if mod is None:
+            cls = nn.GRU if self.cell == "gru" else nn.LSTM
+            mod = cls(self.input_size, self.hidden_size, self.num_layers, batch_first=True, dropout=self.dropout,
+                      bidirectional=self.bidirectional)
+            self.__dict__["_aten"] = mod
+        for name, p in self.named_parameters():
+            mod._parameters[name] = p
+        mod.train(self.training)
+        return mod
+
 
 def run_rnn(params, x, state=None, lengths=None, training=False):
     """batch_first multi-layer (bi)directional GRU/LSTM over x [B,L,in].
@@ -117,6 +132,8 @@ def run_rnn(params, x, state=None, lengths=None, training=False):
     `lengths` reproduces pack_padded_sequence/pad_packed_sequence (encoders.py:55-65): state
     updates stop at each row's length and outputs past it are zero.
     """
+    if params.use_aten and lengths is None:
+        return params.aten_module()(x, state) if state is not None else params.aten_module()(x)
     B, L, _ = x.shape
     H, dirs = params.hidden_size, (2 if params.bidirectional else 1)
     is_lstm = params.cell == "lstm"

@@ -1,0 +1,81 @@
+"""CPU oracle of the composed DLS_VAE training step (TEST INFRASTRUCTURE; see oracle/__init__.py).
+
+Same composition and state_dict keys as pevae_amd/dls_vae.py, built from the oracle restatements of the
+reference modules (oracle/ref_modules.py): data flow of FS_VAE.forward (dialog_models.py:755-818), loss /
+Pack contract of DLS_VAE (dialog_models.py:3451-3465, :3569).  Also the `cpu_baseline` leg of bench.py
+(stock ATen fp32 kernels on the host cores, the same ones the reference modules call).
+"""
+import torch
+import torch.nn as nn
+
+from . import ref_modules as R
+
+PAD_ID, UNK_ID, BOS_ID, EOS_ID = 0, 1, 2, 3
+
+
+class RefDLSVAE(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        c = self.config = config
+        H, E, Z = c.dec_cell_size, c.embed_size, c.latent_size
+        self.emb_size = H // 2
+        self.x_embedding = nn.Embedding(c.vocab_size, E, padding_idx=PAD_ID)
+        self.user_embedding = nn.Embedding(c.n_user, self.emb_size)
+        self.item_embedding = nn.Embedding(c.n_item, self.emb_size)
+        self.rating_embedding = nn.Embedding(5, self.emb_size)
+        self.x_encoder = R.EncoderRNN(E, H, dropout_p=c.dropout, rnn_cell=c.rnn_cell, variable_lengths=False)
+        self.x_decoder = R.DecoderRNN(c.vocab_size, c.max_seq_len, E, H, BOS_ID, EOS_ID, UNK_ID,
+                                      n_layers=c.num_layer, rnn_cell=c.rnn_cell, input_dropout_p=c.dropout,
+                                      dropout_p=c.dropout, use_attention=c.use_attention, attn_mode=c.attn_type,
+                                      attn_size=H, use_gpu=False, embedding=self.x_embedding)
+        self.rec_head = R.Hidden2Gaussian(H, Z)
+        self.prior_fc = nn.Linear(3 * self.emb_size, H)
+        self.pri_head = R.Hidden2Gaussian(H, Z)
+        self.x_init_connector = R.LinearConnector(Z, H, c.rnn_cell == "lstm")
+        if c.do_pred:
+            self.dnn = nn.Sequential(nn.Linear(2 * self.emb_size, H), nn.Linear(H, 1))
+        self.nll_loss = R.NLLEntropy(PAD_ID, c)
+        self.ppl = R.Perplexity(PAD_ID, c)
+        self.kl_loss = R.NormKLLoss(unit_average=False)
+
+    def use_aten_rnn(self, on=True):
+        """Timing leg: run both GRUs through stock torch.nn.GRU (the kernels the reference itself calls)."""
+        self.x_encoder.rnn.use_aten = on
+        self.x_decoder.rnn.use_aten = on
+        return self
+
+    def valid_loss(self, loss):
+        total = loss.vae_nll
+        if self.training and loss.vae_rkl is not None:
+            total = total + loss.vae_rkl
+        if self.config.do_pred and loss.get("rating_mse") is not None:
+            total = total + loss.rating_mse
+        return total
+
+    def forward(self, feed, mode=R.TEACH_FORCE, gen_type="greedy", eps=None):
+        user = self.user_embedding(feed["user_ids"])
+        item = self.item_embedding(feed["item_ids"])
+        rating = self.rating_embedding(feed["ratings"].ge(3).long())
+        enc_outs, enc_last = self.x_encoder(self.x_embedding(feed["sentence_embeddings"]))
+        h = enc_last.transpose(0, 1).contiguous().squeeze(1)
+        mu_q, lv_q = self.rec_head(h)
+        mu_p, lv_p = self.pri_head(torch.tanh(self.prior_fc(torch.cat([user, item, rating], -1))))
+        B = h.size(0)
+        if self.training:
+            if eps is None:
+                eps = torch.randn(B, mu_q.size(1))
+            z = R.reparameterization(mu_q, lv_q, eps)
+            rkl = self.kl_loss(mu_q, lv_q, mu_p, lv_p)
+        else:
+            z, rkl = mu_p, None
+        dec_init = self.x_init_connector(z)
+        ctx = enc_outs if self.config.use_attention else None
+        dec_outs, _, _ = self.x_decoder(B, feed["input_ids"], dec_init, mode=mode, gen_type=gen_type,
+                                        beam_size=self.config.beam_size, attn_context=ctx)
+        pack = R.Pack(vae_zkl=None, vae_nll=self.nll_loss(dec_outs, feed["ans_ids"]),
+                      vae_PPL=self.ppl(dec_outs, feed["ans_ids"]), vae_rnll=None, vae_rkl=rkl)
+        if self.config.do_pred:
+            x = torch.cat([user, item], -1)
+            pred = self.dnn[1](torch.tanh(self.dnn[0](x))).squeeze(-1)
+            pack["rating_mse"] = ((pred - feed["ratings"]) ** 2).mean()
+        return pack

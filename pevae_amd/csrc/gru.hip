@@ -451,6 +451,16 @@ __global__ void gru_bias_reduce_kernel(const float* __restrict__ part, int G, in
   if (gt == 3) db_hh[2 * H + u] = sacc;
 }
 
+// raise the dynamic-LDS limit of a kernel only when a larger request than any earlier one comes in
+template <class K>
+int ensure_lds(K kernel, size_t bytes, size_t* seen) {
+  if (bytes > *seen) {
+    PV_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    *seen = bytes;
+  }
+  return PV_OK;
+}
+
 int g_cu_count = 0;
 int cu_count() {
   if (!g_cu_count) {
@@ -502,11 +512,12 @@ int pv_gru_fwd(const float* xproj, const void* whh_bf16, const float* bhh, const
   GruFwdArgs a{xproj, (const bf16_t*)whh_bf16, bhh, out, out_sb, out_st, (bf16_t*)hseq_bf16, gsave, hn, hall,
                counters, err, L, B, H, Hk, Bpad, NG, G, S, reverse};
   const size_t smem = (size_t)3 * U * Hk * 2 + (size_t)4 * ROWS * (3 * U + 4) * 4;
+  static size_t seen_f2 = 0, seen_f1 = 0;
   if (UT == 2) {
-    PV_HIP(hipFuncSetAttribute((const void*)gru_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if ((rc = ensure_lds(gru_fwd_kernel<2>, smem, &seen_f2))) return rc;
     hipLaunchKernelGGL(gru_fwd_kernel<2>, dim3(G * S), dim3(256), smem, st, a);
   } else {
-    PV_HIP(hipFuncSetAttribute((const void*)gru_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if ((rc = ensure_lds(gru_fwd_kernel<1>, smem, &seen_f1))) return rc;
     hipLaunchKernelGGL(gru_fwd_kernel<1>, dim3(G * S), dim3(256), smem, st, a);
   }
   PV_LAUNCH_CHECK("gru_fwd_kernel");
@@ -540,11 +551,12 @@ int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, 
   }
   GruBwdArgs a{dout, dout_sb, dout_st, dhn, gsave, hall, (const bf16_t*)whhT_bf16, (bf16_t*)dgi_bf16,
                (bf16_t*)dgh_bf16, dh0, dbias_part, counters, err, L, B, H, K3, Bpad, NG, G, S, reverse};
+  static size_t seen_b2 = 0, seen_b1 = 0;
   if (UT == 2) {
-    PV_HIP(hipFuncSetAttribute((const void*)gru_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if ((rc = ensure_lds(gru_bwd_kernel<2>, smem, &seen_b2))) return rc;
     hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3(G * S), dim3(256), smem, st, a);
   } else {
-    PV_HIP(hipFuncSetAttribute((const void*)gru_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if ((rc = ensure_lds(gru_bwd_kernel<1>, smem, &seen_b1))) return rc;
     hipLaunchKernelGGL(gru_bwd_kernel<1>, dim3(G * S), dim3(256), smem, st, a);
   }
   PV_LAUNCH_CHECK("gru_bwd_kernel");

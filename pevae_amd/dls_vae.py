@@ -1,0 +1,142 @@
+"""The composed DLS_VAE training step on the HIP modules.
+
+The reference's `DLS_VAE` class cannot be constructed (it needs network downloads and undefined names,
+dialog_models.py:3356-3437), so this is the build's documented composition:
+  * data flow of FS_VAE.forward (dialog_models.py:755-818): user / item / rating / word embedding gathers
+    (:758-765), EncoderRNN over the explanation (:765-766), recognition and prior heads, reparameterised
+    sample (:191-203), LinearConnector into the decoder state (:711, nn_lib.py:146-156), teacher-forced
+    DecoderRNN sharing the word embedding (:712, :560-570), NLLEntropy + Perplexity (:790-791);
+  * loss / Pack contract of DLS_VAE (dialog_models.py:3451-3465, :3569): Pack(vae_zkl, vae_nll, vae_PPL,
+    vae_rnll, vae_rkl); valid_loss = vae_nll + vae_rkl in training, vae_nll in eval.
+Latent stack 'gauss' (flat): q(z|x) = Hidden2Gaussian(h_enc), p(z|u,i,r) = Hidden2Gaussian(tanh(W [u;i;r])),
+KL = NormKLLoss(q, p).  oracle/ref_step.py holds the same composition on the CPU oracle modules.
+"""
+from argparse import Namespace
+
+import torch
+import torch.nn as nn
+
+from . import criterions, nn_lib, ops
+from .enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
+from .enc2dec.encoders import EncoderRNN
+from .utils import Pack
+
+PAD_ID, UNK_ID, BOS_ID, EOS_ID = 0, 1, 2, 3      # vocab = [<pad>, <unk>, <s>, </s>] + words (corpora.py:624-651)
+
+
+def default_config(**kw):
+    cfg = Namespace(vocab_size=20004, embed_size=100, dec_cell_size=512, max_seq_len=50, n_user=30000,
+                    n_item=20000, latent_size=64, dropout=0.3, rnn_cell="gru", num_layer=1, use_attention=False,
+                    attn_type="cat", do_pred=False, beam_size=10, batch_size=256, init_lr=1e-4, grad_clip=5.0,
+                    warmup_steps=0, use_gpu=True)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class DLSVAE(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        c = self.config = config
+        H, E, Z = c.dec_cell_size, c.embed_size, c.latent_size
+        self.emb_size = H // 2
+        self.x_embedding = nn.Embedding(c.vocab_size, E, padding_idx=PAD_ID)            # dialog_models.py:468
+        self.user_embedding = nn.Embedding(c.n_user, self.emb_size)                      # :473
+        self.item_embedding = nn.Embedding(c.n_item, self.emb_size)                      # :475
+        self.rating_embedding = nn.Embedding(5, self.emb_size)                           # :502
+        self.x_encoder = EncoderRNN(E, H, dropout_p=c.dropout, rnn_cell=c.rnn_cell, variable_lengths=False)  # :530
+        self.x_decoder = DecoderRNN(c.vocab_size, c.max_seq_len, E, H, BOS_ID, EOS_ID, UNK_ID,
+                                    n_layers=c.num_layer, rnn_cell=c.rnn_cell, input_dropout_p=c.dropout,
+                                    dropout_p=c.dropout, use_attention=c.use_attention, attn_mode=c.attn_type,
+                                    attn_size=H, use_gpu=c.use_gpu, embedding=self.x_embedding)               # :560-570
+        self.rec_head = nn_lib.Hidden2Gaussian(H, Z)
+        self.prior_fc = nn.Linear(3 * self.emb_size, H)
+        self.pri_head = nn_lib.Hidden2Gaussian(H, Z)
+        self.x_init_connector = nn_lib.LinearConnector(Z, H, c.rnn_cell == "lstm")      # :626
+        if c.do_pred:                                                                    # `self.dnn`, used at :815, never
+            self.dnn = nn.Sequential(nn.Linear(2 * self.emb_size, H), nn.Linear(H, 1))  # defined by the reference
+        self.nll_loss = criterions.NLLEntropy(PAD_ID, c)                                 # :634
+        self.ppl = criterions.Perplexity(PAD_ID, c)                                      # :637
+        self.kl_loss = criterions.NormKLLoss(unit_average=False)
+        self.backLoss = True
+
+    # -- loss contract (dialog_models.py:3451-3465) ----------------------------------------------------------
+    def valid_loss(self, loss, batch_cnt=None, step=None):
+        loss.vae_zkl = 0
+        if loss.vae_nll is None:
+            loss.vae_nll = 0
+        if self.training and loss.vae_rkl is not None:
+            total = loss.vae_nll + loss.vae_rkl
+        else:
+            total = loss.vae_nll
+        if self.config.do_pred and loss.get("rating_mse") is not None:
+            total = total + loss.rating_mse
+        return total
+
+    def backward(self, batch_cnt, loss, step=None):                                     # dialog_models.py:51-53
+        self.valid_loss(loss, batch_cnt, step=step).backward()
+
+    def forward(self, data_feed, mode=TEACH_FORCE, gen_type="greedy", eps=None):
+        user = ops.embedding(self.user_embedding.weight, data_feed["user_ids"])          # :758
+        item = ops.embedding(self.item_embedding.weight, data_feed["item_ids"])          # :759
+        rating = ops.embedding(self.rating_embedding.weight, data_feed["ratings"].ge(3).long())   # :760
+        words = ops.embedding(self.x_embedding.weight, data_feed["sentence_embeddings"], PAD_ID)
+        enc_outs, enc_last = self.x_encoder(words)                                        # :765
+        h = enc_last.transpose(0, 1).contiguous().squeeze(1)                              # :766
+        mu_q, lv_q = self.rec_head(h)
+        prior_h = ops.tanh(ops.linear(torch.cat([user, item, rating], -1), self.prior_fc.weight, self.prior_fc.bias))
+        mu_p, lv_p = self.pri_head(prior_h)
+        B = h.size(0)
+        if self.training:
+            if eps is None:
+                eps = torch.randn(B, mu_q.size(1), device=h.device)                       # :197
+            z, kl_row = ops.reparam_kl(mu_q, lv_q, mu_p, lv_p, eps, mode=0)               # :191-203 + criterions.py:145-155
+            rkl = ops.mean(kl_row)
+        else:
+            z, rkl = mu_p, None                                                            # eval: condition on the prior mean
+        dec_init = self.x_init_connector(z)                                                # :711
+        attn_ctx = enc_outs if self.config.use_attention else None
+        dec_outs, dec_last, dec_ctx = self.x_decoder(B, data_feed["input_ids"], dec_init, mode=mode,
+                                                     gen_type=gen_type, beam_size=self.config.beam_size,
+                                                     attn_context=attn_ctx)                # :712
+        if not self.backLoss:                                                              # generation: :813-817
+            if self.config.do_pred:
+                return dec_ctx, data_feed["ans_ids"], self._rating(user, item)
+            return dec_ctx, data_feed["ans_ids"]
+        vae_nll = self.nll_loss(dec_outs, data_feed["ans_ids"])                            # :790
+        vae_ppl = self.ppl(dec_outs, data_feed["ans_ids"])                                 # :791
+        pack = Pack(vae_zkl=None, vae_nll=vae_nll, vae_PPL=vae_ppl, vae_rnll=None, vae_rkl=rkl)
+        if self.config.do_pred:
+            diff = self._rating(user, item) - data_feed["ratings"]                         # main_pretrain.py:891-893
+            pack["rating_mse"] = ops.mean(diff * diff)
+        return pack
+
+    def _rating(self, user, item):
+        x = torch.cat([user, item], -1)
+        x = ops.linear(x, self.dnn[0].weight, self.dnn[0].bias)
+        return ops.linear(ops.tanh(x), self.dnn[1].weight, self.dnn[1].bias).squeeze(-1)
+
+
+def synthetic_batch(config, batch_size, seed, device="cpu"):
+    """Synthetic batch in the format of YELPDataLoader.batcher.__call__ (data_loaders.py:704-715):
+    BOS, len-2 Zipf-distributed word ids in [4, V), EOS, PAD to L; ans_ids = input_ids shifted left."""
+    g = torch.Generator().manual_seed(seed)
+    B, L, V = batch_size, config.max_seq_len, config.vocab_size
+    lens = torch.randint(min(8, L), L + 1, (B,), generator=g)
+    ranks = torch.arange(1, V - 3, dtype=torch.float64)
+    probs = (1.0 / ranks ** 1.1)
+    words = torch.multinomial(probs / probs.sum(), B * L, replacement=True, generator=g).view(B, L) + 4
+    pos = torch.arange(L).unsqueeze(0)
+    ids = torch.where(pos < lens.unsqueeze(1), words, torch.zeros_like(words))
+    ids[:, 0] = BOS_ID
+    ids[torch.arange(B), lens - 1] = EOS_ID
+    ans = torch.cat([ids[:, 1:], torch.zeros(B, 1, dtype=torch.long)], 1)
+    user = torch.randint(0, config.n_user, (B,), generator=g)
+    item = torch.randint(0, config.n_item, (B,), generator=g)
+    feed = {
+        "user_ids": user, "item_ids": item, "feature_ids": torch.zeros(B, dtype=torch.long),
+        "sentence_embeddings": ids, "attention_masks": (ids != 0).long(),
+        "ratings": torch.randint(0, 5, (B,), generator=g).float(), "input_ids": ids.clone(), "ans_ids": ans,
+        "rd_ids": torch.randn(B, generator=g), "ui_ids": user + 1000000000 * item,
+    }
+    return {k: v.to(device).contiguous() for k, v in feed.items()}

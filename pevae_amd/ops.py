@@ -34,6 +34,27 @@ def round_up(a, b):
 
 _WS = {}
 
+TIMERS = None       # bench.py: dict tag -> [(start_event, end_event)] recorded on the launch stream
+
+
+class timed(object):
+    """HIP-event bracket around a kernel launch (active only while bench.py sets TIMERS)."""
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if TIMERS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if TIMERS is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            TIMERS.setdefault(self.tag, []).append((self.e0, e1))
+        return False
+
 
 def workspace(tag, numel, dtype, device, zero=False):
     """Persistent scratch (reused every step, stream-ordered).  Never handed to autograd as saved state."""
@@ -140,8 +161,9 @@ class VocabNLL(torch.autograd.Function):
         lse = torch.empty(T, dtype=torch.float32, device=dev)
         nll = torch.empty(T, dtype=torch.float32, device=dev)
         bias_c = bias.contiguous()
-        _lib.call("pv_vocab_nll_fwd", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(target), T, V, Hp, inv_temp,
-                  ignore_index, _p(ws), _p(lse), _p(nll), _stream())
+        with timed("vocab_fwd"):
+            _lib.call("pv_vocab_nll_fwd", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(target), T, V, Hp, inv_temp,
+                      ignore_index, _p(ws), _p(lse), _p(nll), _stream())
         ctx.save_for_backward(h_bf, w_bf, bias_c, target, lse)
         ctx.dims = (T, H, V, Hp, ldh, inv_temp, ignore_index)
         ctx.hid_dtype = hid.dtype
@@ -159,8 +181,9 @@ class VocabNLL(torch.autograd.Function):
         PT = workspace("vocab_PT", Vp * Tp, BF16, dev)
         dbp = workspace("vocab_dbias_part", (Tp // 64) * Vp, torch.float32, dev)
         dbias = torch.empty(V, dtype=torch.float32, device=dev)
-        _lib.call("pv_vocab_nll_bwd_prob", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(target), _p(lse), _p(gscale),
-                  T, V, Hp, inv_temp, _p(P), Vp, _p(PT), Tp, _p(dbp), _p(dbias), _stream())
+        with timed("vocab_bwd_prob"):
+            _lib.call("pv_vocab_nll_bwd_prob", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(target), _p(lse),
+                      _p(gscale), T, V, Hp, inv_temp, _p(P), Vp, _p(PT), Tp, _p(dbp), _p(dbias), _stream())
         dH, dW = _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp)
         if ctx.layout is not None:
             L, B, Bpad = ctx.layout
@@ -171,9 +194,11 @@ class VocabNLL(torch.autograd.Function):
 def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp):
     dev = w_bf.device
     wT = transpose_to_bf16(w_bf, V, H, Hp, Vp, out=workspace("vocab_WT", H * Vp, BF16, dev).view(H, Vp))
-    dH = gemm_nt(P, Vp, wT, Vp, T, H, Vp)
+    with timed("vocab_dH"):
+        dH = gemm_nt(P, Vp, wT, Vp, T, H, Vp)
     hT = transpose_to_bf16(h_bf, T, H, ldh, Tp, out=workspace("vocab_hT", H * Tp, BF16, dev).view(H, Tp))
-    dW = gemm_nt(PT, Tp, hT, Tp, V, H, Tp)
+    with timed("vocab_dW"):
+        dW = gemm_nt(PT, Tp, hT, Tp, V, H, Tp)
     return dH, dW
 
 
@@ -262,8 +287,9 @@ class GRULayer(torch.autograd.Function):
         hall = torch.empty(((L + 1) * Bpad, H), dtype=torch.float32, device=dev) if save else None
         sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
         h0c = None if h0 is None else h0.contiguous()
-        _lib.call("pv_gru_fwd", _p(xproj), _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), L, B, H, 0, _p(out), L * H, H,
-                  _p(hseq), _p(gsave), _p(hall), _p(hn), _p(sync), GRU_MAX_WGS, _stream())
+        with timed("gru_fwd"):
+            _lib.call("pv_gru_fwd", _p(xproj), _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), L, B, H, 0, _p(out), L * H,
+                      H, _p(hseq), _p(gsave), _p(hall), _p(hn), _p(sync), GRU_MAX_WGS, _stream())
         if save:
             ctx.save_for_backward(x_bf, hseq, gsave, hall, w_ih, w_hh)
         if len(LAST_GRU_SYNC) < 64:
@@ -290,9 +316,10 @@ class GRULayer(torch.autograd.Function):
         if dout is not None:
             dout = dout if dout.stride(2) == 1 else dout.contiguous()
         dhn_c = None if dhn is None else dhn.contiguous()
-        _lib.call("pv_gru_bwd", _p(dout), 0 if dout is None else dout.stride(0), 0 if dout is None else dout.stride(1),
-                  _p(dhn_c), _p(gsave), _p(hall), _p(whhT), L, B, H, 0, _p(dgi), _p(dgh), _p(dh0), _p(dbp), _p(db_ih),
-                  _p(db_hh), _p(sync), GRU_MAX_WGS, _stream())
+        with timed("gru_bwd"):
+            _lib.call("pv_gru_bwd", _p(dout), 0 if dout is None else dout.stride(0),
+                      0 if dout is None else dout.stride(1), _p(dhn_c), _p(gsave), _p(hall), _p(whhT), L, B, H, 0,
+                      _p(dgi), _p(dgh), _p(dh0), _p(dbp), _p(db_ih), _p(db_hh), _p(sync), GRU_MAX_WGS, _stream())
         if len(LAST_GRU_SYNC) < 64:
             LAST_GRU_SYNC.append((sync, NG, "pv_gru_bwd"))
         Tt = L * Bpad
