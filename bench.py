@@ -75,6 +75,10 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # everything (warm-up, capture, replay, eager passes) runs on ONE non-default stream: autograd ties each node
+    # to the stream it was created on, and the legacy default stream cannot take part in a capture
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
 
     cfg = default_config(dropout=args.dropout, batch_size=args.batch)
     torch.manual_seed(0)                                    # identical initial weights on every rank
@@ -98,24 +102,22 @@ def main():
         opt.step()
         return loss
 
-    # warm-up (eager): allocates every workspace, sets kernel attributes
-    for _ in range(max(2, args.warmup if not args.graph else 2)):
-        loss = eager_step()
+    # warm-up (eager, on a side stream as torch's graph-capture rules ask): allocates every workspace
+    for _ in range(max(3, args.warmup if not args.graph else 3)):
+        eager_step()
     torch.cuda.synchronize()
     ops.gru_check_all()
 
     step = eager_step
     if args.graph:
+        # no autograd graph from the warm-up may stay alive (its AccumulateGrad nodes are tied to the warm-up stream)
+        # and capture runs on the SAME side stream as the warm-up
+        import gc
+        gc.collect()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fwd_bwd()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, stream=side):
             static_loss = fwd_bwd()
-        with torch.cuda.graph(g2):
+        with torch.cuda.graph(g2, pool=g1.pool(), stream=side):
             opt.step()
         ops.LAST_GRU_SYNC.clear()
 
@@ -124,8 +126,13 @@ def main():
             reducer.reduce()
             g2.replay()
             return static_loss
-        for _ in range(args.warmup):
-            loss = step()
+    for i in range(args.warmup):
+        step()
+        if rank == 0 and os.environ.get("PEVAE_BENCH_DEBUG"):
+            st = opt.state_dict_host()
+            bad = [n for n, p in model.named_parameters() if not torch.isfinite(p.grad).all()]
+            print("debug warm replay", i, "norm", st["last_norm"], "skip", st["skip"], "nll",
+                  float(static_loss.vae_nll.detach()) if args.graph else None, "nonfinite grads:", bad[:6], file=sys.stderr)
 
     def barrier():
         if world > 1:
@@ -142,9 +149,11 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    if rank == 0 and os.environ.get("PEVAE_BENCH_DEBUG"):
+        print("debug: guard state", opt.state_dict_host(), "nll", float(loss.vae_nll.detach()), file=sys.stderr)
     ms = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
-    final_nll = float(loss.vae_nll)
+    final_nll = float(loss.vae_nll.detach())
 
     # ---- instrumented eager pass: HIP events on the launch stream around the dominant kernels ---------------
     roof, kern_ms = None, {}
