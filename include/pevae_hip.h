@@ -28,11 +28,11 @@ int pv_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
 /* ---- bf16 MFMA GEMM core -------------------------------------------------------------------------------
  * C[M,N] = A[M,K] B[N,K]^T (+bias[N]); A,B bf16 row-major, K % 64 == 0 (zero padded), lda/ldb % 8 == 0,
- * 16-byte aligned.  Writes fp32 C and/or bf16 Cb.  Replaces the cuBLAS GEMMs inside nn.GRU's input
+ * 16-byte aligned.  Writes fp32 C (C += when accumulate != 0) and/or bf16 Cb.  Replaces the cuBLAS GEMMs inside nn.GRU's input
  * projection (models/enc2dec/base_modules.py:42) and the weight/data-gradient GEMMs of nn.Linear backward
  * for `project` (models/enc2dec/decoders.py:162). */
 int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
-                    float* C, int ldc, void* Cb, int ldcb, void* stream);
+                    float* C, int ldc, void* Cb, int ldcb, int accumulate, void* stream);
 
 /* ---- fused vocabulary projection + log-softmax + NLL -----------------------------------------------------
  * Forward: logits = (h W^T + bias) * inv_temp are produced tile-wise by the MFMA GEMM and reduced on the fly

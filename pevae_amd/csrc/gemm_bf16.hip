@@ -135,7 +135,7 @@ struct EpiStore {
   float* C;
   bf16_t* Cb;
   const float* bias;
-  int M, N, ldc, ldcb;
+  int M, N, ldc, ldcb, accumulate;
   __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
     const int c16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
@@ -149,8 +149,11 @@ struct EpiStore {
         for (int j = 0; j < 4; ++j) {
           const int row = row0 + mi * 16 + q4 * 4 + j;
           if (row >= M) continue;
-          const float v = acc[mi][ni][j] + bv;
-          if (C) C[(size_t)row * ldc + col] = v;
+          float v = acc[mi][ni][j] + bv;
+          if (C) {
+            if (accumulate) v += C[(size_t)row * ldc + col];
+            C[(size_t)row * ldc + col] = v;
+          }
           if (Cb) Cb[(size_t)row * ldcb + col] = f2bf(v);
         }
     }
@@ -410,13 +413,14 @@ int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who) {
 extern "C" {
 
 int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
-                    const float* bias, float* C, int ldc, void* Cb, int ldcb, void* stream) {
+                    const float* bias, float* C, int ldc, void* Cb, int ldcb, int accumulate, void* stream) {
   int rc = check_gemm(A, B, M, N, K, lda, ldb, "pv_gemm_bf16_nt");
   if (rc) return rc;
   PV_REQUIRE(C || Cb, "pv_gemm_bf16_nt: no output given");
   PV_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N), "pv_gemm_bf16_nt: output leading dimension < N");
   GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb};
-  EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb};
+  PV_REQUIRE(!accumulate || C, "pv_gemm_bf16_nt: accumulate needs the fp32 output");
+  EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb, accumulate};
   return launch(g, e, (hipStream_t)stream, "pv_gemm_bf16_nt");
 }
 

@@ -1,4 +1,4 @@
-// Small exact-fp32 strided GEMM for the latent / connector linears of the DLS_VAE step (M = batch = 256,
+// Small fp32 strided GEMM (f32-input MFMA) for the latent / connector linears of the DLS_VAE step (M = batch = 256,
 // K,N <= a few hundred: Hidden2Gaussian nn_lib.py:198-199, LinearConnector nn_lib.py:143, the Block MLPs
 // dialog_models.py:258-263).  These are launch-latency bound, not FLOP bound, and they feed KL terms that are
 // compared with the reference at fp32 tolerance, so they stay in fp32 FMA (no bf16 rounding).
@@ -12,7 +12,14 @@
 
 namespace {
 
-constexpr int TM = 64, TN = 64, TK = 16;
+// 64x64 output tile per 256-thread workgroup, 4 waves as 2x2, each wave 32x32 = 2x2 v_mfma_f32_16x16x4_f32
+// accumulators (exact fp32 FMA chain in k order).  K is walked 32 deep; the next K-tile's global loads are
+// issued BEFORE the current tile's MFMAs and written to the other LDS buffer after them (one barrier per
+// K-tile), so the global latency of these tiny, launch/latency-bound GEMMs overlaps the math.
+// The LDS image is [k][m] (row stride 80 floats: the 4 k-rows of one MFMA fragment land on disjoint banks),
+// filled from 16-byte global loads along whichever direction has unit stride.
+constexpr int TM = 64, TN = 64, TK = 32, LS = 80;
+constexpr int MODE_SCALAR = 0, MODE_XFAST = 1, MODE_KFAST = 2;
 
 struct LinArgs {
   const float* A;
@@ -24,66 +31,136 @@ struct LinArgs {
   long bsa, bsb, bsc;   // batch strides (0 = shared)
   float alpha;
   int accumulate;
+  int modeA, modeB;
 };
 
+// P[x*sx + k*sk] for x in [x0, x0+64), k in [k0, k0+32) -> 8 registers per thread
+__device__ __forceinline__ void tile_load(const float* __restrict__ P, long sx, long sk, int X, int K, int x0, int k0,
+                                          int mode, int tid, float (&r)[8]) {
+  if (mode == MODE_XFAST) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int e = tid + p * 256, x = x0 + (e & 15) * 4, k = k0 + (e >> 4);
+      if (k < K && x + 3 < X) {
+        const float4 v = *(const float4*)(P + x + (long)k * sk);
+        r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[p * 4 + q] = (k < K && x + q < X) ? P[x + q + (long)k * sk] : 0.f;
+      }
+    }
+  } else if (mode == MODE_KFAST) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int e = tid + p * 256, x = x0 + (e & 63), k = k0 + (e >> 6) * 4;
+      if (x < X && k + 3 < K) {
+        const float4 v = *(const float4*)(P + (long)x * sx + k);
+        r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[p * 4 + q] = (x < X && k + q < K) ? P[(long)x * sx + k + q] : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int e = tid + p * 256, x = x0 + (e & 63), k = k0 + (e >> 6);
+      r[p] = (x < X && k < K) ? P[(long)x * sx + (long)k * sk] : 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void tile_store(float* __restrict__ S, int mode, int tid, const float (&r)[8]) {
+  if (mode == MODE_XFAST) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int e = tid + p * 256;
+      *(float4*)(S + (e >> 4) * LS + (e & 15) * 4) = make_float4(r[p * 4], r[p * 4 + 1], r[p * 4 + 2], r[p * 4 + 3]);
+    }
+  } else if (mode == MODE_KFAST) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int e = tid + p * 256;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[((e >> 6) * 4 + q) * LS + (e & 63)] = r[p * 4 + q];
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int e = tid + p * 256;
+      S[(e >> 6) * LS + (e & 63)] = r[p];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
-  __shared__ float As[TK][TM + 1];
-  __shared__ float Bs[TK][TN + 1];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  __shared__ __attribute__((aligned(16))) float lds[2][2][TK * LS];      // [buffer][A|B][k][x]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+  const int i16 = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const float* A = g.A + (long)blockIdx.z * g.bsa;
   const float* B = g.B + (long)blockIdx.z * g.bsb;
   float* C = g.C + (long)blockIdx.z * g.bsc;
-  float acc[4][4];
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  // loader mapping: prefer the unit-stride direction as the fast thread index
-  const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
-  for (int k0 = 0; k0 < g.K; k0 += TK) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256;
-      int mm, kk;
-      if (a_kfast) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
-      const int m = m0 + mm, k = k0 + kk;
-      As[kk][mm] = (m < g.M && k < g.K) ? A[m * g.sam + k * g.sak] : 0.f;
-      int nn, kb;
-      if (b_nfast) { nn = e & 63; kb = e >> 6; } else { kb = e & 15; nn = e >> 4; }
-      const int n = n0 + nn, k2 = k0 + kb;
-      Bs[kb][nn] = (n < g.N && k2 < g.K) ? B[k2 * g.sbk + n * g.sbn] : 0.f;
+    for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ra[8], rb[8];
+  const int nk = (g.K + TK - 1) / TK;
+  tile_load(A, g.sam, g.sak, g.M, g.K, m0, 0, g.modeA, tid, ra);
+  tile_load(B, g.sbn, g.sbk, g.N, g.K, n0, 0, g.modeB, tid, rb);
+  tile_store(lds[0][0], g.modeA, tid, ra);
+  tile_store(lds[0][1], g.modeB, tid, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int s = kt & 1;
+    if (kt + 1 < nk) {
+      tile_load(A, g.sam, g.sak, g.M, g.K, m0, (kt + 1) * TK, g.modeA, tid, ra);
+      tile_load(B, g.sbn, g.sbk, g.N, g.K, n0, (kt + 1) * TK, g.modeB, tid, rb);
     }
-    __syncthreads();
+    const float* As = lds[s][0] + wm * 32 + i16;
+    const float* Bs = lds[s][1] + wn * 32 + i16;
 #pragma unroll
-    for (int kk = 0; kk < TK; ++kk) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx + 16 * j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    for (int ks = 0; ks < TK / 4; ++ks) {
+      const int kr = (ks * 4 + kq) * LS;
+      const float a0 = As[kr], a1 = As[kr + 16], b0 = Bs[kr], b1 = Bs[kr + 16];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      tile_store(lds[s ^ 1][0], g.modeA, tid, ra);
+      tile_store(lds[s ^ 1][1], g.modeB, tid, rb);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= g.M) continue;
+  for (int u = 0; u < 2; ++u) {
+    const int n = n0 + wn * 32 + u * 16 + i16;
+    if (n >= g.N) continue;
+    const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx + 16 * j;
-      if (n >= g.N) continue;
-      float v = g.alpha * acc[i][j];
-      if (g.bias) v += g.bias[n];
-      float* dst = C + m * g.ldc + n;
-      if (g.accumulate) v += *dst;
-      *dst = v;
-    }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + t * 16 + kq * 4 + r;
+        if (m >= g.M) continue;
+        float v = g.alpha * acc[t][u][r] + bv;
+        float* dst = C + (long)m * g.ldc + n;
+        if (g.accumulate) v += *dst;
+        *dst = v;
+      }
   }
+}
+
+// which 16-byte load pattern an operand P[x*sx + k*sk] admits
+int pick_mode(const float* P, long sx, long sk, long bs, int batch) {
+  const bool al = ((uintptr_t)P & 15) == 0 && (batch == 1 || bs % 4 == 0);
+  if (al && sx == 1 && sk % 4 == 0) return MODE_XFAST;
+  if (al && sk == 1 && sx % 4 == 0) return MODE_KFAST;
+  return MODE_SCALAR;
 }
 
 }  // namespace
@@ -94,7 +171,8 @@ int pv_linear_f32(const float* A, long sam, long sak, const float* B, long sbk, 
                   float* C, long ldc, int M, int N, int K, float alpha, int accumulate, int batch, long bsa,
                   long bsb, long bsc, void* stream) {
   PV_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && ldc >= N, "pv_linear_f32: bad argument");
-  LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, bsa, bsb, bsc, alpha, accumulate};
+  LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, bsa, bsb, bsc, alpha, accumulate,
+            pick_mode(A, sam, sak, bsa, batch), pick_mode(B, sbn, sbk, bsb, batch)};
   hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv(N, TN), cdiv(M, TM), batch), dim3(256), 0, (hipStream_t)stream, g);
   PV_LAUNCH_CHECK("linear_f32_kernel");
   return PV_OK;

@@ -109,15 +109,27 @@ def transpose_to_bf16(src, R, Cc, lds, rpad, out=None):
     return out
 
 
-def gemm_nt(A, lda, Bm, ldb, M, N, K, bias=None, out=None, out_bf16=None):
-    """C[M,N] = A[M,K] B[N,K]^T (+bias) with bf16 operands on the MFMA core."""
+def gemm_nt(A, lda, Bm, ldb, M, N, K, bias=None, out=None, out_bf16=None, accumulate=False):
+    """C[M,N] (+)= A[M,K] B[N,K]^T (+bias) with bf16 operands on the MFMA core."""
     _need_cuda(A, Bm)
     if out is None and out_bf16 is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     _lib.call("pv_gemm_bf16_nt", _p(A), lda, _p(Bm), ldb, M, N, K, _p(bias), _p(out),
               0 if out is None else out.stride(0), _p(out_bf16), 0 if out_bf16 is None else out_bf16.stride(0),
-              _stream())
+              1 if accumulate else 0, _stream())
     return out if out is not None else out_bf16
+
+
+def grad_sink(param, shape=None):
+    """A parameter that already owns a dense fp32 `.grad` (FlatAdam's views into the flat gradient buffer, or
+    any earlier backward) lets the backward kernels ACCUMULATE into that buffer in place -- the autograd node
+    then returns None for it, which removes the temporary, its memset and the AccumulateGrad add kernel.
+    Parameters without a `.grad` get their gradient returned the ordinary way."""
+    g = getattr(param, "grad", None)
+    if (isinstance(param, torch.nn.Parameter) and g is not None and g.is_cuda and g.dtype == torch.float32
+            and g.is_contiguous() and (shape is None or tuple(g.shape) == tuple(shape))):
+        return g
+    return None
 
 
 def masked_sum(x, mask=None, ignore=0):
@@ -167,6 +179,7 @@ class VocabNLL(torch.autograd.Function):
         ctx.save_for_backward(h_bf, w_bf, bias_c, target, lse)
         ctx.dims = (T, H, V, Hp, ldh, inv_temp, ignore_index)
         ctx.hid_dtype = hid.dtype
+        ctx.params = (weight, bias)
         ctx.mark_non_differentiable(lse)
         return nll, lse
 
@@ -184,21 +197,26 @@ class VocabNLL(torch.autograd.Function):
         with timed("vocab_bwd_prob"):
             _lib.call("pv_vocab_nll_bwd_prob", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(target), _p(lse),
                       _p(gscale), T, V, Hp, inv_temp, _p(P), Vp, _p(PT), Tp, _p(dbp), _p(dbias), _stream())
-        dH, dW = _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp)
+        weight, _bias = ctx.params
+        dH, dW = _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, grad_sink(weight, (V, H)))
         if ctx.layout is not None:
             L, B, Bpad = ctx.layout
             dH = dH.view(L, Bpad, H)[:, :B].transpose(0, 1)
         return dH, dW, dbias, None, None, None, None, None
 
 
-def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp):
+def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, dw_sink=None):
     dev = w_bf.device
     wT = transpose_to_bf16(w_bf, V, H, Hp, Vp, out=workspace("vocab_WT", H * Vp, BF16, dev).view(H, Vp))
     with timed("vocab_dH"):
         dH = gemm_nt(P, Vp, wT, Vp, T, H, Vp)
     hT = transpose_to_bf16(h_bf, T, H, ldh, Tp, out=workspace("vocab_hT", H * Tp, BF16, dev).view(H, Tp))
     with timed("vocab_dW"):
-        dW = gemm_nt(PT, Tp, hT, Tp, V, H, Tp)
+        if dw_sink is not None:
+            gemm_nt(PT, Tp, hT, Tp, V, H, Tp, out=dw_sink, accumulate=True)
+            dW = None
+        else:
+            dW = gemm_nt(PT, Tp, hT, Tp, V, H, Tp)
     return dH, dW
 
 
@@ -295,6 +313,7 @@ class GRULayer(torch.autograd.Function):
         if len(LAST_GRU_SYNC) < 64:
             LAST_GRU_SYNC.append((sync, NG, "pv_gru_fwd"))
         ctx.dims = (B, L, E, H, Hk, K3, Bpad, NG, Ep)
+        ctx.params = (w_ih, w_hh)
         ctx.has_h0 = h0 is not None
         ctx.sync = sync
         ctx.mark_non_differentiable(hseq)
@@ -331,10 +350,15 @@ class GRULayer(torch.autograd.Function):
         # dW_ih = dgi^T x ; dW_hh = dgh^T h_prev   (K = all time-major rows)
         dgiT = transpose_to_bf16(dgi, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
         xT = transpose_to_bf16(x_bf, Tt, E, Ep, Tp, out=workspace("gru_xT", E * Tp, BF16, dev).view(E, Tp))
-        dw_ih = gemm_nt(dgiT, Tp, xT, Tp, 3 * H, E, Tp)
+        p_ih, p_hh = ctx.params
+        sink = grad_sink(p_ih, (3 * H, E))
+        dw_ih = gemm_nt(dgiT, Tp, xT, Tp, 3 * H, E, Tp, out=sink, accumulate=sink is not None)
+        dw_ih = None if sink is not None else dw_ih
         dghT = transpose_to_bf16(dgh, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
         hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
-        dw_hh = gemm_nt(dghT, Tp, hpT, Tp, 3 * H, H, Tp)
+        sink = grad_sink(p_hh, (3 * H, H))
+        dw_hh = gemm_nt(dghT, Tp, hpT, Tp, 3 * H, H, Tp, out=sink, accumulate=sink is not None)
+        dw_hh = None if sink is not None else dw_hh
         return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None
 
 
@@ -358,6 +382,7 @@ class EmbeddingLookup(torch.autograd.Function):
                       None, _stream())
         ctx.save_for_backward(ids_c)
         ctx.meta = (w.shape[0], D, -1 if padding_idx is None else padding_idx)
+        ctx.param = weight
         return out
 
     @staticmethod
@@ -366,13 +391,14 @@ class EmbeddingLookup(torch.autograd.Function):
         rows, D, pad = ctx.meta
         n = ids_c.numel()
         dev = dout.device
-        dw = torch.empty((rows, D), dtype=torch.float32, device=dev)
+        sink = grad_sink(ctx.param, (rows, D))
+        dw = sink if sink is not None else torch.empty((rows, D), dtype=torch.float32, device=dev)
         nbytes = _lib.load().pv_embedding_bwd_ws_bytes(max(n, 1))
         ws = workspace("emb_bwd", nbytes, torch.uint8, dev)
         g = dout.contiguous().view(-1, D)
-        _lib.call("pv_embedding_bwd", _p(g), D, _p(ids_c), n, max(n, 1), max(n, 1), 0, 1, rows, D, pad, 0, _p(dw),
-                  _p(ws), nbytes, _stream())
-        return dw, None, None
+        _lib.call("pv_embedding_bwd", _p(g), D, _p(ids_c), n, max(n, 1), max(n, 1), 0, 1, rows, D, pad,
+                  1 if sink is not None else 0, _p(dw), _p(ws), nbytes, _stream())
+        return (None if sink is not None else dw), None, None
 
 
 def embedding(weight, ids, padding_idx=None):
@@ -405,6 +431,7 @@ class LinearF32(torch.autograd.Function):
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.xshape = x.shape
+        ctx.params = (weight, bias)
         return y.view(tuple(x.shape[:-1]) + (N,))
 
     @staticmethod
@@ -418,12 +445,17 @@ class LinearF32(torch.autograd.Function):
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             _lin(dy2, N, 1, w, K, 1, None, dx, K, M, K, N)                 # dx = dy W
             dx = dx.view(ctx.xshape)
+        p_w, p_b = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            _lin(dy2, 1, N, x2, K, 1, None, dw, K, N, K, M)                # dW = dy^T x
+            sink = grad_sink(p_w, (N, K))
+            dw = sink if sink is not None else torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            _lin(dy2, 1, N, x2, K, 1, None, dw, K, N, K, M, accumulate=1 if sink is not None else 0)   # dW = dy^T x
+            dw = None if sink is not None else dw
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(N, dtype=torch.float32, device=dy.device)
-            _lib.call("pv_colsum_f32", _p(dy2), M, N, N, _p(db), 0, _stream())
+            sink = grad_sink(p_b, (N,))
+            db = sink if sink is not None else torch.empty(N, dtype=torch.float32, device=dy.device)
+            _lib.call("pv_colsum_f32", _p(dy2), M, N, N, _p(db), 1 if sink is not None else 0, _stream())
+            db = None if sink is not None else db
         return dx, dw, db
 
 
