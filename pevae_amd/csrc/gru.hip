@@ -9,16 +9,21 @@
 // GEMM (gemm_bf16.hip) and arrive here as `xproj`.  The serial part, h_{t-1} @ W_hh^T, runs as ONE
 // persistent launch: workgroup (g, s) owns batch rows [32g, 32g+32) and hidden units [U s, U s + U)
 // (U = 16 or 32) and keeps its slice of W_hh (3U rows x H, bf16) resident in LDS for the whole
-// sequence.  Every step it (1) waits until the S workgroups of ITS batch group have published
-// h_{t-1}, (2) pulls the group's h_{t-1} rows (bf16) straight into MFMA A fragments (K split over the
-// 4 waves), (3) multiplies against the LDS-resident weights with v_mfma_f32_16x16x32_bf16, (4) reduces
-// the 4 K-partials through LDS and applies the gate math in-register (the 3 gates of a unit live in
-// one thread), and (5) publishes its slice of h_t.
+// sequence.  Wave (mt, ut) owns the 16 rows x 16 units tile (mt, ut) and computes ALL THREE gate
+// pre-activations of that tile over the full K, so the r/z/n accumulators of one (row, unit) sit in the
+// same lane and the gate math runs straight on the MFMA output registers (no cross-wave reduction).
+// Per step the critical path is: poll the group's arrival counter -> barrier -> 16-byte sc1 loads of
+// h_{t-1} into MFMA A fragments -> 3 x (H/32) MFMAs against the LDS-resident weights -> gates ->
+// bf16 h_t through a 2 KB LDS tile -> ONE 16-byte write-through store per thread -> drain -> barrier ->
+// one arrival.  Everything that is not needed by the next step (fp32 outputs, the saved gates for the
+// backward pass) is stored AFTER the arrival and drains while the next step waits.
 //
-// Inter-workgroup hand-off (cdna guide, Guideline 16, recipe R1): payload = 8-byte write-through
-// (sc1) stores; every storing wave drains vmcnt(0); barrier; ONE lane bumps the group's arrival
-// counter (agent-scope atomic).  Consumer: one lane polls the counter relaxed, ONE agent-scope acquire,
-// vmcnt(0), barrier, then plain loads.  Batch groups are independent, so a barrier spans only the S
+// Inter-workgroup hand-off (cdna guide, Guideline 16; MI355X_MICROARCH "Valid forms", table row 1):
+// every payload byte is stored sc1 (write-through) with 16-byte stores; every storing wave drains
+// vmcnt(0); workgroup barrier; ONE lane adds to the group's arrival counter (agent-scope atomic).
+// Consumer: one lane polls the counter with sc1 loads, workgroup barrier, then EVERY load of the
+// handed-off bytes is a 16-byte `buffer_load ... sc1` to registers -- no L1 invalidate is needed because
+// no plain load ever touches those bytes.  Batch groups are independent, so a barrier spans only the S
 // workgroups of one group.  Nothing depends on dispatch order or XCD placement; every spin is bounded
 // (wall clock) and reports through `err` instead of hanging.  The grid is sized by the host so that all
 // workgroups are co-resident (1 per CU; <= the device's CU count).
@@ -27,13 +32,14 @@
 
 namespace {
 
-constexpr int MT = 2;                       // 16-row MFMA tiles per batch group  -> 32 rows
-constexpr int ROWS = MT * 16;
+constexpr int ROWS = 32;                    // batch rows per group = 2 MFMA row tiles
 constexpr unsigned long long SPIN_LIMIT = 300000000ull;   // 3 s of s_memrealtime (100 MHz)
 
 typedef unsigned int u32;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int AUX_SC1 = 16;                 // cache-policy bits of the raw buffer builtins: sc1
 
-__device__ __forceinline__ u32 ld_relaxed(const u32* p) {
+__device__ __forceinline__ u32 ld_relaxed(const u32* p) {      // global_load_dword ... sc1
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -59,6 +65,9 @@ __device__ __forceinline__ int swz_mask_for(int nchunks) {
   return m - 1;
 }
 
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
+
 struct GruFwdArgs {
   const float* xproj;     // [L][Bpad][3H]  (W_ih x + b_ih), time-major
   const bf16_t* whh;      // [3H][Hk] bf16, columns >= H zero
@@ -72,158 +81,126 @@ struct GruFwdArgs {
   u32* counters;          // [NG] zeroed
   u32* err;
   int L, B, H, Hk, Bpad, NG, G, S, reverse;
+  unsigned hseq_bytes;
 };
 
 template <int UT>
 __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
-  constexpr int U = UT * 16, NT3 = 3 * UT, PPT = MT * UT;   // PPT consecutive units per thread
-  constexpr int PLD = 3 * U + 4;
+  constexpr int U = UT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, q4 = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int mt = w & 1, ut = w >> 1;
+  const bool active = ut < UT;                                // wave owns tile (mt, ut)
   const int g = blockIdx.x / a.S, s = blockIdx.x % a.S, u0 = s * U;
-  const int Hk = a.Hk, nch = Hk / 8, mask = swz_mask_for(nch), NKS = Hk / 32;
+  const int Hk = a.Hk, H = a.H, nch = Hk / 8, mask = swz_mask_for(nch), NKS = Hk / 32;
   char* wl = smem;                                            // [3U][Hk] bf16, swizzled
-  float* part = (float*)(smem + (size_t)3 * U * Hk * 2);      // [4][ROWS][PLD]
+  bf16_t* tile = (bf16_t*)(smem + (size_t)3 * U * Hk * 2);    // [ROWS][U] bf16: h_t of this slice
 
   for (int i = tid; i < 3 * U * nch; i += 256) {              // resident weight slice
     const int n = i / nch, ch = i % nch, gate = n / U, u = n % U;
-    const uint4 v = *(const uint4*)(a.whh + (size_t)(gate * a.H + u0 + u) * Hk + ch * 8);
+    const uint4 v = *(const uint4*)(a.whh + (size_t)(gate * H + u0 + u) * Hk + ch * 8);
     *(uint4*)(wl + (size_t)n * Hk * 2 + ((ch ^ (n & mask)) * 16)) = v;
   }
+  const int unit = u0 + (active ? ut : 0) * 16 + c16;
+  const float bh_r = a.bhh[unit], bh_z = a.bhh[H + unit], bh_n = a.bhh[2 * H + unit];
+  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hseq, 0, a.hseq_bytes, 0x00020000);
+  const bool single = a.NG <= a.G;                            // one row group per workgroup: state stays in registers
+  float hp[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  const int prow = (tid * PPT) / U, pu = (tid * PPT) % U;     // this thread's (row, first unit)
-  bool ok = true;
   for (int step = 0; step < a.L; ++step) {
     const int t = a.reverse ? a.L - 1 - step : step;
     for (int rg = g; rg < a.NG; rg += a.G) {
-      const int row0 = rg * ROWS;
-      const int brow = row0 + prow;
-      const bool live = brow < a.B;
-      // (a) independent of h: this thread's input projections and previous state
-      float xr[PPT], xz[PPT], xn[PPT], hp[PPT];
-      if (live) {
-        const float* xp = a.xproj + ((size_t)t * a.Bpad + brow) * 3 * a.H + u0 + pu;
-        const float* hs = a.hstate + (size_t)brow * a.H + u0 + pu;
+      const int row0 = rg * ROWS, rbase = row0 + mt * 16 + q4 * 4;
+      // (a) independent of h_{t-1}: this lane's input projections (and state, when it is not register resident)
+      float xr[4], xz[4], xn[4];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          xr[k] = xp[k];
-          xz[k] = xp[a.H + k];
-          xn[k] = xp[2 * a.H + k];
-          hp[k] = hs[k];
+      for (int j = 0; j < 4; ++j) {
+        xr[j] = xz[j] = xn[j] = 0.f;
+        if (active && rbase + j < a.B) {
+          const float* xp = a.xproj + ((size_t)t * a.Bpad + rbase + j) * 3 * H + unit;
+          xr[j] = xp[0];
+          xz[j] = xp[H];
+          xn[j] = xp[2 * H];
+          if (!single || step == 0) hp[j] = a.hstate[(size_t)(rbase + j) * H + unit];
         }
       }
       // (b) wait for the group's h_{step-1}
       if (step > 0) {
-        if (tid == 0) {
-          ok = wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (tid == 0) wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
         __syncthreads();
       }
-      // (c) K-split MFMA: wave w takes k-steps w, w+4, ...
-      f32x4 acc[MT][NT3];
+      // (c) three gate tiles over the full K; A fragments straight from the published bf16 states (sc1)
+      f32x4 acc[3];
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (active) {
+        const unsigned abase = (unsigned)((((size_t)step * a.Bpad + row0 + mt * 16 + c16) * Hk + q4 * 8) * 2);
+        for (int ks0 = 0; ks0 < NKS; ks0 += 16) {
+          u32x4 av[16];
 #pragma unroll
-        for (int j = 0; j < NT3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const bf16_t* hsrc = a.hseq + ((size_t)step * a.Bpad + row0) * Hk;
-      for (int ks0 = w; ks0 < NKS; ks0 += 16) {
-        uint4 av[4][MT];
+          for (int kk = 0; kk < 16; ++kk)
+            if (ks0 + kk < NKS) av[kk] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, abase + (ks0 + kk) * 64, 0, AUX_SC1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int ks = ks0 + kk * 4;
-          if (ks < NKS) {
+          for (int kk = 0; kk < 16; ++kk) {
+            const int ks = ks0 + kk;
+            if (ks < NKS) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-              av[kk][i] = *(const uint4*)(hsrc + (size_t)(i * 16 + c16) * Hk + ks * 32 + q4 * 8);
-          }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int ks = ks0 + kk * 4;
-          if (ks < NKS) {
-#pragma unroll
-            for (int j = 0; j < NT3; ++j) {
-              const int n = j * 16 + c16;
-              const bf16x8 b = __builtin_bit_cast(
-                  bf16x8, *(const uint4*)(wl + (size_t)n * Hk * 2 + (((ks * 4 + q4) ^ (n & mask)) * 16)));
-#pragma unroll
-              for (int i = 0; i < MT; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[kk][i]), b,
-                                                                    acc[i][j], 0, 0, 0);
+              for (int gt = 0; gt < 3; ++gt) {
+                const int n = gt * U + ut * 16 + c16;
+                const bf16x8 b = __builtin_bit_cast(
+                    bf16x8, *(const uint4*)(wl + (size_t)n * Hk * 2 + (((ks * 4 + q4) ^ (n & mask)) * 16)));
+                acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[kk]), b, acc[gt], 0, 0, 0);
+              }
             }
           }
         }
       }
+      // (d) gate math on the accumulator layout: lane (c16, q4) holds rows rbase..rbase+3 of unit `unit`
+      float rr[4], zz[4], nn[4], hn[4], hv[4];
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT3; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            part[((size_t)w * ROWS + i * 16 + q4 * 4 + r) * PLD + j * 16 + c16] = acc[i][j][r];
+      for (int j = 0; j < 4; ++j) {
+        const bool live = active && rbase + j < a.B;
+        hn[j] = acc[2][j] + bh_n;
+        rr[j] = fast_sigmoid(xr[j] + acc[0][j] + bh_r);
+        zz[j] = fast_sigmoid(xz[j] + acc[1][j] + bh_z);
+        nn[j] = fast_tanh(xn[j] + rr[j] * hn[j]);
+        hv[j] = live ? (1.f - zz[j]) * nn[j] + zz[j] * hp[j] : 0.f;
+        hp[j] = hv[j];
+        if (active) tile[(mt * 16 + q4 * 4 + j) * U + ut * 16 + c16] = f2bf(hv[j]);
+      }
       __syncthreads();
-      // (d) gate math: PPT consecutive units of one row per thread
-      u32 packed[PPT / 2];
-      {
-        float hnew[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          float hr = 0.f, hz = 0.f, hn = 0.f;
-#pragma unroll
-          for (int ww = 0; ww < 4; ++ww) {
-            const float* pp = part + ((size_t)ww * ROWS + prow) * PLD + pu + k;
-            hr += pp[0];
-            hz += pp[U];
-            hn += pp[2 * U];
-          }
-          const int uu = u0 + pu + k;
-          hr += a.bhh[uu];
-          hz += a.bhh[a.H + uu];
-          hn += a.bhh[2 * a.H + uu];
-          float r = 0.f, z = 0.f, n = 0.f, hv = 0.f;
-          if (live) {
-            r = 1.f / (1.f + expf(-(xr[k] + hr)));
-            z = 1.f / (1.f + expf(-(xz[k] + hz)));
-            n = tanhf(xn[k] + r * hn);
-            hv = (1.f - z) * n + z * hp[k];
-            if (a.gsave) {
-              float* gs = a.gsave + (((size_t)t * a.Bpad + brow) * 4) * a.H + uu;
-              gs[0] = r;
-              gs[a.H] = z;
-              gs[2 * a.H] = n;
-              gs[3 * a.H] = hn;
-            }
-            a.hstate[(size_t)brow * a.H + uu] = hv;
-            if (a.hall) a.hall[((size_t)(step + 1) * a.Bpad + brow) * a.H + uu] = hv;
-            if (a.out) a.out[brow * a.out_sb + t * a.out_st + uu] = hv;
-          }
-          hnew[k] = hv;
-        }
-#pragma unroll
-        for (int k = 0; k < PPT / 2; ++k) packed[k] = pack2bf(hnew[2 * k], hnew[2 * k + 1]);
-      }
-      // (e) publish h_step (write-through stores), then arrive
-      {
-        bf16_t* dst = a.hseq + ((size_t)(step + 1) * a.Bpad + brow) * Hk + u0 + pu;
-        if constexpr (PPT == 2) {
-          __hip_atomic_store((u32*)dst, packed[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-#pragma unroll
-          for (int k = 0; k < PPT / 4; ++k) {
-            const unsigned long long v = (unsigned long long)packed[2 * k] | ((unsigned long long)packed[2 * k + 1] << 32);
-            __hip_atomic_store((unsigned long long*)(dst + 4 * k), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
+      // (e) publish h_step: one 16-byte write-through store per thread, drain, barrier, one arrival
+      if (tid < ROWS * U / 8) {
+        const int row = tid / (U / 8), ch = tid % (U / 8);
+        const u32x4 v = *(const u32x4*)(tile + row * U + ch * 8);
+        const unsigned off = (unsigned)((((size_t)(step + 1) * a.Bpad + row0 + row) * Hk + u0 + ch * 8) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(v, hrsrc, off, 0, AUX_SC1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(a.counters + rg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::: "memory");
+      // (f) everything the next step does not wait for
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int brow = rbase + j;
+        if (active && brow < a.B) {
+          if (a.gsave) {
+            float* gs = a.gsave + (((size_t)t * a.Bpad + brow) * 4) * H + unit;
+            gs[0] = rr[j];
+            gs[H] = zz[j];
+            gs[2 * H] = nn[j];
+            gs[3 * H] = hn[j];
+          }
+          if (!single || step == a.L - 1) a.hstate[(size_t)brow * H + unit] = hv[j];
+          if (a.hall) a.hall[((size_t)(step + 1) * a.Bpad + brow) * H + unit] = hv[j];
+          if (a.out) a.out[brow * a.out_sb + t * a.out_st + unit] = hv[j];
+        }
+      }
     }
   }
-  (void)ok;
 }
 
 struct GruBwdArgs {
@@ -236,37 +213,45 @@ struct GruBwdArgs {
   bf16_t* dgi;            // [L][Bpad][K3] bf16: (dr, dz, dn)       rows >= B zero
   bf16_t* dgh;            // [L][Bpad][K3] bf16: (dr, dz, dn * r)   exchange buffer
   float* dcarry;          // [B][H] fp32 scratch; ends as dL/dh0
-  float* dbias_part;      // [NG][4][H]: sums over rows & time of dr, dz, dn, dn*r
+  float* dbias_part;      // [G][4][H]: sums over rows & time of dr, dz, dn, dn*r
   u32* counters;          // [NG] zeroed
   u32* err;
   int L, B, H, K3, Bpad, NG, G, S, reverse;
+  unsigned dg_bytes;
 };
 
+// Backward through time.  Per step: rec = dgh[previously handled step] @ W_hh (K = 3H, split over the 4
+// waves, partials combined through LDS), then the elementwise gate backward on the MFMA output layout
+// (wave (mt, ut) owns tile (mt, ut) as in the forward kernel), then the bf16 gate gradients go through an
+// LDS tile so that the exchanged copy (dgh) leaves as 16-byte write-through stores; the same hand-off
+// protocol as the forward kernel.
 template <int UT>
 __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
-  constexpr int U = UT * 16, PPT = MT * UT;
-  constexpr int PLD = U + 4;
+  constexpr int U = UT * 16, NTILE = 2 * UT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, q4 = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int mt = w & 1, ut = w >> 1;
+  const bool active = ut < UT;
   const int g = blockIdx.x / a.S, s = blockIdx.x % a.S, u0 = s * U;
   const int K3 = a.K3, nch = K3 / 8, mask = swz_mask_for(nch), NKS = K3 / 32, H = a.H;
-  char* wl = smem;                                           // [U][K3] bf16 swizzled (W_hh^T slice)
-  float* part = (float*)(smem + (size_t)U * K3 * 2);         // [4][ROWS][PLD]
-  float* bred = part + 4 * ROWS * PLD;                       // [ROWS][4][U] bias-grad reduction
+  char* wl = smem;                                                   // [U][K3] bf16 swizzled (W_hh^T slice)
+  f32x4* part = (f32x4*)(smem + (size_t)U * K3 * 2);                 // [4 waves][NTILE][64 lanes]
+  bf16_t* tgh = (bf16_t*)(part + 4 * NTILE * 64);                    // [ROWS][3][U] bf16: dr, dz, dn*r
+  bf16_t* tgi = tgh + ROWS * 3 * U;                                  // [ROWS][3][U] bf16: dr, dz, dn
+  float* bred = (float*)(tgi + ROWS * 3 * U);                        // [8][4][U] bias-grad reduction
 
   for (int i = tid; i < U * nch; i += 256) {
     const int n = i / nch, ch = i % nch;
     const uint4 v = *(const uint4*)(a.whhT + (size_t)(u0 + n) * K3 + ch * 8);
     *(uint4*)(wl + (size_t)n * K3 * 2 + ((ch ^ (n & mask)) * 16)) = v;
   }
+  const int unit = u0 + (active ? ut : 0) * 16 + c16;
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dgh, 0, a.dg_bytes, 0x00020000);
+  const bool single = a.NG <= a.G;
+  float carry[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-
-  const int prow = (tid * PPT) / U, pu = (tid * PPT) % U;
-  float bsum[4][PPT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) bsum[i][k] = 0.f;
 
   // steps run from the last processed time step back to the first; one extra pass (step == L)
   // only folds the recurrent term of the first step into dL/dh0.
@@ -274,39 +259,52 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     const int ti = a.L - 1 - step;                       // processing index whose gradients we form
     const int t = a.reverse ? a.L - 1 - ti : ti;         // time index of that step
     for (int rg = g; rg < a.NG; rg += a.G) {
-      const int row0 = rg * ROWS, brow = row0 + prow;
-      const bool live = brow < a.B;
-      // (a) recurrent term from the previously handled step: dgh[prev] @ W_hh  (K = 3H)
-      float rec[PPT];
+      const int row0 = rg * ROWS, rbase = row0 + mt * 16 + q4 * 4;
+      // (a) independent of the exchange: saved gates / states / upstream gradients of this lane's 4 rows
+      float gr[4], gz[4], gn[4], ghn[4], ghp[4], gdo[4];
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) rec[k] = 0.f;
-      if (step > 0) {
-        if (tid == 0) {
-          wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int j = 0; j < 4; ++j) {
+        gr[j] = gz[j] = gn[j] = ghn[j] = ghp[j] = gdo[j] = 0.f;
+        const int brow = rbase + j;
+        if (active && brow < a.B && step < a.L) {
+          const float* gs = a.gsave + (((size_t)t * a.Bpad + brow) * 4) * H + unit;
+          gr[j] = gs[0];
+          gz[j] = gs[H];
+          gn[j] = gs[2 * H];
+          ghn[j] = gs[3 * H];
+          ghp[j] = a.hall[((size_t)ti * a.Bpad + brow) * H + unit];
+          if (a.dout) gdo[j] = a.dout[brow * a.dout_sb + t * a.dout_st + unit];
+          if (step == 0) {
+            if (a.dhn) gdo[j] += a.dhn[(size_t)brow * H + unit];
+          } else if (!single) {
+            carry[j] = a.dcarry[(size_t)brow * H + unit];
+          }
         }
+      }
+      // (b) recurrent term from the previously handled step: dgh[prev] @ W_hh  (K = 3H)
+      float rec[4] = {0.f, 0.f, 0.f, 0.f};
+      if (step > 0) {
+        if (tid == 0) wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
         __syncthreads();
         const int tprev = a.reverse ? a.L - 1 - (ti + 1) : ti + 1;
-        const bf16_t* src = a.dgh + ((size_t)tprev * a.Bpad + row0) * K3;
-        f32x4 acc[MT][UT];
+        f32x4 acc[2][UT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < UT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks0 = w; ks0 < NKS; ks0 += 16) {
-          uint4 av[4][MT];
+        const unsigned abase = (unsigned)((((size_t)tprev * a.Bpad + row0 + c16) * K3 + q4 * 8) * 2);
+        for (int ks0 = w; ks0 < NKS; ks0 += 48) {           // wave w takes k-steps w, w+4, ... (12 per pass)
+          u32x4 av[12][2];
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int ks = ks0 + kk * 4;
-            if (ks < NKS) {
+          for (int kk = 0; kk < 12; ++kk)
+            if (ks0 + kk * 4 < NKS) {
 #pragma unroll
-              for (int i = 0; i < MT; ++i)
-                av[kk][i] = *(const uint4*)(src + (size_t)(i * 16 + c16) * K3 + ks * 32 + q4 * 8);
+              for (int i = 0; i < 2; ++i)
+                av[kk][i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    grsrc, abase + (unsigned)(i * 16 * K3 * 2) + (ks0 + kk * 4) * 64, 0, AUX_SC1);
             }
-          }
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
+          for (int kk = 0; kk < 12; ++kk) {
             const int ks = ks0 + kk * 4;
             if (ks < NKS) {
 #pragma unroll
@@ -315,113 +313,101 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
                 const bf16x8 b = __builtin_bit_cast(
                     bf16x8, *(const uint4*)(wl + (size_t)n * K3 * 2 + (((ks * 4 + q4) ^ (n & mask)) * 16)));
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[kk][i]), b,
-                                                                      acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[kk][i]), b, acc[i][j], 0, 0, 0);
               }
             }
           }
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < UT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              part[((size_t)w * ROWS + i * 16 + q4 * 4 + r) * PLD + j * 16 + c16] = acc[i][j][r];
+          for (int j = 0; j < UT; ++j) part[(w * NTILE + i * UT + j) * 64 + lane] = acc[i][j];
         __syncthreads();
+        if (active) {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k)
+          for (int ww = 0; ww < 4; ++ww) {
+            const f32x4 p = part[(ww * NTILE + mt * UT + ut) * 64 + lane];
 #pragma unroll
-          for (int ww = 0; ww < 4; ++ww) rec[k] += part[((size_t)ww * ROWS + prow) * PLD + pu + k];
-      }
-      // (b) elementwise backward of step ti
-      if (step == a.L) {
-        if (live) {
-#pragma unroll
-          for (int k = 0; k < PPT; ++k) a.dcarry[(size_t)brow * H + u0 + pu + k] += rec[k];
+            for (int j = 0; j < 4; ++j) rec[j] += p[j];
+          }
         }
-        // the partial buffer is reused by the next row group
-        __syncthreads();
+      }
+      // (c) elementwise backward of step ti
+      if (step == a.L) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int brow = rbase + j;
+          if (active && brow < a.B) {
+            const float prev = single ? carry[j] : a.dcarry[(size_t)brow * H + unit];
+            a.dcarry[(size_t)brow * H + unit] = prev + rec[j];
+          }
+        }
+        __syncthreads();          // the partial buffer is reused by the next row group
         continue;
       }
-      u32 pgi[3][PPT / 2], pgh[PPT / 2];
-      {
-        float vgi[3][PPT], vgh[PPT];
+      float dr[4], dz[4], dn[4], dnr[4];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          const int uu = u0 + pu + k;
-          float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f;
-          if (live) {
-            const float* gs = a.gsave + (((size_t)t * a.Bpad + brow) * 4) * H + uu;
-            const float r = gs[0], z = gs[H], n = gs[2 * H], hn = gs[3 * H];
-            const float hp = a.hall[((size_t)ti * a.Bpad + brow) * H + uu];
-            float dh = rec[k];
-            if (step == 0) {
-              if (a.dhn) dh += a.dhn[(size_t)brow * H + uu];
-            } else {
-              dh += a.dcarry[(size_t)brow * H + uu];
-            }
-            if (a.dout) dh += a.dout[brow * a.dout_sb + t * a.dout_st + uu];
-            dn = dh * (1.f - z) * (1.f - n * n);
-            dz = dh * (hp - n) * z * (1.f - z);
-            dr = dn * hn * r * (1.f - r);
-            dnr = dn * r;
-            a.dcarry[(size_t)brow * H + uu] = dh * z;
-          }
-          vgi[0][k] = dr;
-          vgi[1][k] = dz;
-          vgi[2][k] = dn;
-          vgh[k] = dnr;
-          bsum[0][k] += dr;
-          bsum[1][k] += dz;
-          bsum[2][k] += dn;
-          bsum[3][k] += dnr;
-        }
-#pragma unroll
-        for (int k = 0; k < PPT / 2; ++k) {
-#pragma unroll
-          for (int gt = 0; gt < 3; ++gt) pgi[gt][k] = pack2bf(vgi[gt][2 * k], vgi[gt][2 * k + 1]);
-          pgh[k] = pack2bf(vgh[2 * k], vgh[2 * k + 1]);
+      for (int j = 0; j < 4; ++j) {
+        const bool live = active && rbase + j < a.B;
+        const float dh = rec[j] + gdo[j] + (step > 0 ? carry[j] : 0.f);
+        dn[j] = dh * (1.f - gz[j]) * (1.f - gn[j] * gn[j]);
+        dz[j] = dh * (ghp[j] - gn[j]) * gz[j] * (1.f - gz[j]);
+        dr[j] = dn[j] * ghn[j] * gr[j] * (1.f - gr[j]);
+        dnr[j] = dn[j] * gr[j];
+        if (!live) dn[j] = dz[j] = dr[j] = dnr[j] = 0.f;
+        carry[j] = dh * gz[j];
+        bsum[0] += dr[j];
+        bsum[1] += dz[j];
+        bsum[2] += dn[j];
+        bsum[3] += dnr[j];
+        if (active) {
+          const int o = (mt * 16 + q4 * 4 + j) * 3 * U + ut * 16 + c16;
+          const bf16_t br = f2bf(dr[j]), bz = f2bf(dz[j]);
+          tgh[o] = br;
+          tgh[o + U] = bz;
+          tgh[o + 2 * U] = f2bf(dnr[j]);
+          tgi[o] = br;
+          tgi[o + U] = bz;
+          tgi[o + 2 * U] = f2bf(dn[j]);
         }
       }
-      {
-        const size_t base = ((size_t)t * a.Bpad + brow) * K3 + u0 + pu;
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt) {
-          bf16_t* d1 = a.dgi + base + (size_t)gt * H;
-          bf16_t* d2 = a.dgh + base + (size_t)gt * H;
-          if constexpr (PPT == 2) {
-            *(u32*)d1 = pgi[gt][0];
-            __hip_atomic_store((u32*)d2, gt == 2 ? pgh[0] : pgi[gt][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else {
-#pragma unroll
-            for (int k = 0; k < PPT / 4; ++k) {
-              const unsigned long long vi = (unsigned long long)pgi[gt][2 * k] | ((unsigned long long)pgi[gt][2 * k + 1] << 32);
-              const unsigned long long vh = gt == 2 ? ((unsigned long long)pgh[2 * k] | ((unsigned long long)pgh[2 * k + 1] << 32)) : vi;
-              *(unsigned long long*)(d1 + 4 * k) = vi;
-              __hip_atomic_store((unsigned long long*)(d2 + 4 * k), vh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-        }
+      __syncthreads();
+      // (d) publish dgh (write-through), drain, barrier, arrive; then the copies nobody waits for
+      constexpr int NCH = ROWS * 3 * U / 8;                  // 16-byte chunks per image
+      for (int c = tid; c < NCH; c += 256) {
+        const int row = c / (3 * U / 8), rem = c % (3 * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
+        const u32x4 v = *(const u32x4*)(tgh + row * 3 * U + gt * U + ch * 8);
+        const unsigned off = (unsigned)((((size_t)t * a.Bpad + row0 + row) * K3 + gt * H + u0 + ch * 8) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(v, grsrc, off, 0, AUX_SC1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(a.counters + rg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::: "memory");
+      for (int c = tid; c < NCH; c += 256) {
+        const int row = c / (3 * U / 8), rem = c % (3 * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
+        const uint4 v = *(const uint4*)(tgi + row * 3 * U + gt * U + ch * 8);
+        *(uint4*)(a.dgi + ((size_t)t * a.Bpad + row0 + row) * K3 + gt * H + u0 + ch * 8) = v;
+      }
+      if (!single) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (active && rbase + j < a.B) a.dcarry[(size_t)(rbase + j) * H + unit] = carry[j];
+      }
     }
   }
   // bias-gradient partials: reduce this workgroup's rows in a fixed order
   {
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int k = 0; k < PPT; ++k) bred[((size_t)prow * 4 + i) * U + pu + k] = bsum[i][k];
+      for (int i = 0; i < 4; ++i) bred[((mt * 4 + q4) * 4 + i) * U + ut * 16 + c16] = bsum[i];
+    }
     __syncthreads();
     for (int i = tid; i < 4 * U; i += 256) {
-      const int gt = i / U, u = i % U;
       float sacc = 0.f;
-      for (int r = 0; r < ROWS; ++r) sacc += bred[((size_t)r * 4 + gt) * U + u];
-      a.dbias_part[((size_t)g * 4 + gt) * H + u0 + u] = sacc;
+      for (int r = 0; r < 8; ++r) sacc += bred[r * 4 * U + i];
+      a.dbias_part[((size_t)g * 4 + i / U) * H + u0 + i % U] = sacc;
     }
   }
 }
@@ -499,7 +485,11 @@ int pv_gru_fwd(const float* xproj, const void* whh_bf16, const float* bhh, const
   PV_REQUIRE(xproj && whh_bf16 && bhh && hseq_bf16 && hn && sync && L > 0, "pv_gru_fwd: null/empty argument");
   PV_REQUIRE(((uintptr_t)whh_bf16 & 15) == 0 && ((uintptr_t)hseq_bf16 & 15) == 0, "pv_gru_fwd: bf16 buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int UT = (H % 32 == 0) ? 2 : 1, U = UT * 16, S = H / U;
+  const size_t hseq_bytes = (size_t)(L + 1) * Bpad * Hk * 2;
+  PV_REQUIRE(hseq_bytes < (1ull << 31), "pv_gru_fwd: state sequence of %zu bytes exceeds the 2 GiB buffer-addressing limit", hseq_bytes);
+  int UT = (H % 32 == 0) ? 2 : 1;
+  if (UT == 2 && (size_t)3 * 32 * Hk * 2 + ROWS * 32 * 2 > 160 * 1024) UT = 1;    // weight slice must fit the 160 KiB LDS
+  const int U = UT * 16, S = H / U;
   const int cap = max_wgs > 0 ? max_wgs : cu_count();
   PV_REQUIRE(S <= cap, "pv_gru_fwd: %d unit slices exceed the %d co-resident workgroups available", S, cap);
   const int G = NG < cap / S ? NG : cap / S;
@@ -510,8 +500,8 @@ int pv_gru_fwd(const float* xproj, const void* whh_bf16, const float* bhh, const
   hipLaunchKernelGGL(gru_pack_h0_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, h0, B, H, Hk, (bf16_t*)hseq_bf16, hn, hall);
   PV_LAUNCH_CHECK("gru_pack_h0_kernel");
   GruFwdArgs a{xproj, (const bf16_t*)whh_bf16, bhh, out, out_sb, out_st, (bf16_t*)hseq_bf16, gsave, hn, hall,
-               counters, err, L, B, H, Hk, Bpad, NG, G, S, reverse};
-  const size_t smem = (size_t)3 * U * Hk * 2 + (size_t)4 * ROWS * (3 * U + 4) * 4;
+               counters, err, L, B, H, Hk, Bpad, NG, G, S, reverse, (unsigned)hseq_bytes};
+  const size_t smem = (size_t)3 * U * Hk * 2 + (size_t)ROWS * U * 2;
   static size_t seen_f2 = 0, seen_f1 = 0;
   if (UT == 2) {
     if ((rc = ensure_lds(gru_fwd_kernel<2>, smem, &seen_f2))) return rc;
@@ -534,11 +524,19 @@ int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, 
   PV_REQUIRE(gsave && hall && whhT_bf16 && dgi_bf16 && dgh_bf16 && dh0 && dbias_part && db_ih && db_hh && sync && L > 0,
              "pv_gru_bwd: null/empty argument");
   hipStream_t st = (hipStream_t)stream;
-  const int UT = (H % 32 == 0) ? 2 : 1, U = UT * 16, S = H / U;
+  const size_t dg_bytes = (size_t)L * Bpad * K3 * 2;
+  PV_REQUIRE(dg_bytes < (1ull << 31), "pv_gru_bwd: gate-gradient buffer of %zu bytes exceeds the 2 GiB buffer-addressing limit", dg_bytes);
+  auto lds_need = [&](int ut) {
+    const size_t u = (size_t)ut * 16;
+    return u * K3 * 2 + (size_t)4 * 2 * ut * 64 * 16 + 2 * (size_t)ROWS * 3 * u * 2 + (size_t)8 * 4 * u * 4;
+  };
+  int UT = (H % 32 == 0) ? 2 : 1;
+  if (UT == 2 && lds_need(2) > 160 * 1024) UT = 1;
+  const int U = UT * 16, S = H / U;
   const int cap = max_wgs > 0 ? max_wgs : cu_count();
   PV_REQUIRE(S <= cap, "pv_gru_bwd: %d unit slices exceed the %d co-resident workgroups available", S, cap);
   const int G = NG < cap / S ? NG : cap / S;
-  const size_t smem = (size_t)U * K3 * 2 + (size_t)4 * ROWS * (U + 4) * 4 + (size_t)ROWS * 4 * U * 4;
+  const size_t smem = lds_need(UT);
   PV_REQUIRE(smem <= 160 * 1024, "pv_gru_bwd: LDS need %zu exceeds 160 KiB", smem);
   u32* counters = (u32*)sync;
   u32* err = counters + NG;
@@ -550,7 +548,8 @@ int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, 
     PV_HIP(hipMemsetAsync(dgh_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
   }
   GruBwdArgs a{dout, dout_sb, dout_st, dhn, gsave, hall, (const bf16_t*)whhT_bf16, (bf16_t*)dgi_bf16,
-               (bf16_t*)dgh_bf16, dh0, dbias_part, counters, err, L, B, H, K3, Bpad, NG, G, S, reverse};
+               (bf16_t*)dgh_bf16, dh0, dbias_part, counters, err, L, B, H, K3, Bpad, NG, G, S, reverse,
+               (unsigned)dg_bytes};
   static size_t seen_b2 = 0, seen_b1 = 0;
   if (UT == 2) {
     if ((rc = ensure_lds(gru_bwd_kernel<2>, smem, &seen_b2))) return rc;
