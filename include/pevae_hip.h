@@ -27,12 +27,12 @@ int pv_abi_version(void);
 int pv_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
 /* ---- bf16 MFMA GEMM core -------------------------------------------------------------------------------
- * C[M,N] = A[M,K] B[N,K]^T (+bias[N]); A,B bf16 row-major, K % 64 == 0 (zero padded), lda/ldb % 8 == 0,
+ * C[M,N] = A[M,K] B[N,K]^T (+bias[N], or +bias[M] when bias_per_row != 0); A,B bf16 row-major, K % 64 == 0 (zero padded), lda/ldb % 8 == 0,
  * 16-byte aligned.  Writes fp32 C (C += when accumulate != 0) and/or bf16 Cb.  Replaces the cuBLAS GEMMs inside nn.GRU's input
  * projection (models/enc2dec/base_modules.py:42) and the weight/data-gradient GEMMs of nn.Linear backward
  * for `project` (models/enc2dec/decoders.py:162). */
 int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
-                    float* C, int ldc, void* Cb, int ldcb, int accumulate, void* stream);
+                    int bias_per_row, float* C, int ldc, void* Cb, int ldcb, int accumulate, void* stream);
 
 /* ---- fused vocabulary projection + log-softmax + NLL -----------------------------------------------------
  * Forward: logits = (h W^T + bias) * inv_temp are produced tile-wise by the MFMA GEMM and reduced on the fly
@@ -62,21 +62,23 @@ int pv_logsoftmax_bwd_bf16(const float* logp, const float* dlogp, int T, int V, 
 
 /* ---- persistent GRU recurrence ---------------------------------------------------------------------------
  * torch.nn.GRU semantics (gate order r,z,n) as used at encoders.py:59-62 and decoders.py:182.
- * xproj [L][Bpad][3H] fp32 = W_ih x + b_ih (time-major; from pv_gemm_bf16_nt); whh_bf16 [3H][Hk];
- * hseq_bf16 [(L+1)][Bpad][Hk] scratch (bf16 states, slot i = state before processing step i);
- * out (optional) is written as out[b*out_sb + t*out_st + u]; gsave (optional, training) [L][Bpad][4][H];
- * hall (optional, training) [(L+1)][Bpad][H]; hn [B][H]; sync: pv_gru_sync_bytes(B) bytes, word NG = error flag
- * (1 = a bounded spin timed out).  reverse != 0 walks time backwards (bidirectional encoders).
+ * xprojT [3H][ldx] fp32 = (W_ih x + b_ih) with (time t, batch row b) at column t*Bpad + b (batch row fastest:
+ * one 16-byte load feeds the 4 rows a lane owns; from pv_gemm_bf16_nt with the weight as the A operand);
+ * whh_bf16 [3H][Hk]; hseq_bf16 [(L+1)][Bpad][Hk] scratch (bf16 states, slot i = state before processing step i);
+ * hall [(L+1)][Bpad][H] fp32 states in processing order (slot 0 = h0) -- slots 1..L ARE the layer output
+ * (out[b][t] = hall[t+1][b], or hall[L-t][b] when reverse != 0); gsaveT (optional, training) [L][4][H][Bpad];
+ * hn [B][H]; sync: pv_gru_sync_bytes(B) bytes, word NG = error flag (1 = a bounded spin timed out).
+ * reverse != 0 walks time backwards (bidirectional encoders).
  * max_wgs <= 0 means "one workgroup per CU of the current device". */
 int pv_gru_geometry(int B, int H, int* Hk, int* K3, int* Bpad, int* NG);   /* host out-params */
 size_t pv_gru_sync_bytes(int B);
-int pv_gru_fwd(const float* xproj, const void* whh_bf16, const float* bhh, const float* h0, int L, int B, int H,
-               int reverse, float* out, long out_sb, long out_st, void* hseq_bf16, float* gsave, float* hall,
-               float* hn, void* sync, int max_wgs, void* stream);
+int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0, int L, int B,
+               int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall, float* hn, void* sync, int max_wgs,
+               void* stream);
 /* Backward through time.  whhT_bf16 [H][K3] = W_hh^T.  Emits dgi_bf16 / dgh_bf16 [L][Bpad][K3] (gate
  * gradients w.r.t. the input / hidden pre-activations; GEMM operands for dW_ih, dx, dW_hh), dh0 [B][H],
  * db_ih / db_hh [3H].  dbias_part: NG*4*H floats of scratch. */
-int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsave,
+int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsaveT,
                const float* hall, const void* whhT_bf16, int L, int B, int H, int reverse, void* dgi_bf16,
                void* dgh_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
                int max_wgs, void* stream);

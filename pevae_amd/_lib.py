@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpevae_hip.so")
+# PEVAE_HIP_LIB: load a diagnostic build of the same library instead (tools/ only; there is still no CPU path)
+LIB_PATH = os.environ.get("PEVAE_HIP_LIB") or os.path.join(_HERE, "lib", "libpevae_hip.so")
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 lng = C.c_long
@@ -17,7 +18,7 @@ SIGNATURES = {
     "pv_last_error": (C.c_char_p, []),
     "pv_abi_version": (i32, []),
     "pv_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
-    "pv_gemm_bf16_nt": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]),
+    "pv_gemm_bf16_nt": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp]),
     "pv_vocab_nll_fwd_ws_bytes": (sz, [i32, i32]),
     "pv_vocab_nll_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i64, vp, vp, vp, vp]),
     "pv_vocab_nll_bwd_prob": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, i32, vp, i32, vp, vp, vp]),
@@ -25,7 +26,7 @@ SIGNATURES = {
     "pv_logsoftmax_bwd_bf16": (i32, [vp, vp, i32, i32, f32, vp, i32, vp, vp]),
     "pv_gru_geometry": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "pv_gru_sync_bytes": (sz, [i32]),
-    "pv_gru_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, lng, lng, vp, vp, vp, vp, vp, i32, vp]),
+    "pv_gru_fwd": (i32, [vp, lng, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     "pv_gru_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pv_embedding_gather": (i32, [vp, lng, i32, vp, i32, i32, i32, lng, lng, vp, i32, vp, i32, vp, vp]),
     "pv_embedding_bwd_ws_bytes": (sz, [i32]),

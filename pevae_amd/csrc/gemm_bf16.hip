@@ -135,14 +135,14 @@ struct EpiStore {
   float* C;
   bf16_t* Cb;
   const float* bias;
-  int M, N, ldc, ldcb, accumulate;
+  int M, N, ldc, ldcb, accumulate, bias_per_row;
   __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
     const int c16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int col = col0 + ni * 16 + c16;
       if (col >= N) continue;
-      const float bv = bias ? bias[col] : 0.f;
+      const float bv = (bias && !bias_per_row) ? bias[col] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -150,6 +150,7 @@ struct EpiStore {
           const int row = row0 + mi * 16 + q4 * 4 + j;
           if (row >= M) continue;
           float v = acc[mi][ni][j] + bv;
+          if (bias && bias_per_row) v += bias[row];
           if (C) {
             if (accumulate) v += C[(size_t)row * ldc + col];
             C[(size_t)row * ldc + col] = v;
@@ -413,14 +414,15 @@ int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who) {
 extern "C" {
 
 int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
-                    const float* bias, float* C, int ldc, void* Cb, int ldcb, int accumulate, void* stream) {
+                    const float* bias, int bias_per_row, float* C, int ldc, void* Cb, int ldcb, int accumulate,
+                    void* stream) {
   int rc = check_gemm(A, B, M, N, K, lda, ldb, "pv_gemm_bf16_nt");
   if (rc) return rc;
   PV_REQUIRE(C || Cb, "pv_gemm_bf16_nt: no output given");
   PV_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N), "pv_gemm_bf16_nt: output leading dimension < N");
   GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb};
   PV_REQUIRE(!accumulate || C, "pv_gemm_bf16_nt: accumulate needs the fp32 output");
-  EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb, accumulate};
+  EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb, accumulate, bias_per_row};
   return launch(g, e, (hipStream_t)stream, "pv_gemm_bf16_nt");
 }
 

@@ -29,6 +29,7 @@
 // workgroups are co-resident (1 per CU; <= the device's CU count).
 #include "common.h"
 #include "../../include/pevae_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -43,17 +44,35 @@ __device__ __forceinline__ u32 ld_relaxed(const u32* p) {      // global_load_dw
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// one lane waits for *ctr >= want; returns false on timeout / error already flagged
+// One lane waits for *ctr >= want; returns false on timeout / error already flagged.  The counter line lives at the
+// memory side (atomics are executed there), so every poll is a ~0.5 us round trip: four polls are kept in flight
+// and checked in issue order, which cuts the detection delay to a quarter of a round trip.  The error word and the
+// wall clock are looked at only every 64 polls.
 __device__ __forceinline__ bool wait_ge(const u32* ctr, u32 want, u32* err) {
-  if (ld_relaxed(ctr) >= want) return true;
+  u32 v0 = ld_relaxed(ctr);
+  if (v0 >= want) return true;
+  __builtin_amdgcn_s_sleep(1);
+  u32 v1 = ld_relaxed(ctr);
+  __builtin_amdgcn_s_sleep(1);
+  u32 v2 = ld_relaxed(ctr);
+  __builtin_amdgcn_s_sleep(1);
+  u32 v3 = ld_relaxed(ctr);
   const unsigned long long t0 = wall_clock64();
-  for (;;) {
-    __builtin_amdgcn_s_sleep(1);
-    if (ld_relaxed(ctr) >= want) return true;
-    if (ld_relaxed(err) != 0) return false;
-    if (wall_clock64() - t0 > SPIN_LIMIT) {
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
+  for (unsigned it = 0;; ++it) {
+    if (v0 >= want) return true;
+    v0 = ld_relaxed(ctr);
+    if (v1 >= want) return true;
+    v1 = ld_relaxed(ctr);
+    if (v2 >= want) return true;
+    v2 = ld_relaxed(ctr);
+    if (v3 >= want) return true;
+    v3 = ld_relaxed(ctr);
+    if ((it & 15) == 15) {
+      if (ld_relaxed(err) != 0) return false;
+      if (wall_clock64() - t0 > SPIN_LIMIT) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
     }
   }
 }
@@ -68,146 +87,300 @@ __device__ __forceinline__ int swz_mask_for(int nchunks) {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
 
+// Diagnostic build only (-DPV_GRU_STAMPS): wave 0 accumulates wall-clock (100 MHz) time per segment of the
+// step into words 64.. of the sync buffer.  Never compiled into the shipped library.
+#ifdef PV_GRU_STAMPS
+#define STAMP(i)                                                    \
+  do {                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+    const unsigned long long now__ = wall_clock64();                \
+    stamp_acc[i] += (unsigned)(now__ - stamp_t);                    \
+    stamp_t = now__;                                                \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 struct GruFwdArgs {
-  const float* xproj;     // [L][Bpad][3H]  (W_ih x + b_ih), time-major
+  const float* xprojT;    // [3H][ldx]: (W_ih x + b_ih)[gate*H+u] of (time t, batch row b) at column t*Bpad + b
+  long ldx;
   const bf16_t* whh;      // [3H][Hk] bf16, columns >= H zero
   const float* bhh;       // [3H]
-  float* out;             // optional: out[b*out_sb + t*out_st + u]
-  long out_sb, out_st;
   bf16_t* hseq;           // [(L+1)][Bpad][Hk]; slot i = state before step i (slot 0 pre-filled)
-  float* gsave;           // optional [L][Bpad][4][H]: r, z, n, (W_hn h + b_hn)
-  float* hstate;          // [B][H] running state (pre-filled with h0), ends as h_n
-  float* hall;            // optional [(L+1)][Bpad][H] fp32 states in processing order (slot 0 pre-filled)
+  float* gsaveT;          // optional [L][4][H][Bpad]: r, z, n, (W_hn h + b_hn)   (batch row fastest)
+  float* hstate;          // [B][H]: ends as h_n
+  float* hall;            // [(L+1)][Bpad][H] fp32 states in processing order (slot 0 pre-filled with h0)
   u32* counters;          // [NG] zeroed
   u32* err;
-  int L, B, H, Hk, Bpad, NG, G, S, reverse;
+  u32* stamps;            // diagnostic build only
+  int L, B, H, Hk, Bpad, NG, G, S, reverse, a_lds;
   unsigned hseq_bytes;
+  int dbg;                // timing ablation bits (env PV_GRU_DBG; 0 in normal use, results are wrong otherwise)
 };
 
-template <int UT>
-__global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
-  constexpr int U = UT * 16;
+// Forward kernel.  512 threads = 8 waves with fixed roles:
+//   waves 0-3  compute: wave (mt, ut) owns the 16 rows x 16 units tile (mt, ut): A staging, MFMAs, gates, publish;
+//   wave  4    poller : its lane 0 spins on the group's arrival counter; it never stores, so its sc1 poll
+//                       loads never queue behind stores (vmcnt returns in issue order);
+//   waves 5-7  storers: copy r, z, n, hn (for the backward pass) and the fp32 h_t from an LDS staging area to
+//                       global memory one step behind, so no compute wave ever has a slow store in front of
+//                       a load it waits for.
+// NKS_C: number of 32-deep k-steps (Hk / 32) when known at compile time, 0 = run-time.  With a compile-time trip
+// count the k loop is straight-line and the LDS fragment reads are software-pipelined one 4-k-step chunk ahead
+// of the MFMAs; the run-time variant branches per k-step and is LDS-latency bound (kept for uncommon sizes).
+constexpr int NT_F = 512, NSTORE = 192;
+
+// MT: 16-row MFMA tiles per batch group (group = 16*MT rows).  MT = 1 halves a group's work so that a workgroup
+// can own TWO groups and process them alternately: the hand-off latency of one hides behind the other's work.
+template <int UT, int NKS_C, int MT>
+__global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
+  constexpr int U = UT * 16, RW = MT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q4 = lane >> 4;
-  const int mt = w & 1, ut = w >> 1;
-  const bool active = ut < UT;                                // wave owns tile (mt, ut)
+  const int mt = MT == 2 ? (w & 1) : 0, ut = MT == 2 ? ((w >> 1) & 3) : (w & 3);
+  const bool compute = w < 4, active = compute && ut < UT;   // wave owns tile (mt, ut)
+  const bool storer = w >= 5;
+  const int sid = tid - (NT_F - NSTORE);
   const int g = blockIdx.x / a.S, s = blockIdx.x % a.S, u0 = s * U;
-  const int Hk = a.Hk, H = a.H, nch = Hk / 8, mask = swz_mask_for(nch), NKS = Hk / 32;
+  const int Hk = NKS_C ? NKS_C * 32 : a.Hk, H = a.H, nch = Hk / 8, mask = swz_mask_for(nch), NKS = Hk / 32;
   char* wl = smem;                                            // [3U][Hk] bf16, swizzled
-  bf16_t* tile = (bf16_t*)(smem + (size_t)3 * U * Hk * 2);    // [ROWS][U] bf16: h_t of this slice
+  bf16_t* tile = (bf16_t*)(smem + (size_t)3 * U * Hk * 2);    // [RW][U] bf16: h_t of this slice
+  float* sg = (float*)(tile + RW * U);                      // [4][U][RW] fp32: r, z, n, hn (row fastest)
+  float* shv = sg + 4 * U * RW;                             // [RW][U] fp32: h_t
+  char* al = (char*)(shv + RW * U);                         // [RW][Hk] bf16, swizzled: h_{t-1} of the group (a_lds)
 
-  for (int i = tid; i < 3 * U * nch; i += 256) {              // resident weight slice
+  for (int i = tid; i < 3 * U * nch; i += NT_F) {             // resident weight slice
     const int n = i / nch, ch = i % nch, gate = n / U, u = n % U;
     const uint4 v = *(const uint4*)(a.whh + (size_t)(gate * H + u0 + u) * Hk + ch * 8);
     *(uint4*)(wl + (size_t)n * Hk * 2 + ((ch ^ (n & mask)) * 16)) = v;
   }
-  const int unit = u0 + (active ? ut : 0) * 16 + c16;
+  const int utc = active ? ut : 0;
+  const int unit = u0 + utc * 16 + c16;
   const float bh_r = a.bhh[unit], bh_z = a.bhh[H + unit], bh_n = a.bhh[2 * H + unit];
+  // LDS fragment offsets: 16-byte chunk c of row n sits at chunk (c ^ (n & mask)); with c = ks*4 + q4 the XOR only
+  // touches the low 4 bits, so offset = row base + (ks>>2)*256 + off[ks&3]  (immediates in the unrolled loop)
+  const int m16 = c16 & mask;
+  int boff[3][4], aoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int sw = ((j * 4 + q4) ^ m16) * 16;
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt) boff[gt][j] = (gt * U + utc * 16 + c16) * Hk * 2 + sw;
+    aoff[j] = (mt * 16 + c16) * Hk * 2 + sw;
+  }
   const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hseq, 0, a.hseq_bytes, 0x00020000);
   const bool single = a.NG <= a.G;                            // one row group per workgroup: state stays in registers
   float hp[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
+#ifdef PV_GRU_STAMPS
+  unsigned stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_t = wall_clock64();
+#endif
 
   for (int step = 0; step < a.L; ++step) {
     const int t = a.reverse ? a.L - 1 - step : step;
     for (int rg = g; rg < a.NG; rg += a.G) {
-      const int row0 = rg * ROWS, rbase = row0 + mt * 16 + q4 * 4;
-      // (a) independent of h_{t-1}: this lane's input projections (and state, when it is not register resident)
-      float xr[4], xz[4], xn[4];
+      const int row0 = rg * RW, rbase = row0 + mt * 16 + q4 * 4;
+      // (a) independent of h_{t-1}: this lane's input projections, 4 batch rows per 16-byte load
+      float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), xz = xr, xn = xr;
+      if (active && !(a.dbg & 64)) {
+        const float* xp = a.xprojT + (size_t)unit * a.ldx + (size_t)t * a.Bpad + rbase;
+        xr = *(const float4*)xp;
+        xz = *(const float4*)(xp + (size_t)H * a.ldx);
+        xn = *(const float4*)(xp + (size_t)2 * H * a.ldx);
+        if (step == 0 || !single) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        xr[j] = xz[j] = xn[j] = 0.f;
-        if (active && rbase + j < a.B) {
-          const float* xp = a.xproj + ((size_t)t * a.Bpad + rbase + j) * 3 * H + unit;
-          xr[j] = xp[0];
-          xz[j] = xp[H];
-          xn[j] = xp[2 * H];
-          if (!single || step == 0) hp[j] = a.hstate[(size_t)(rbase + j) * H + unit];
+          for (int j = 0; j < 4; ++j)
+            hp[j] = single ? a.hall[((size_t)rbase + j) * H + unit]
+                           : (rbase + j < a.B ? a.hstate[(size_t)(rbase + j) * H + unit] : 0.f);
         }
       }
+      STAMP(0);
       // (b) wait for the group's h_{step-1}
-      if (step > 0) {
-        if (tid == 0) wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
-        __syncthreads();
-      }
-      // (c) three gate tiles over the full K; A fragments straight from the published bf16 states (sc1)
+      if (step > 0 && tid == 256 && !(a.dbg & 1)) wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
+      STAMP(1);
+      __syncthreads();
+      STAMP(2);
+      // (c) three gate tiles over the full K
       f32x4 acc[3];
 #pragma unroll
       for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (active) {
-        const unsigned abase = (unsigned)((((size_t)step * a.Bpad + row0 + mt * 16 + c16) * Hk + q4 * 8) * 2);
-        for (int ks0 = 0; ks0 < NKS; ks0 += 16) {
-          u32x4 av[16];
+      if (a.a_lds) {
+        // the group's h_{t-1} (RW x Hk bf16) is fetched ONCE per workgroup with sc1 loads and shared through LDS
+        if (compute && !(a.dbg & 2)) {
+          const unsigned gbase = (unsigned)(((size_t)step * a.Bpad + row0) * Hk * 2);
+          for (int i0 = 0; i0 < RW * nch; i0 += 8 * 256) {
+            u32x4 v[8];
 #pragma unroll
-          for (int kk = 0; kk < 16; ++kk)
-            if (ks0 + kk < NKS) av[kk] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, abase + (ks0 + kk) * 64, 0, AUX_SC1);
+            for (int i = 0; i < 8; ++i) {
+              const int idx = i0 + i * 256 + tid;
+              if (idx < RW * nch) v[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, gbase + idx * 16, 0, AUX_SC1);
+            }
 #pragma unroll
-          for (int kk = 0; kk < 16; ++kk) {
-            const int ks = ks0 + kk;
-            if (ks < NKS) {
+            for (int i = 0; i < 8; ++i) {
+              const int idx = i0 + i * 256 + tid;
+              if (idx < RW * nch) {
+                const int row = idx / nch, ch = idx % nch;
+                *(u32x4*)(al + (size_t)row * Hk * 2 + ((ch ^ (row & mask)) * 16)) = v[i];
+              }
+            }
+          }
+        }
+        __syncthreads();
+        STAMP(3);
+        if (active && !(a.dbg & 4)) {
+          if constexpr (NKS_C > 0) {
+            // fragments of 2 k-steps per chunk, read one chunk ahead of the MFMAs that consume them
+            constexpr int NC = NKS_C / 2;
+            static_assert(NKS_C % 4 == 0, "compile-time k-step count must be a multiple of 4");
+            bf16x8 fa[2][2], fb[2][3][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              fa[0][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(al + aoff[j]));
+#pragma unroll
+              for (int gt = 0; gt < 3; ++gt) fb[0][gt][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[gt][j]));
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const int cur = c & 1, nxt = cur ^ 1;
+              if (c + 1 < NC) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                  const int ks = (c + 1) * 2 + j, o = (ks >> 2) * 256;
+                  fa[nxt][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(al + aoff[ks & 3] + o));
+#pragma unroll
+                  for (int gt = 0; gt < 3; ++gt)
+                    fb[nxt][gt][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[gt][ks & 3] + o));
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt)
+                  acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][j], fb[cur][gt][j], acc[gt], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+            for (int ks = 0; ks < NKS; ++ks) {
+              const int o = (ks >> 2) * 256;
+              const bf16x8 av = __builtin_bit_cast(bf16x8, *(const uint4*)(al + aoff[ks & 3] + o));
 #pragma unroll
               for (int gt = 0; gt < 3; ++gt) {
-                const int n = gt * U + ut * 16 + c16;
-                const bf16x8 b = __builtin_bit_cast(
-                    bf16x8, *(const uint4*)(wl + (size_t)n * Hk * 2 + (((ks * 4 + q4) ^ (n & mask)) * 16)));
+                const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[gt][ks & 3] + o));
+                acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b, acc[gt], 0, 0, 0);
+              }
+            }
+          }
+        }
+      } else if (NKS_C == 0 && active) {
+        // LDS too small for the shared copy (H > 512): A fragments straight from the published states
+        const unsigned abase = (unsigned)((((size_t)step * a.Bpad + row0 + mt * 16 + c16) * Hk + q4 * 8) * 2);
+        for (int ks0 = 0; ks0 < NKS; ks0 += 8) {
+          u32x4 av[8];
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk)
+            if (ks0 + kk < NKS) av[kk] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, abase + (ks0 + kk) * 64, 0, AUX_SC1);
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            if (ks0 + kk < NKS) {
+              const int o = ks0 * 64 + (kk >> 2) * 256;
+#pragma unroll
+              for (int gt = 0; gt < 3; ++gt) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[gt][kk & 3] + o));
                 acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[kk]), b, acc[gt], 0, 0, 0);
               }
             }
           }
         }
       }
+      STAMP(4);
       // (d) gate math on the accumulator layout: lane (c16, q4) holds rows rbase..rbase+3 of unit `unit`
-      float rr[4], zz[4], nn[4], hn[4], hv[4];
+      float hv[4];
+      if (active) {
+        const float xrv[4] = {xr.x, xr.y, xr.z, xr.w}, xzv[4] = {xz.x, xz.y, xz.z, xz.w}, xnv[4] = {xn.x, xn.y, xn.z, xn.w};
+        float rr[4], zz[4], nn[4], hn[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool live = active && rbase + j < a.B;
-        hn[j] = acc[2][j] + bh_n;
-        rr[j] = fast_sigmoid(xr[j] + acc[0][j] + bh_r);
-        zz[j] = fast_sigmoid(xz[j] + acc[1][j] + bh_z);
-        nn[j] = fast_tanh(xn[j] + rr[j] * hn[j]);
-        hv[j] = live ? (1.f - zz[j]) * nn[j] + zz[j] * hp[j] : 0.f;
-        hp[j] = hv[j];
-        if (active) tile[(mt * 16 + q4 * 4 + j) * U + ut * 16 + c16] = f2bf(hv[j]);
+        for (int j = 0; j < 4; ++j) {
+          hn[j] = acc[2][j] + bh_n;
+          rr[j] = fast_sigmoid(xrv[j] + acc[0][j] + bh_r);
+          zz[j] = fast_sigmoid(xzv[j] + acc[1][j] + bh_z);
+          nn[j] = fast_tanh(xnv[j] + rr[j] * hn[j]);
+          hv[j] = (rbase + j < a.B) ? nn[j] + zz[j] * (hp[j] - nn[j]) : 0.f;
+          hp[j] = hv[j];
+        }
+        const int lu = ut * 16 + c16, lr = mt * 16 + q4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          tile[(lr + j) * U + lu] = f2bf(hv[j]);
+          shv[(lr + j) * U + lu] = hv[j];
+        }
+        if (a.gsaveT) {
+          *(float4*)(sg + (0 * U + lu) * RW + lr) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+          *(float4*)(sg + (1 * U + lu) * RW + lr) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+          *(float4*)(sg + (2 * U + lu) * RW + lr) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+          *(float4*)(sg + (3 * U + lu) * RW + lr) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        }
       }
       __syncthreads();
-      // (e) publish h_step: one 16-byte write-through store per thread, drain, barrier, one arrival
-      if (tid < ROWS * U / 8) {
+      STAMP(5);
+      // (e) publish h_step: one 16-byte write-through store per thread, drain, barrier, one arrival.
+      //     (The storer waves copy the staged values out after the arrival; the staging area is not rewritten
+      //     before they have passed the next two barriers.)
+      constexpr int NG4 = 4 * U * RW / 4, IT_G = (NG4 + NSTORE - 1) / NSTORE;
+      constexpr int NH4 = RW * U / 4, IT_H = (NH4 + NSTORE - 1) / NSTORE;
+      if (tid < RW * U / 8 && !(a.dbg & 8)) {
         const int row = tid / (U / 8), ch = tid % (U / 8);
         const u32x4 v = *(const u32x4*)(tile + row * U + ch * 8);
         const unsigned off = (unsigned)((((size_t)(step + 1) * a.Bpad + row0 + row) * Hk + u0 + ch * 8) * 2);
         __builtin_amdgcn_raw_buffer_store_b128(v, hrsrc, off, 0, AUX_SC1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(6);
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(a.counters + rg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && !(a.dbg & 16)) __hip_atomic_fetch_add(a.counters + rg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("" ::: "memory");
+      STAMP(7);
       // (f) everything the next step does not wait for
+      if (storer && !(a.dbg & 32)) {
+        if (a.gsaveT) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int brow = rbase + j;
-        if (active && brow < a.B) {
-          if (a.gsave) {
-            float* gs = a.gsave + (((size_t)t * a.Bpad + brow) * 4) * H + unit;
-            gs[0] = rr[j];
-            gs[H] = zz[j];
-            gs[2 * H] = nn[j];
-            gs[3 * H] = hn[j];
+          for (int k = 0; k < IT_G; ++k) {
+            const int i = sid + k * NSTORE;          // float4 index into sg: [(q*U + unit)][row/4]
+            if (i < NG4) {
+              const int qu = i / (RW / 4), r4 = i % (RW / 4), q = qu / U, lu = qu % U;
+              *(float4*)(a.gsaveT + (((size_t)t * 4 + q) * H + u0 + lu) * a.Bpad + row0 + r4 * 4) = *(const float4*)(sg + i * 4);
+            }
           }
-          if (!single || step == a.L - 1) a.hstate[(size_t)brow * H + unit] = hv[j];
-          if (a.hall) a.hall[((size_t)(step + 1) * a.Bpad + brow) * H + unit] = hv[j];
-          if (a.out) a.out[brow * a.out_sb + t * a.out_st + unit] = hv[j];
         }
+#pragma unroll
+        for (int k = 0; k < IT_H; ++k) {
+          const int i = sid + k * NSTORE;            // float4 index into shv: [row][unit/4]
+          if (i < NH4) {
+            const int row = i / (U / 4), c4 = i % (U / 4);
+            *(float4*)(a.hall + ((size_t)(step + 1) * a.Bpad + row0 + row) * H + u0 + c4 * 4) = *(const float4*)(shv + i * 4);
+          }
+        }
+      } else if (active && (!single || step == a.L - 1)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (rbase + j < a.B) a.hstate[(size_t)(rbase + j) * H + unit] = hv[j];
       }
+      STAMP(8);
     }
   }
+#ifdef PV_GRU_STAMPS
+  if (tid == 0 && blockIdx.x < 16)
+    for (int i = 0; i < 10; ++i) a.stamps[blockIdx.x * 10 + i] = stamp_acc[i];
+#endif
 }
 
 struct GruBwdArgs {
   const float* dout;      // optional dL/d out: dout[b*sb + t*st + u]
   long dout_sb, dout_st;
   const float* dhn;       // optional [B][H]
-  const float* gsave;     // [L][Bpad][4][H]
+  const float* gsaveT;    // [L][4][H][Bpad]  (batch row fastest)
   const float* hall;      // [(L+1)][Bpad][H] fp32 states in processing order (slot i = state before step i)
   const bf16_t* whhT;     // [H][K3] bf16: whhT[u][k] = W_hh[k][u], columns >= 3H zero
   bf16_t* dgi;            // [L][Bpad][K3] bf16: (dr, dz, dn)       rows >= B zero
@@ -225,7 +398,7 @@ struct GruBwdArgs {
 // (wave (mt, ut) owns tile (mt, ut) as in the forward kernel), then the bf16 gate gradients go through an
 // LDS tile so that the exchanged copy (dgh) leaves as 16-byte write-through stores; the same hand-off
 // protocol as the forward kernel.
-template <int UT>
+template <int UT, int NKS_C>
 __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   constexpr int U = UT * 16, NTILE = 2 * UT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -234,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   const int mt = w & 1, ut = w >> 1;
   const bool active = ut < UT;
   const int g = blockIdx.x / a.S, s = blockIdx.x % a.S, u0 = s * U;
-  const int K3 = a.K3, nch = K3 / 8, mask = swz_mask_for(nch), NKS = K3 / 32, H = a.H;
+  const int K3 = NKS_C ? NKS_C * 32 : a.K3, nch = K3 / 8, mask = swz_mask_for(nch), NKS = K3 / 32, H = a.H;
   char* wl = smem;                                                   // [U][K3] bf16 swizzled (W_hh^T slice)
   f32x4* part = (f32x4*)(smem + (size_t)U * K3 * 2);                 // [4 waves][NTILE][64 lanes]
   bf16_t* tgh = (bf16_t*)(part + 4 * NTILE * 64);                    // [ROWS][3][U] bf16: dr, dz, dn*r
@@ -247,6 +420,11 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     *(uint4*)(wl + (size_t)n * K3 * 2 + ((ch ^ (n & mask)) * 16)) = v;
   }
   const int unit = u0 + (active ? ut : 0) * 16 + c16;
+  // wave w takes k-steps ks = w + 4*i: chunk ks*4 + q4 has constant low bits (w*4 + q4), so the swizzled
+  // LDS offset is a per-lane base + i*256
+  int boff[UT];
+#pragma unroll
+  for (int j = 0; j < UT; ++j) boff[j] = (j * 16 + c16) * K3 * 2 + ((((w & 3) * 4 + q4) ^ (c16 & mask)) * 16);
   const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dgh, 0, a.dg_bytes, 0x00020000);
   const bool single = a.NG <= a.G;
   float carry[4] = {0.f, 0.f, 0.f, 0.f};
@@ -262,16 +440,24 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
       const int row0 = rg * ROWS, rbase = row0 + mt * 16 + q4 * 4;
       // (a) independent of the exchange: saved gates / states / upstream gradients of this lane's 4 rows
       float gr[4], gz[4], gn[4], ghn[4], ghp[4], gdo[4];
+      if (active && step < a.L) {
+        const float* gs = a.gsaveT + ((size_t)t * 4 * H + unit) * a.Bpad + rbase;
+        const size_t gq = (size_t)H * a.Bpad;
+        const float4 v0 = *(const float4*)gs, v1 = *(const float4*)(gs + gq), v2 = *(const float4*)(gs + 2 * gq),
+                     v3 = *(const float4*)(gs + 3 * gq);
+        gr[0] = v0.x; gr[1] = v0.y; gr[2] = v0.z; gr[3] = v0.w;
+        gz[0] = v1.x; gz[1] = v1.y; gz[2] = v1.z; gz[3] = v1.w;
+        gn[0] = v2.x; gn[1] = v2.y; gn[2] = v2.z; gn[3] = v2.w;
+        ghn[0] = v3.x; ghn[1] = v3.y; ghn[2] = v3.z; ghn[3] = v3.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gr[j] = gz[j] = gn[j] = ghn[j] = 0.f;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        gr[j] = gz[j] = gn[j] = ghn[j] = ghp[j] = gdo[j] = 0.f;
+        ghp[j] = gdo[j] = 0.f;
         const int brow = rbase + j;
         if (active && brow < a.B && step < a.L) {
-          const float* gs = a.gsave + (((size_t)t * a.Bpad + brow) * 4) * H + unit;
-          gr[j] = gs[0];
-          gz[j] = gs[H];
-          gn[j] = gs[2 * H];
-          ghn[j] = gs[3 * H];
           ghp[j] = a.hall[((size_t)ti * a.Bpad + brow) * H + unit];
           if (a.dout) gdo[j] = a.dout[brow * a.dout_sb + t * a.dout_st + unit];
           if (step == 0) {
@@ -309,9 +495,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
             if (ks < NKS) {
 #pragma unroll
               for (int j = 0; j < UT; ++j) {
-                const int n = j * 16 + c16;
-                const bf16x8 b = __builtin_bit_cast(
-                    bf16x8, *(const uint4*)(wl + (size_t)n * K3 * 2 + (((ks * 4 + q4) ^ (n & mask)) * 16)));
+                const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[j] + (ks0 >> 2) * 256 + kk * 256));
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                   acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[kk][i]), b, acc[i][j], 0, 0, 0);
@@ -474,54 +658,84 @@ int pv_gru_geometry(int B, int H, int* Hk, int* K3, int* Bpad, int* NG) {
   return PV_OK;
 }
 
-size_t pv_gru_sync_bytes(int B) { return ((size_t)cdiv(B, ROWS) + 1) * sizeof(u32); }
+size_t pv_gru_sync_bytes(int B) {
+#ifdef PV_GRU_STAMPS
+  return 1024;
+#else
+  return ((size_t)3 * cdiv(B, ROWS) + 2) * sizeof(u32);   // [NG]: unused, [NG]: error flag, then up to 2*NG arrival counters
+#endif
+}
 
-int pv_gru_fwd(const float* xproj, const void* whh_bf16, const float* bhh, const float* h0, int L, int B,
-               int H, int reverse, float* out, long out_sb, long out_st, void* hseq_bf16, float* gsave,
-               float* hall, float* hn, void* sync, int max_wgs, void* stream) {
+int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0, int L, int B,
+               int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall, float* hn, void* sync, int max_wgs,
+               void* stream) {
   int Hk, K3, Bpad, NG;
   int rc = pv_gru_geometry(B, H, &Hk, &K3, &Bpad, &NG);
   if (rc) return rc;
-  PV_REQUIRE(xproj && whh_bf16 && bhh && hseq_bf16 && hn && sync && L > 0, "pv_gru_fwd: null/empty argument");
+  PV_REQUIRE(xprojT && whh_bf16 && bhh && hseq_bf16 && hall && hn && sync && L > 0, "pv_gru_fwd: null/empty argument");
   PV_REQUIRE(((uintptr_t)whh_bf16 & 15) == 0 && ((uintptr_t)hseq_bf16 & 15) == 0, "pv_gru_fwd: bf16 buffers must be 16-byte aligned");
+  PV_REQUIRE(ldx >= (long)L * Bpad && ldx % 4 == 0 && ((uintptr_t)xprojT & 15) == 0 && ((uintptr_t)gsaveT & 15) == 0,
+             "pv_gru_fwd: xprojT needs ldx >= L*Bpad = %ld, ldx %% 4 == 0 and 16-byte alignment (also gsaveT)", (long)L * Bpad);
   hipStream_t st = (hipStream_t)stream;
   const size_t hseq_bytes = (size_t)(L + 1) * Bpad * Hk * 2;
   PV_REQUIRE(hseq_bytes < (1ull << 31), "pv_gru_fwd: state sequence of %zu bytes exceeds the 2 GiB buffer-addressing limit", hseq_bytes);
   int UT = (H % 32 == 0) ? 2 : 1;
-  if (UT == 2 && (size_t)3 * 32 * Hk * 2 + ROWS * 32 * 2 > 160 * 1024) UT = 1;    // weight slice must fit the 160 KiB LDS
+  if (UT == 2 && (size_t)3 * 32 * Hk * 2 + ROWS * 32 * 2 + 5 * 32 * ROWS * 4 > 160 * 1024) UT = 1;   // weight slice must fit the 160 KiB LDS
   const int U = UT * 16, S = H / U;
   const int cap = max_wgs > 0 ? max_wgs : cu_count();
   PV_REQUIRE(S <= cap, "pv_gru_fwd: %d unit slices exceed the %d co-resident workgroups available", S, cap);
-  const int G = NG < cap / S ? NG : cap / S;
-  u32* counters = (u32*)sync;
-  u32* err = counters + NG;
+  // Group shape: 32-row groups, one per workgroup when they all fit.  (16-row groups, two per workgroup processed
+  // alternately, were measured slower at B=256, H=512 -- 544 vs 430 us -- because the per-group cost is dominated by
+  // fixed barrier / latency terms, not by rows; kept selectable with PV_GRU_MT=1 for experiments.)
+  int MT = 2;
+  if (const char* e = getenv("PV_GRU_MT")) MT = atoi(e) == 1 ? 1 : 2;
+  const int RW = MT * 16, NGk = Bpad / RW;
+  int G = NGk < cap / S ? NGk : cap / S;
+  if (MT == 1 && G > (NGk + 1) / 2) G = (NGk + 1) / 2;         // two groups per workgroup
+  if (const char* e = getenv("PV_GRU_G")) { const int v = atoi(e); if (v >= 1 && v <= G) G = v; }
+  u32* err = (u32*)sync + NG;
+  u32* counters = err + 1;
   PV_HIP(hipMemsetAsync(sync, 0, pv_gru_sync_bytes(B), st));
   if (Hk != H || Bpad != B) PV_HIP(hipMemsetAsync(hseq_bf16, 0, (size_t)(L + 1) * Bpad * Hk * 2, st));
   hipLaunchKernelGGL(gru_pack_h0_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, h0, B, H, Hk, (bf16_t*)hseq_bf16, hn, hall);
   PV_LAUNCH_CHECK("gru_pack_h0_kernel");
-  GruFwdArgs a{xproj, (const bf16_t*)whh_bf16, bhh, out, out_sb, out_st, (bf16_t*)hseq_bf16, gsave, hn, hall,
-               counters, err, L, B, H, Hk, Bpad, NG, G, S, reverse, (unsigned)hseq_bytes};
-  const size_t smem = (size_t)3 * U * Hk * 2 + (size_t)ROWS * U * 2;
-  static size_t seen_f2 = 0, seen_f1 = 0;
-  if (UT == 2) {
-    if ((rc = ensure_lds(gru_fwd_kernel<2>, smem, &seen_f2))) return rc;
-    hipLaunchKernelGGL(gru_fwd_kernel<2>, dim3(G * S), dim3(256), smem, st, a);
+  const size_t smem_base = (size_t)3 * U * Hk * 2 + (size_t)RW * U * 2 + (size_t)5 * U * RW * 4,
+               smem_a = (size_t)RW * Hk * 2;
+  const int a_lds = smem_base + smem_a <= 160 * 1024;       // share the group's h_{t-1} through LDS when it fits
+  const size_t smem = smem_base + (a_lds ? smem_a : 0);
+  GruFwdArgs a{xprojT, ldx, (const bf16_t*)whh_bf16, bhh, (bf16_t*)hseq_bf16, gsaveT, hn, hall,
+               counters, err, (u32*)sync + 64, L, B, H, Hk, Bpad, NGk, G, S, reverse, a_lds, (unsigned)hseq_bytes, 0};
+  if (const char* e = getenv("PV_GRU_DBG")) a.dbg = atoi(e);
+#define PV_GRU_LAUNCH_F(UTv, NKv, MTv)                                                           \
+  do {                                                                                           \
+    static size_t seen = 0;                                                                      \
+    if ((rc = ensure_lds(gru_fwd_kernel<UTv, NKv, MTv>, smem, &seen))) return rc;                \
+    hipLaunchKernelGGL((gru_fwd_kernel<UTv, NKv, MTv>), dim3(G * S), dim3(NT_F), smem, st, a);   \
+  } while (0)
+  if (MT == 1) {
+    if (UT == 2 && Hk == 512 && a_lds) PV_GRU_LAUNCH_F(2, 16, 1);
+    else if (UT == 2 && Hk == 256 && a_lds) PV_GRU_LAUNCH_F(2, 8, 1);
+    else if (UT == 2) PV_GRU_LAUNCH_F(2, 0, 1);
+    else PV_GRU_LAUNCH_F(1, 0, 1);
   } else {
-    if ((rc = ensure_lds(gru_fwd_kernel<1>, smem, &seen_f1))) return rc;
-    hipLaunchKernelGGL(gru_fwd_kernel<1>, dim3(G * S), dim3(256), smem, st, a);
+    if (UT == 2 && Hk == 512 && a_lds) PV_GRU_LAUNCH_F(2, 16, 2);
+    else if (UT == 2 && Hk == 256 && a_lds) PV_GRU_LAUNCH_F(2, 8, 2);
+    else if (UT == 2) PV_GRU_LAUNCH_F(2, 0, 2);
+    else PV_GRU_LAUNCH_F(1, 0, 2);
   }
+#undef PV_GRU_LAUNCH_F
   PV_LAUNCH_CHECK("gru_fwd_kernel");
   return PV_OK;
 }
 
-int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsave,
+int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsaveT,
                const float* hall, const void* whhT_bf16, int L, int B, int H, int reverse, void* dgi_bf16,
                void* dgh_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
                int max_wgs, void* stream) {
   int Hk, K3, Bpad, NG;
   int rc = pv_gru_geometry(B, H, &Hk, &K3, &Bpad, &NG);
   if (rc) return rc;
-  PV_REQUIRE(gsave && hall && whhT_bf16 && dgi_bf16 && dgh_bf16 && dh0 && dbias_part && db_ih && db_hh && sync && L > 0,
+  PV_REQUIRE(gsaveT && hall && whhT_bf16 && dgi_bf16 && dgh_bf16 && dh0 && dbias_part && db_ih && db_hh && sync && L > 0,
              "pv_gru_bwd: null/empty argument");
   hipStream_t st = (hipStream_t)stream;
   const size_t dg_bytes = (size_t)L * Bpad * K3 * 2;
@@ -538,8 +752,8 @@ int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, 
   const int G = NG < cap / S ? NG : cap / S;
   const size_t smem = lds_need(UT);
   PV_REQUIRE(smem <= 160 * 1024, "pv_gru_bwd: LDS need %zu exceeds 160 KiB", smem);
-  u32* counters = (u32*)sync;
-  u32* err = counters + NG;
+  u32* err = (u32*)sync + NG;
+  u32* counters = err + 1;
   PV_HIP(hipMemsetAsync(sync, 0, pv_gru_sync_bytes(B), st));
   PV_HIP(hipMemsetAsync(dh0, 0, (size_t)B * H * sizeof(float), st));
   PV_HIP(hipMemsetAsync(dbias_part, 0, (size_t)NG * 4 * H * sizeof(float), st));
@@ -547,17 +761,20 @@ int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, 
     PV_HIP(hipMemsetAsync(dgi_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
     PV_HIP(hipMemsetAsync(dgh_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
   }
-  GruBwdArgs a{dout, dout_sb, dout_st, dhn, gsave, hall, (const bf16_t*)whhT_bf16, (bf16_t*)dgi_bf16,
+  GruBwdArgs a{dout, dout_sb, dout_st, dhn, gsaveT, hall, (const bf16_t*)whhT_bf16, (bf16_t*)dgi_bf16,
                (bf16_t*)dgh_bf16, dh0, dbias_part, counters, err, L, B, H, K3, Bpad, NG, G, S, reverse,
                (unsigned)dg_bytes};
-  static size_t seen_b2 = 0, seen_b1 = 0;
-  if (UT == 2) {
-    if ((rc = ensure_lds(gru_bwd_kernel<2>, smem, &seen_b2))) return rc;
-    hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3(G * S), dim3(256), smem, st, a);
-  } else {
-    if ((rc = ensure_lds(gru_bwd_kernel<1>, smem, &seen_b1))) return rc;
-    hipLaunchKernelGGL(gru_bwd_kernel<1>, dim3(G * S), dim3(256), smem, st, a);
-  }
+#define PV_GRU_LAUNCH_B(UTv, NKv)                                                             \
+  do {                                                                                        \
+    static size_t seen = 0;                                                                   \
+    if ((rc = ensure_lds(gru_bwd_kernel<UTv, NKv>, smem, &seen))) return rc;                  \
+    hipLaunchKernelGGL((gru_bwd_kernel<UTv, NKv>), dim3(G * S), dim3(256), smem, st, a);      \
+  } while (0)
+  if (UT == 2 && K3 == 1536) PV_GRU_LAUNCH_B(2, 48);
+  else if (UT == 2 && K3 == 768) PV_GRU_LAUNCH_B(2, 24);
+  else if (UT == 2) PV_GRU_LAUNCH_B(2, 0);
+  else PV_GRU_LAUNCH_B(1, 0);
+#undef PV_GRU_LAUNCH_B
   PV_LAUNCH_CHECK("gru_bwd_kernel");
   hipLaunchKernelGGL(gru_bias_reduce_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, dbias_part, G, H, db_ih, db_hh);
   PV_LAUNCH_CHECK("gru_bias_reduce_kernel");

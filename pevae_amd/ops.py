@@ -109,12 +109,12 @@ def transpose_to_bf16(src, R, Cc, lds, rpad, out=None):
     return out
 
 
-def gemm_nt(A, lda, Bm, ldb, M, N, K, bias=None, out=None, out_bf16=None, accumulate=False):
+def gemm_nt(A, lda, Bm, ldb, M, N, K, bias=None, out=None, out_bf16=None, accumulate=False, bias_per_row=False):
     """C[M,N] (+)= A[M,K] B[N,K]^T (+bias) with bf16 operands on the MFMA core."""
     _need_cuda(A, Bm)
     if out is None and out_bf16 is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    _lib.call("pv_gemm_bf16_nt", _p(A), lda, _p(Bm), ldb, M, N, K, _p(bias), _p(out),
+    _lib.call("pv_gemm_bf16_nt", _p(A), lda, _p(Bm), ldb, M, N, K, _p(bias), 1 if bias_per_row else 0, _p(out),
               0 if out is None else out.stride(0), _p(out_bf16), 0 if out_bf16 is None else out_bf16.stride(0),
               1 if accumulate else 0, _stream())
     return out if out is not None else out_bf16
@@ -296,18 +296,19 @@ class GRULayer(torch.autograd.Function):
         x_bf = cast_pack(x, L, B, Bpad, E, x.stride(1), x.stride(0), x.stride(2), Ep)
         wih_bf = pack_matrix(w_ih, Ep)
         whh_bf = pack_matrix(w_hh, Hk)
-        xproj = gemm_nt(x_bf, Ep, wih_bf, Ep, L * Bpad, 3 * H, Ep, bias=b_ih.contiguous(),
-                        out=workspace("gru_xproj", L * Bpad * 3 * H, torch.float32, dev).view(L * Bpad, 3 * H))
-        out = torch.empty((B, L, H), dtype=torch.float32, device=dev)
+        # xproj^T [3H][L*Bpad]: the weight is the A operand, so a lane of the recurrence finds its 4 batch rows in 16 bytes
+        xprojT = gemm_nt(wih_bf, Ep, x_bf, Ep, 3 * H, L * Bpad, Ep, bias=b_ih.contiguous(), bias_per_row=True,
+                         out=workspace("gru_xprojT", 3 * H * L * Bpad, torch.float32, dev).view(3 * H, L * Bpad))
         hseq = torch.empty(((L + 1) * Bpad, Hk), dtype=BF16, device=dev)
         hn = torch.empty((B, H), dtype=torch.float32, device=dev)
-        gsave = torch.empty((L * Bpad, 4 * H), dtype=torch.float32, device=dev) if save else None
-        hall = torch.empty(((L + 1) * Bpad, H), dtype=torch.float32, device=dev) if save else None
+        gsave = torch.empty((L * 4 * H, Bpad), dtype=torch.float32, device=dev) if save else None
+        hall = torch.empty(((L + 1), Bpad, H), dtype=torch.float32, device=dev)
         sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
         h0c = None if h0 is None else h0.contiguous()
         with timed("gru_fwd"):
-            _lib.call("pv_gru_fwd", _p(xproj), _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), L, B, H, 0, _p(out), L * H,
-                      H, _p(hseq), _p(gsave), _p(hall), _p(hn), _p(sync), GRU_MAX_WGS, _stream())
+            _lib.call("pv_gru_fwd", _p(xprojT), L * Bpad, _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), L, B, H, 0,
+                      _p(hseq), _p(gsave), _p(hall), _p(hn), _p(sync), GRU_MAX_WGS, _stream())
+        out = hall[1:, :B].transpose(0, 1)          # [B,L,H] view of the fp32 states: no second copy is written
         if save:
             ctx.save_for_backward(x_bf, hseq, gsave, hall, w_ih, w_hh)
         if len(LAST_GRU_SYNC) < 64:
