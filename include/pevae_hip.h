@@ -34,6 +34,15 @@ int pv_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                     int bias_per_row, float* C, int ldc, void* Cb, int ldcb, int accumulate, void* stream);
 
+/* Split-K form for weight-gradient GEMMs with few output tiles and a long K (dW_ih / dW_hh of the GRU: K = all
+ * L*B tokens): `splits` slices of K are computed by separate workgroups into fp32 slabs of `workspace`
+ * (pv_gemm_splitk_ws_bytes) and summed in slice order by a second kernel (bitwise reproducible, no atomics);
+ * C (+)= the sum.  pv_gemm_splitk_plan picks `splits` so that tiles * splits ~ target_wgs. */
+int pv_gemm_splitk_plan(int M, int N, int K, int target_wgs, int* splits);   /* host out-param */
+size_t pv_gemm_splitk_ws_bytes(int M, int N, int splits);
+int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits,
+                           void* workspace, float* C, int ldc, int accumulate, void* stream);
+
 /* ---- fused vocabulary projection + log-softmax + NLL -----------------------------------------------------
  * Forward: logits = (h W^T + bias) * inv_temp are produced tile-wise by the MFMA GEMM and reduced on the fly
  * to per-token lse[t] and nll[t] = lse - logit[target] (0 where target == ignore_index); the [T,V] log-prob

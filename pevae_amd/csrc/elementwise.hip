@@ -255,13 +255,30 @@ __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ P, int R, int ld, 
   out[c] = s;
 }
 
-__global__ void colsum_f32_kernel(const float* __restrict__ X, int R, long ld, int n, float* __restrict__ out,
-                                  int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  float s = accumulate ? out[c] : 0.f;
-  for (int r = 0; r < R; ++r) s += X[(size_t)r * ld + c];
-  out[c] = s;
+// out[c] (+)= sum_r X[r][c].  Block = 64 columns x 4 row phases; each thread keeps 8 independent loads in flight
+// over its rows (r = y, y+4, ...), then the 4 phases are added in a fixed order: bitwise reproducible.
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ X, int R, long ld, int n,
+                                                          float* __restrict__ out, int accumulate) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, y = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < n) {
+    int r = y;
+    for (; r + 28 < R; r += 32) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = X[(size_t)(r + 4 * k) * ld + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; r < R; r += 4) s += X[(size_t)r * ld + c];
+  }
+  part[y][cl] = s;
+  __syncthreads();
+  if (y == 0 && c < n) {
+    const float t = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // dense-input NLL pick: out[t] = -logp[t][target[t]] (0 where target == ignore)   (criterions.py:57-63)
@@ -415,7 +432,7 @@ int pv_pick_nll_bwd(const float* dout, const int64_t* target, int64_t ignore, in
 
 int pv_colsum_f32(const float* X, int R, long ld, int n, float* out, int accumulate, void* stream) {
   PV_REQUIRE(X && out && R > 0 && n > 0 && ld >= n, "pv_colsum_f32: bad argument");
-  hipLaunchKernelGGL(colsum_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, X, R, ld, n, out,
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, X, R, ld, n, out,
                      accumulate);
   PV_LAUNCH_CHECK("colsum_f32_kernel");
   return PV_OK;

@@ -30,6 +30,7 @@ struct GemmArgs {
   const bf16_t* A;
   const bf16_t* B;
   int M, N, K, lda, ldb;
+  int kt_per_split;   // split-K: blockIdx.y handles k-tiles [y*kt_per_split, (y+1)*kt_per_split); 0 = all of K
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -99,9 +100,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi ep
     swz[i] = (c16 >> 1) & 7;   // (row>>1)&7 : rows are 16-aligned + c16, so only c16 matters
   }
 
-  const int nk = g.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
+  const int nk_all = g.K / BK;
+  const int kt0 = g.kt_per_split ? blockIdx.y * g.kt_per_split : 0;
+  const int nk = g.kt_per_split ? min(nk_all, kt0 + g.kt_per_split) : nk_all;
+  stage(kt0 & 1, kt0);
+  for (int kt = kt0; kt < nk; ++kt) {
     const int s = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -136,8 +139,10 @@ struct EpiStore {
   bf16_t* Cb;
   const float* bias;
   int M, N, ldc, ldcb, accumulate, bias_per_row;
+  long split_stride;   // split-K: slab blockIdx.y of the fp32 output starts at C + y * split_stride
   __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
     const int c16 = lane & 15, q4 = lane >> 4;
+    float* C = this->C ? this->C + (long)blockIdx.y * split_stride : nullptr;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int col = col0 + ni * 16 + c16;
@@ -375,16 +380,6 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float2* __restr
   }
 }
 
-// dbias[v] = sum over row-slabs of dbias_part[slab][v]   (fixed order: bitwise reproducible)
-__global__ void colsum_kernel(const float* __restrict__ part, int nrows, int ld, int n,
-                              float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  float s = 0.f;
-  for (int r = 0; r < nrows; ++r) s += part[(size_t)r * ld + c];
-  out[c] = s;
-}
-
 int check_gemm(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const char* who) {
   PV_REQUIRE(A && B, "%s: null operand", who);
   PV_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty problem M=%d N=%d K=%d", who, M, N, K);
@@ -395,8 +390,19 @@ int check_gemm(const void* A, const void* B, int M, int N, int K, int lda, int l
   return PV_OK;
 }
 
+// C[m][n] (+)= sum over splits of ws[s][m][n]   (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long slab, int M,
+                                                             int N, float* __restrict__ C, int ldc, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * N) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += ws[k * slab + i];
+  float* dst = C + (i / N) * ldc + i % N;
+  *dst = accumulate ? *dst + s : s;
+}
+
 template <class Epi>
-int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who) {
+int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who, int splits = 1) {
   static bool attr_done = false;
   if (!attr_done) {
     PV_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -404,7 +410,7 @@ int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who) {
     attr_done = true;
   }
   const int nwg = cdiv(g.M, BM) * cdiv(g.N, BN);
-  hipLaunchKernelGGL(gemm_nt_kernel<Epi>, dim3(nwg), dim3(NTHREADS), SMEM_BYTES, st, g, epi);
+  hipLaunchKernelGGL(gemm_nt_kernel<Epi>, dim3(nwg, splits), dim3(NTHREADS), SMEM_BYTES, st, g, epi);
   PV_LAUNCH_CHECK(who);
   return PV_OK;
 }
@@ -420,10 +426,42 @@ int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N
   if (rc) return rc;
   PV_REQUIRE(C || Cb, "pv_gemm_bf16_nt: no output given");
   PV_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N), "pv_gemm_bf16_nt: output leading dimension < N");
-  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb};
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, 0};
   PV_REQUIRE(!accumulate || C, "pv_gemm_bf16_nt: accumulate needs the fp32 output");
-  EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb, accumulate, bias_per_row};
+  EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb, accumulate, bias_per_row, 0};
   return launch(g, e, (hipStream_t)stream, "pv_gemm_bf16_nt");
+}
+
+int pv_gemm_splitk_plan(int M, int N, int K, int target_wgs, int* splits) {
+  PV_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && splits, "pv_gemm_splitk_plan: bad argument");
+  const int tiles = cdiv(M, BM) * cdiv(N, BN), nk = K / BK;
+  int s = target_wgs / tiles;
+  if (s < 1) s = 1;
+  if (s > nk / 4) s = nk / 4 > 0 ? nk / 4 : 1;         // keep >= 4 k-tiles per split
+  const int per = cdiv(nk, s);
+  *splits = cdiv(nk, per);                             // no empty split
+  return PV_OK;
+}
+
+size_t pv_gemm_splitk_ws_bytes(int M, int N, int splits) { return (size_t)splits * M * N * sizeof(float); }
+
+int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits,
+                           void* workspace, float* C, int ldc, int accumulate, void* stream) {
+  int rc = check_gemm(A, B, M, N, K, lda, ldb, "pv_gemm_bf16_nt_splitk");
+  if (rc) return rc;
+  PV_REQUIRE(C && workspace && ldc >= N && splits >= 1 && splits <= K / BK, "pv_gemm_bf16_nt_splitk: bad argument");
+  const int per = cdiv(K / BK, splits);
+  PV_REQUIRE(cdiv(K / BK, per) == splits, "pv_gemm_bf16_nt_splitk: %d splits leave an empty split (use pv_gemm_splitk_plan)", splits);
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, per};
+  EpiStore e{(float*)workspace, nullptr, nullptr, M, N, N, 0, 0, 0, (long)M * N};
+  hipStream_t st = (hipStream_t)stream;
+  rc = launch(g, e, st, "pv_gemm_bf16_nt_splitk", splits);
+  if (rc) return rc;
+  const long n = (long)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                     splits, n, M, N, C, ldc, accumulate);
+  PV_LAUNCH_CHECK("splitk_reduce_kernel");
+  return PV_OK;
 }
 
 size_t pv_vocab_nll_fwd_ws_bytes(int T, int V) {
@@ -442,7 +480,7 @@ int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float
   hipStream_t st = (hipStream_t)stream;
   // rows whose target is out of range (e.g. ignore_index < 0) never get a target logit written
   PV_HIP(hipMemsetAsync(tgt_logit, 0, (size_t)Tpad * sizeof(float), st));
-  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw};
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 0};
   EpiSoftmax e{bias, target, part, tgt_logit, T, V, Tpad, inv_temp};
   rc = launch(g, e, st, "pv_vocab_nll_fwd");
   if (rc) return rc;
@@ -464,13 +502,12 @@ int pv_vocab_nll_bwd_prob(const void* h, int ldh, const void* W, int ldw, const 
              "pv_vocab_nll_bwd_prob: need ldp >= %d and ldpt >= %d (multiples of 8)", Vpad, Tpad);
   PV_REQUIRE(((uintptr_t)P & 15) == 0 && ((uintptr_t)PT & 15) == 0, "pv_vocab_nll_bwd_prob: P/PT must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw};
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 0};
   EpiProb e{bias, target, lse, gscale, (bf16_t*)P, (bf16_t*)PT, dbias_part, T, V, Tpad, Vpad, ldp, ldpt, inv_temp};
   rc = launch(g, e, st, "pv_vocab_nll_bwd_prob");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(V, 256)), dim3(256), 0, st, dbias_part, Tpad / 64, ldp, V, dbias);
-  PV_LAUNCH_CHECK("colsum_kernel");
-  return PV_OK;
+  // dbias[v] = sum over row-slabs of dbias_part[slab][v]   (fixed order: bitwise reproducible)
+  return pv_colsum_f32(dbias_part, Tpad / 64, ldp, V, dbias, 0, stream);
 }
 
 int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const float* bias,
@@ -478,7 +515,7 @@ int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const
   int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_logprob_dense");
   if (rc) return rc;
   PV_REQUIRE(bias && lse && out, "pv_vocab_logprob_dense: null argument");
-  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw};
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 0};
   EpiLogProb e{bias, lse, out, T, V, inv_temp};
   return launch(g, e, (hipStream_t)stream, "pv_vocab_logprob_dense");
 }

@@ -120,6 +120,28 @@ def gemm_nt(A, lda, Bm, ldb, M, N, K, bias=None, out=None, out_bf16=None, accumu
     return out if out is not None else out_bf16
 
 
+def gemm_nt_wgrad(A, lda, Bm, ldb, M, N, K, sink=None):
+    """Weight-gradient GEMM C[M,N] = A[M,K] B[N,K]^T whose K is the token count: split-K over ~2 workgroups per CU when
+    the plain tiling would leave most of the chip idle.  Accumulates into `sink` when given, else returns C."""
+    _need_cuda(A, Bm)
+    cus = device_info()["cu_count"] if not _DEV_CU else _DEV_CU[0]
+    if not _DEV_CU:
+        _DEV_CU.append(cus)
+    splits = C.c_int(1)
+    _lib.call("pv_gemm_splitk_plan", M, N, K, 2 * cus, C.byref(splits))
+    out = sink if sink is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if splits.value <= 1:
+        gemm_nt(A, lda, Bm, ldb, M, N, K, out=out, accumulate=sink is not None)
+    else:
+        ws = workspace("gemm_splitk", _lib.load().pv_gemm_splitk_ws_bytes(M, N, splits.value), torch.uint8, A.device)
+        _lib.call("pv_gemm_bf16_nt_splitk", _p(A), lda, _p(Bm), ldb, M, N, K, splits.value, _p(ws), _p(out),
+                  out.stride(0), 1 if sink is not None else 0, _stream())
+    return None if sink is not None else out
+
+
+_DEV_CU = []
+
+
 def grad_sink(param, shape=None):
     """A parameter that already owns a dense fp32 `.grad` (FlatAdam's views into the flat gradient buffer, or
     any earlier backward) lets the backward kernels ACCUMULATE into that buffer in place -- the autograd node
@@ -352,14 +374,10 @@ class GRULayer(torch.autograd.Function):
         dgiT = transpose_to_bf16(dgi, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
         xT = transpose_to_bf16(x_bf, Tt, E, Ep, Tp, out=workspace("gru_xT", E * Tp, BF16, dev).view(E, Tp))
         p_ih, p_hh = ctx.params
-        sink = grad_sink(p_ih, (3 * H, E))
-        dw_ih = gemm_nt(dgiT, Tp, xT, Tp, 3 * H, E, Tp, out=sink, accumulate=sink is not None)
-        dw_ih = None if sink is not None else dw_ih
+        dw_ih = gemm_nt_wgrad(dgiT, Tp, xT, Tp, 3 * H, E, Tp, grad_sink(p_ih, (3 * H, E)))
         dghT = transpose_to_bf16(dgh, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
         hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
-        sink = grad_sink(p_hh, (3 * H, H))
-        dw_hh = gemm_nt(dghT, Tp, hpT, Tp, 3 * H, H, Tp, out=sink, accumulate=sink is not None)
-        dw_hh = None if sink is not None else dw_hh
+        dw_hh = gemm_nt_wgrad(dghT, Tp, hpT, Tp, 3 * H, H, Tp, grad_sink(p_hh, (3 * H, H)))
         return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None
 
 

@@ -282,3 +282,28 @@ def test_guard_skips_nonfinite_and_spikes(dev):
     assert torch.equal(p.detach(), after1) and fa.state_dict_host()["skipped_total"] == 2
     fa.zero_grad(); p.grad.fill_(0.1); fa.step()
     assert not torch.equal(p.detach(), after1)
+
+
+def test_gemm_splitk_exact_and_colsum(dev):
+    """Split-K weight-gradient GEMM: exact on integer data (any split count), accumulate form, and the column-sum kernel."""
+    import ctypes as C
+    from pevae_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    for (M, N, K) in [(96, 40, 1024), (1536, 100, 3200), (130, 512, 640)]:
+        A = torch.randint(-2, 3, (M, K), generator=g).float()
+        Bm = torch.randint(-2, 3, (N, K), generator=g).float()
+        want = A @ Bm.t()
+        Ab, Bb = A.to(dev).to(torch.bfloat16), Bm.to(dev).to(torch.bfloat16)
+        got = ops.gemm_nt_wgrad(Ab, K, Bb, K, M, N, K)
+        assert torch.equal(got.cpu(), want)
+        sink = torch.nn.Parameter(torch.zeros(M, N, device=dev))
+        sink.grad = torch.ones(M, N, device=dev)
+        assert ops.gemm_nt_wgrad(Ab, K, Bb, K, M, N, K, ops.grad_sink(sink, (M, N))) is None
+        assert torch.equal(sink.grad.cpu(), want + 1)
+        s = C.c_int(0)
+        _lib.call("pv_gemm_splitk_plan", M, N, K, 512, C.byref(s))
+        assert 1 <= s.value <= K // 64
+    x = torch.randn(517, 300, generator=g)
+    out = torch.empty(300, device=dev)
+    _lib.call("pv_colsum_f32", x.to(dev).data_ptr(), 517, 300, 300, out.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    np.testing.assert_allclose(out.cpu().numpy(), x.sum(0).numpy(), rtol=1e-5, atol=1e-4)
