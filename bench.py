@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--dropout", type=float, default=0.3)
+    ap.add_argument("--latent", default="gauss", choices=["gauss", "dls"], help="latent stack of the composed step")
+    ap.add_argument("--attention", type=int, default=0, help="decoder attention over encoder states (configs[2])")
     ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for per-kernel times")
     return ap.parse_args()
 
@@ -80,7 +82,8 @@ def main():
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
 
-    cfg = default_config(dropout=args.dropout, batch_size=args.batch)
+    cfg = default_config(dropout=args.dropout, batch_size=args.batch, latent_stack=args.latent,
+                         use_attention=bool(args.attention))
     torch.manual_seed(0)                                    # identical initial weights on every rank
     model = DLSVAE(cfg).to(dev)
     model.train()
@@ -185,8 +188,8 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "DLS_VAE Yelp-shape bs=256/GPU bf16 (configs[1]): embed=100 dec_cell=512 L=50 "
-                                   "V=20004 NU=30000 NI=20000 Z=64, dropout=%.1f, Adam lr=1e-4 clip=5, flat Gaussian "
-                                   "latent stack" % args.dropout,
+                                   "V=20004 NU=30000 NI=20000 Z=64, dropout=%.1f, Adam lr=1e-4 clip=5, latent stack '%s'%s"
+                                   % (args.dropout, args.latent, ", decoder attention" if args.attention else ""),
                        "global_batch": args.batch * world, "seq_len": cfg.max_seq_len, "params": n_params,
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph)},
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kern_ms, "final_vae_nll": round(final_nll, 4),

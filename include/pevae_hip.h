@@ -142,8 +142,30 @@ int pv_cat_rows_bwd(const float* log_q, const float* log_p, long log_p_numel, co
 /* ---- small exact-fp32 strided GEMM (Hidden2Gaussian nn_lib.py:198-199, LinearConnector nn_lib.py:143, Block
  * dialog_models.py:258-263, attention bmm decoders.py:85-107) ------------------------------------------------- */
 int pv_linear_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias,
-                  float* C, long ldc, int M, int N, int K, float alpha, int accumulate, int batch, long bsa,
-                  long bsb, long bsc, void* stream);
+                  float* C, long ldc, int M, int N, int K, float alpha, const float* alpha_dev, int accumulate,
+                  int batch, long bsa, long bsb, long bsc, void* stream);   /* alpha_dev: optional device scalar factor */
+
+/* ---- DLS latent pyramid pieces (dialog_models.py:253-271 Block, :1835-1870 DlsRec/DlsPri, :3161-3352 DLS_Auto) ------
+ * LayerNorm over a residual sum (Block, :269: layer_norm(x + xhat)); y may be NULL. */
+int pv_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta, int rows, int D, float eps,
+                     float* out, float* mean, float* rstd, void* stream);
+int pv_layernorm_bwd(const float* x, const float* y, const float* gamma, const float* dout, const float* mean,
+                     const float* rstd, int rows, int D, float* ds, float* dgamma, float* dbeta, int accumulate_params,
+                     void* stream);
+/* torch.nn.utils.spectral_norm of the Block linears (:258-263): one power iteration (do_iter != 0: u, v updated in
+ * place) and inv_sigma[0] = 1 / (u . W v).  Backward correction of the weight gradient:
+ * dW -= <dy, y - bias> * inv_sigma * u v^T  (dW must already hold (dy^T x) * inv_sigma); scratch1: one float. */
+int pv_spectral_norm(const float* W, float* u, float* v, int n_out, int n_in, float eps, int do_iter, float* inv_sigma,
+                     void* stream);
+int pv_spectral_norm_bwd(const float* dy, const float* y, const float* bias, long M, int n_out, int n_in, const float* u,
+                         const float* v, const float* inv_sigma, float* scratch1, float* dW, void* stream);
+/* DLS_Auto.cons_loss (:3266-3272): row L2 normalisation and the symmetric InfoNCE over a [B][B] score matrix with
+ * the diagonal as targets: loss = (CE(log_softmax rows) + CE(log_softmax columns)) / 2. */
+int pv_l2norm_rows_fwd(const float* x, int rows, int D, float* a, float* nrm, void* stream);
+int pv_l2norm_rows_bwd(const float* a, const float* nrm, const float* da, int rows, int D, float* dx, void* stream);
+int pv_infonce_fwd(const float* S, int B, float* lse_r, float* lse_c, float* loss, void* stream);
+int pv_infonce_bwd(const float* S, const float* lse_r, const float* lse_c, const float* gout, int B, float* dS,
+                   void* stream);
 
 /* ---- decoder attention (decoders.py:89-118): fused additive scores, row softmax, tanh / GELU ---------------------
  * score[b,i,j] = qw . tanh(k[b,j,:] + q[b,i,:]) + qb without the [B,Lo,Li,D] intermediate of decoders.py:92-94.

@@ -713,3 +713,61 @@ class DlsPyramid(nn.Module):
             acts.append(output)
             output = layer(output)
         return output, acts
+
+
+class DLSAuto(nn.Module):
+    """DLS_Auto.forward, dialog_models.py:3274-3352 (train branch :3285-3311, restarted / ost branch :3312-3351),
+    restated on the oracle Block.  NOT reproduced: the density-estimate regulariser (:3232-3236, :3308, :3311), which
+    raises in the reference itself (torch.log of the Python int n_batch = -1); `batch_arrange` is arange(actual
+    batch) instead of arange(config.batch_size) (:3186).  The uniform draws of dis_reparameterization (:3206-3207) are
+    passed in as `noise` (one [B, d] tensor per level).  Parity of this composition is unpinned by the reference (its
+    constructor needs a CUDA device, :3198); its parts -- Block, gaussian_analytical_kl, cons_loss -- are pinned by
+    tests/golden/block.npz and dls_helpers.npz."""
+
+    def __init__(self, input_dim, output_dim, config):
+        super().__init__()
+        self.config = config
+        self.layers, self.dis_layers, self.dis_layers2 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        cnt = 0
+        while input_dim <= output_dim:
+            self.layers.append(Block(input_dim, input_dim * 2, input_dim * 2))
+            k = 2 if cnt == 0 else 3
+            self.dis_layers.append(Block(input_dim * k, input_dim * 4, input_dim * 4))
+            self.dis_layers2.append(Block(input_dim * k, input_dim * 4, input_dim * 4))
+            input_dim *= 2
+            cnt += 1
+
+    def forward(self, output, rec_output, act1, act2, restarted=False, noise=None):
+        cfg = self.config
+        cip, ew, cw = getattr(cfg, "cip_weight", 1.0), cfg.expand_weight, cfg.converge_weight
+        arange = torch.arange(output.size(0))
+        rkl = cons_loss(output, rec_output, arange) * cip
+        last_sample = last_t = None
+        train_branch = not restarted and not getattr(cfg, "ost", False)
+        for i, (layer, dis, dis2) in enumerate(zip(self.layers, self.dis_layers, self.dis_layers2)):
+            a1, a2 = act1[-i - 1], act2[-i - 1]
+            if last_sample is None:
+                q_in, p_in = a1 + a2, a2
+            else:
+                q_in = torch.cat([a1 + a2, last_sample], -1)
+                p_in = torch.cat([a2, last_t if train_branch else last_sample], -1)
+            t_mean, t_lv = dis2(p_in).chunk(2, -1)
+            if train_branch or self.training:
+                mean, lv = dis(q_in).chunk(2, -1)
+            if train_branch:
+                eps = noise[i] if noise is not None else torch.rand_like(lv)
+                last_sample = reparameterization(mean, lv, eps) + a2
+                last_t = t_mean
+                rkl = rkl + ew * gaussian_analytical_kl(t_mean, mean.detach(), t_lv, lv.detach())
+                rkl = rkl + cw * gaussian_analytical_kl(t_mean.detach(), mean, t_lv.detach(), lv)
+                rkl = rkl + cons_loss(a1, a2, arange) * cip
+                output = layer(output) + last_sample
+            else:
+                if self.training:
+                    eps = noise[i] if noise is not None else torch.rand_like(t_lv)
+                    last_sample = reparameterization(t_mean, t_lv, eps) + a2
+                    rkl = rkl + ew * gaussian_analytical_kl(t_mean, mean.detach(), t_lv, lv.detach())
+                else:
+                    last_sample = t_mean + a2
+                output = torch.nan_to_num(layer(output) + last_sample)
+        return output, rkl

@@ -28,10 +28,17 @@ class RefDLSVAE(nn.Module):
                                       n_layers=c.num_layer, rnn_cell=c.rnn_cell, input_dropout_p=c.dropout,
                                       dropout_p=c.dropout, use_attention=c.use_attention, attn_mode=c.attn_type,
                                       attn_size=H, use_gpu=False, embedding=self.x_embedding)
-        self.rec_head = R.Hidden2Gaussian(H, Z)
+        self.latent_stack = getattr(c, "latent_stack", "gauss")
+        if self.latent_stack == "dls":                                                   # dialog_models.py:3401-3417
+            self.rec_encoder = R.DlsPyramid(H, H // 16, c)
+            self.pri_encoder = R.DlsPyramid(H, H // 16, c, wrap=True)
+            self.sup_decoder = R.DLSAuto(H // 32, H // 8, c)
+            self.dls_connector = nn.Sequential(R.Block(H // 4, H // 2, H // 2), R.Block(H // 2, H, H))
         self.prior_fc = nn.Linear(3 * self.emb_size, H)
-        self.pri_head = R.Hidden2Gaussian(H, Z)
-        self.x_init_connector = R.LinearConnector(Z, H, c.rnn_cell == "lstm")
+        if self.latent_stack == "gauss":
+            self.rec_head = R.Hidden2Gaussian(H, Z)
+            self.pri_head = R.Hidden2Gaussian(H, Z)
+            self.x_init_connector = R.LinearConnector(Z, H, c.rnn_cell == "lstm")
         if c.do_pred:
             self.dnn = nn.Sequential(nn.Linear(2 * self.emb_size, H), nn.Linear(H, 1))
         self.nll_loss = R.NLLEntropy(PAD_ID, c)
@@ -58,17 +65,26 @@ class RefDLSVAE(nn.Module):
         rating = self.rating_embedding(feed["ratings"].ge(3).long())
         enc_outs, enc_last = self.x_encoder(self.x_embedding(feed["sentence_embeddings"]))
         h = enc_last.transpose(0, 1).contiguous().squeeze(1)
-        mu_q, lv_q = self.rec_head(h)
-        mu_p, lv_p = self.pri_head(torch.tanh(self.prior_fc(torch.cat([user, item, rating], -1))))
+        prior_h = torch.tanh(self.prior_fc(torch.cat([user, item, rating], -1)))
         B = h.size(0)
-        if self.training:
-            if eps is None:
-                eps = torch.randn(B, mu_q.size(1))
-            z = R.reparameterization(mu_q, lv_q, eps)
-            rkl = self.kl_loss(mu_q, lv_q, mu_p, lv_p)
+        if self.latent_stack == "dls":
+            z_pri, pri_state = self.pri_encoder(prior_h)
+            z_rec, rec_state = self.rec_encoder(h)
+            z, rkl = self.sup_decoder(z_pri, z_rec, rec_state, pri_state, getattr(self, "restarted", False), noise=eps)
+            if not self.training:
+                rkl = None
+            dec_init = self.dls_connector(z).unsqueeze(0)
         else:
-            z, rkl = mu_p, None
-        dec_init = self.x_init_connector(z)
+            mu_q, lv_q = self.rec_head(h)
+            mu_p, lv_p = self.pri_head(prior_h)
+            if self.training:
+                if eps is None:
+                    eps = torch.randn(B, mu_q.size(1))
+                z = R.reparameterization(mu_q, lv_q, eps)
+                rkl = self.kl_loss(mu_q, lv_q, mu_p, lv_p)
+            else:
+                z, rkl = mu_p, None
+            dec_init = self.x_init_connector(z)
         ctx = enc_outs if self.config.use_attention else None
         dec_outs, _, _ = self.x_decoder(B, feed["input_ids"], dec_init, mode=mode, gen_type=gen_type,
                                         beam_size=self.config.beam_size, attn_context=ctx)

@@ -1,0 +1,307 @@
+// Kernels for the DLS latent pyramid (models/dialog_models.py:253-271 Block, :1835-1870 DlsRec/DlsPri,
+// :3161-3352 DLS_Auto): LayerNorm over a residual sum, spectral-norm power iteration and its weight-gradient
+// correction, row L2 normalisation and the symmetric InfoNCE loss of DLS_Auto.cons_loss (:3266-3272).
+// All of these are tiny (batch x <=1536) and latency bound: one wave per row, fixed-order reductions.
+#include "common.h"
+#include "../../include/pevae_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 256 threads of a block (result valid in every thread); `red` = 4 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// out[r] = LayerNorm(x[r] + y[r]) * gamma + beta   (nn.LayerNorm, biased variance; dialog_models.py:269)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int rows, int D, float eps, float* __restrict__ out,
+                                                             float* __restrict__ mean, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + (size_t)r * D;
+  const float* yr = y ? y + (size_t)r * D : nullptr;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += xr[c] + (yr ? yr[c] : 0.f);
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float d = xr[c] + (yr ? yr[c] : 0.f) - mu;
+    q += d * d;
+  }
+  const float rs = rsqrtf(wave_sum(q) / D + eps);
+  for (int c = lane; c < D; c += 64)
+    out[(size_t)r * D + c] = (xr[c] + (yr ? yr[c] : 0.f) - mu) * rs * gamma[c] + beta[c];
+  if (lane == 0) {
+    mean[r] = mu;
+    rstd[r] = rs;
+  }
+}
+
+// ds[r] = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dout * gamma   (gradient w.r.t. the summed input)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ dout,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             int rows, int D, float* __restrict__ ds) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + (size_t)r * D;
+  const float* yr = y ? y + (size_t)r * D : nullptr;
+  const float mu = mean[r], rs = rstd[r];
+  float a = 0.f, b = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float xh = (xr[c] + (yr ? yr[c] : 0.f) - mu) * rs, g = dout[(size_t)r * D + c] * gamma[c];
+    a += g;
+    b += g * xh;
+  }
+  a = wave_sum(a) / D;
+  b = wave_sum(b) / D;
+  for (int c = lane; c < D; c += 64) {
+    const float xh = (xr[c] + (yr ? yr[c] : 0.f) - mu) * rs, g = dout[(size_t)r * D + c] * gamma[c];
+    ds[(size_t)r * D + c] = rs * (g - a - xh * b);
+  }
+}
+
+// dgamma[c] (+)= sum_r dout * xhat, dbeta[c] (+)= sum_r dout   (rows in order: reproducible)
+__global__ void layernorm_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                            const float* __restrict__ dout, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd, int rows, int D, int accumulate,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float g = 0.f, b = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    const float s = x[(size_t)r * D + c] + (y ? y[(size_t)r * D + c] : 0.f);
+    const float d = dout[(size_t)r * D + c];
+    g += d * (s - mean[r]) * rstd[r];
+    b += d;
+  }
+  dgamma[c] = accumulate ? dgamma[c] + g : g;
+  dbeta[c] = accumulate ? dbeta[c] + b : b;
+}
+
+// torch.nn.utils.spectral_norm (hook form, one power iteration per training forward, dialog_models.py:258-263):
+//   training: v = normalize(W^T u), u = normalize(W v) (buffers updated in place);  sigma = u . (W v)
+// One block per matrix; writes 1/sigma.  W [out][in] row-major.
+__global__ __launch_bounds__(256) void spectral_iter_kernel(const float* __restrict__ W, float* __restrict__ u,
+                                                             float* __restrict__ v, int n_out, int n_in, float eps,
+                                                             int do_iter, float* __restrict__ inv_sigma) {
+  extern __shared__ float sh[];           // u [n_out], v [n_in], wv [n_out], red [4]
+  float* su = sh;
+  float* sv = sh + n_out;
+  float* swv = sv + n_in;
+  float* red = swv + n_out;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < n_out; i += 256) su[i] = u[i];
+  for (int j = tid; j < n_in; j += 256) sv[j] = v[j];
+  __syncthreads();
+  if (do_iter) {
+    float nn = 0.f;
+    for (int j = tid; j < n_in; j += 256) {        // v = W^T u   (coalesced over j)
+      float s = 0.f;
+      for (int i = 0; i < n_out; ++i) s += W[(size_t)i * n_in + j] * su[i];
+      sv[j] = s;
+      nn += s * s;
+    }
+    nn = block_sum(nn, red);
+    const float inv = 1.f / fmaxf(sqrtf(nn), eps);
+    for (int j = tid; j < n_in; j += 256) sv[j] *= inv;
+    __syncthreads();
+  }
+  for (int i = w; i < n_out; i += 4) {             // wv = W v   (one wave per row)
+    float s = 0.f;
+    for (int j = lane; j < n_in; j += 64) s += W[(size_t)i * n_in + j] * sv[j];
+    s = wave_sum(s);
+    if (lane == 0) swv[i] = s;
+  }
+  __syncthreads();
+  if (do_iter) {
+    float nn = 0.f;
+    for (int i = tid; i < n_out; i += 256) nn += swv[i] * swv[i];
+    nn = block_sum(nn, red);
+    const float inv = 1.f / fmaxf(sqrtf(nn), eps);
+    for (int i = tid; i < n_out; i += 256) su[i] = swv[i] * inv;
+    __syncthreads();
+    for (int i = tid; i < n_out; i += 256) u[i] = su[i];
+    for (int j = tid; j < n_in; j += 256) v[j] = sv[j];
+  }
+  float d = 0.f;
+  for (int i = tid; i < n_out; i += 256) d += su[i] * swv[i];
+  d = block_sum(d, red);
+  if (tid == 0) inv_sigma[0] = 1.f / d;
+}
+
+// c = sum_{m,n} dy[m][n] * (y[m][n] - bias[n])  =  <dL/dW_eff, W_eff>   (one block, fixed order)
+__global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      const float* __restrict__ bias, long M, int N, float* __restrict__ c) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < M * N; i += 256) s += dy[i] * (y[i] - (bias ? bias[i % N] : 0.f));
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) c[0] = s;
+}
+
+// dW[i][j] -= c * inv_sigma * u[i] * v[j]
+__global__ void sn_rank1_kernel(float* __restrict__ dW, const float* __restrict__ u, const float* __restrict__ v,
+                                const float* __restrict__ c, const float* __restrict__ inv_sigma, int n_out, int n_in) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n_out * n_in) return;
+  dW[i] -= c[0] * inv_sigma[0] * u[i / n_in] * v[i % n_in];
+}
+
+// a[r] = x[r] / ||x[r]||  (dialog_models.py:3269-3270; no epsilon, like the reference)
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int rows, int D,
+                                                          float* __restrict__ a, float* __restrict__ nrm) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float q = 0.f;
+  for (int c = lane; c < D; c += 64) q += x[(size_t)r * D + c] * x[(size_t)r * D + c];
+  const float n = sqrtf(wave_sum(q));
+  for (int c = lane; c < D; c += 64) a[(size_t)r * D + c] = x[(size_t)r * D + c] / n;
+  if (lane == 0) nrm[r] = n;
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ a, const float* __restrict__ nrm,
+                                                          const float* __restrict__ da, int rows, int D,
+                                                          float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float d = 0.f;
+  for (int c = lane; c < D; c += 64) d += a[(size_t)r * D + c] * da[(size_t)r * D + c];
+  d = wave_sum(d);
+  for (int c = lane; c < D; c += 64) dx[(size_t)r * D + c] = (da[(size_t)r * D + c] - a[(size_t)r * D + c] * d) / nrm[r];
+}
+
+// which = 0: lse over row i of S;  which = 1: lse over column i of S.   S [B][B]
+__global__ __launch_bounds__(256) void infonce_lse_kernel(const float* __restrict__ S, int B, float* __restrict__ lse_r,
+                                                           float* __restrict__ lse_c) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6), which = blockIdx.y;
+  if (i >= B) return;
+  const long st = which ? B : 1;
+  const float* p = S + (which ? i : (long)i * B);
+  float m = -INFINITY;
+  for (int j = lane; j < B; j += 64) m = fmaxf(m, p[j * st]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int j = lane; j < B; j += 64) s += expf(p[j * st] - m);
+  s = wave_sum(s);
+  if (lane == 0) (which ? lse_c : lse_r)[i] = m + logf(s);
+}
+// loss = ( mean_i(lse_r[i] - S_ii) + mean_i(lse_c[i] - S_ii) ) / 2      (one block)
+__global__ __launch_bounds__(256) void infonce_loss_kernel(const float* __restrict__ S, const float* __restrict__ lse_r,
+                                                            const float* __restrict__ lse_c, int B, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += lse_r[i] + lse_c[i] - 2.f * S[(long)i * B + i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = s / (2.f * B);
+}
+// dS[i][j] = g/(2B) * (exp(S - lse_r[i]) + exp(S - lse_c[j]) - 2 [i == j])
+__global__ void infonce_bwd_kernel(const float* __restrict__ S, const float* __restrict__ lse_r,
+                                   const float* __restrict__ lse_c, const float* __restrict__ g, int B,
+                                   float* __restrict__ dS) {
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (long)B * B) return;
+  const int i = (int)(k / B), j = (int)(k % B);
+  const float s = S[k];
+  dS[k] = g[0] / (2.f * B) * (expf(s - lse_r[i]) + expf(s - lse_c[j]) - (i == j ? 2.f : 0.f));
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta, int rows, int D, float eps,
+                     float* out, float* mean, float* rstd, void* stream) {
+  PV_REQUIRE(x && gamma && beta && out && mean && rstd && rows > 0 && D > 0, "pv_layernorm_fwd: bad argument");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta,
+                     rows, D, eps, out, mean, rstd);
+  PV_LAUNCH_CHECK("layernorm_fwd_kernel");
+  return PV_OK;
+}
+
+int pv_layernorm_bwd(const float* x, const float* y, const float* gamma, const float* dout, const float* mean,
+                     const float* rstd, int rows, int D, float* ds, float* dgamma, float* dbeta, int accumulate_params,
+                     void* stream) {
+  PV_REQUIRE(x && gamma && dout && mean && rstd && ds && dgamma && dbeta && rows > 0 && D > 0, "pv_layernorm_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, y, gamma, dout, mean, rstd, rows, D, ds);
+  PV_LAUNCH_CHECK("layernorm_bwd_kernel");
+  hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(cdiv(D, 64)), dim3(64), 0, st, x, y, dout, mean, rstd, rows, D,
+                     accumulate_params, dgamma, dbeta);
+  PV_LAUNCH_CHECK("layernorm_bwd_params_kernel");
+  return PV_OK;
+}
+
+int pv_spectral_norm(const float* W, float* u, float* v, int n_out, int n_in, float eps, int do_iter, float* inv_sigma,
+                     void* stream) {
+  PV_REQUIRE(W && u && v && inv_sigma && n_out > 0 && n_in > 0, "pv_spectral_norm: bad argument");
+  const size_t smem = (size_t)(2 * n_out + n_in + 4) * sizeof(float);
+  PV_REQUIRE(smem <= 64 * 1024, "pv_spectral_norm: %d x %d exceeds the 64 KiB LDS staging of the power iteration", n_out, n_in);
+  hipLaunchKernelGGL(spectral_iter_kernel, dim3(1), dim3(256), smem, (hipStream_t)stream, W, u, v, n_out, n_in, eps,
+                     do_iter, inv_sigma);
+  PV_LAUNCH_CHECK("spectral_iter_kernel");
+  return PV_OK;
+}
+
+int pv_spectral_norm_bwd(const float* dy, const float* y, const float* bias, long M, int n_out, int n_in, const float* u,
+                         const float* v, const float* inv_sigma, float* scratch1, float* dW, void* stream) {
+  PV_REQUIRE(dy && y && u && v && inv_sigma && scratch1 && dW && M > 0, "pv_spectral_norm_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(256), 0, st, dy, y, bias, M, n_out, scratch1);
+  PV_LAUNCH_CHECK("sn_dot_kernel");
+  const long n = (long)n_out * n_in;
+  hipLaunchKernelGGL(sn_rank1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dW, u, v, scratch1, inv_sigma,
+                     n_out, n_in);
+  PV_LAUNCH_CHECK("sn_rank1_kernel");
+  return PV_OK;
+}
+
+int pv_l2norm_rows_fwd(const float* x, int rows, int D, float* a, float* nrm, void* stream) {
+  PV_REQUIRE(x && a && nrm && rows > 0 && D > 0, "pv_l2norm_rows_fwd: bad argument");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, D, a, nrm);
+  PV_LAUNCH_CHECK("l2norm_fwd_kernel");
+  return PV_OK;
+}
+
+int pv_l2norm_rows_bwd(const float* a, const float* nrm, const float* da, int rows, int D, float* dx, void* stream) {
+  PV_REQUIRE(a && nrm && da && dx && rows > 0 && D > 0, "pv_l2norm_rows_bwd: bad argument");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, a, nrm, da, rows, D, dx);
+  PV_LAUNCH_CHECK("l2norm_bwd_kernel");
+  return PV_OK;
+}
+
+int pv_infonce_fwd(const float* S, int B, float* lse_r, float* lse_c, float* loss, void* stream) {
+  PV_REQUIRE(S && lse_r && lse_c && loss && B > 0, "pv_infonce_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(infonce_lse_kernel, dim3(cdiv(B, 4), 2), dim3(256), 0, st, S, B, lse_r, lse_c);
+  PV_LAUNCH_CHECK("infonce_lse_kernel");
+  hipLaunchKernelGGL(infonce_loss_kernel, dim3(1), dim3(256), 0, st, S, lse_r, lse_c, B, loss);
+  PV_LAUNCH_CHECK("infonce_loss_kernel");
+  return PV_OK;
+}
+
+int pv_infonce_bwd(const float* S, const float* lse_r, const float* lse_c, const float* gout, int B, float* dS,
+                   void* stream) {
+  PV_REQUIRE(S && lse_r && lse_c && gout && dS && B > 0, "pv_infonce_bwd: bad argument");
+  const long n = (long)B * B;
+  hipLaunchKernelGGL(infonce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, lse_r,
+                     lse_c, gout, B, dS);
+  PV_LAUNCH_CHECK("infonce_bwd_kernel");
+  return PV_OK;
+}
+
+}  // extern "C"

@@ -30,6 +30,7 @@ struct LinArgs {
   long sam, sak, sbk, sbn, ldc;
   long bsa, bsb, bsc;   // batch strides (0 = shared)
   float alpha;
+  const float* alpha_dev;   // optional device scalar multiplied into alpha (1/sigma of a spectral-norm weight)
   int accumulate;
   int modeA, modeB;
 };
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
     }
     __syncthreads();
   }
+  const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int n = n0 + wn * 32 + u * 16 + i16;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 32 + t * 16 + kq * 4 + r;
         if (m >= g.M) continue;
-        float v = g.alpha * acc[t][u][r] + bv;
+        float v = alpha * acc[t][u][r] + bv;
         float* dst = C + (long)m * g.ldc + n;
         if (g.accumulate) v += *dst;
         *dst = v;
@@ -168,10 +170,10 @@ int pick_mode(const float* P, long sx, long sk, long bs, int batch) {
 extern "C" {
 
 int pv_linear_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias,
-                  float* C, long ldc, int M, int N, int K, float alpha, int accumulate, int batch, long bsa,
-                  long bsb, long bsc, void* stream) {
+                  float* C, long ldc, int M, int N, int K, float alpha, const float* alpha_dev, int accumulate,
+                  int batch, long bsa, long bsb, long bsc, void* stream) {
   PV_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && ldc >= N, "pv_linear_f32: bad argument");
-  LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, bsa, bsb, bsc, alpha, accumulate,
+  LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, bsa, bsb, bsc, alpha, alpha_dev, accumulate,
             pick_mode(A, sam, sak, bsa, batch), pick_mode(B, sbn, sbk, bsb, batch)};
   hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv(N, TN), cdiv(M, TM), batch), dim3(256), 0, (hipStream_t)stream, g);
   PV_LAUNCH_CHECK("linear_f32_kernel");

@@ -1,0 +1,137 @@
+"""The DLS latent stack of the reference on the HIP kernels: Block (dialog_models.py:253-271), DlsRec / DlsPri
+(:1835-1870) and DLS_Auto (:3161-3352), with the reference's parameter names (`c1.weight_orig`, `c1.weight_u`,
+`layers.0.0.c1.bias`, ...) so its checkpoints load.
+
+Deviations, all forced by the reference being un-runnable as written:
+  * DLS_Auto's density-estimate regulariser (:3232-3236, :3308, :3311) takes torch.log of a Python int
+    (`n_batch = -1`) and raises; it is left out (gir_weight term = 0).
+  * `gau_list` / `batch_arrange` need CUDA and a fixed batch size at construction (:3186, :3198); the InfoNCE targets
+    are arange(actual batch) here.
+  * uniform noise for `dis_reparameterization` (:3206-3207) can be passed in (`noise=[...]`) so that parity tests are
+    deterministic; by default it is drawn on the device.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class SNLinear(nn.Module):
+    """spectral_norm(nn.Linear(in, out)) with torch.nn.utils.spectral_norm's state_dict layout."""
+
+    def __init__(self, in_f, out_f, eps=1e-12):
+        super().__init__()
+        lin = nn.Linear(in_f, out_f)
+        self.weight_orig = nn.Parameter(lin.weight.data.clone())
+        self.bias = nn.Parameter(lin.bias.data.clone())
+        self.eps = eps
+        self.register_buffer("weight_u", nn.functional.normalize(torch.randn(out_f), dim=0, eps=eps))
+        self.register_buffer("weight_v", nn.functional.normalize(torch.randn(in_f), dim=0, eps=eps))
+
+    def forward(self, x):
+        return ops.sn_linear(x, self.weight_orig, self.bias, self.weight_u, self.weight_v, self.training, self.eps)
+
+
+class Block(nn.Module):
+    def __init__(self, input_dim, output_dim, mid_dim=None):
+        super().__init__()
+        mid = input_dim // 2 if mid_dim is None else mid_dim
+        self.c1 = SNLinear(input_dim, input_dim)
+        self.c2 = SNLinear(input_dim, mid)
+        self.c3 = SNLinear(mid, mid)
+        self.c4 = SNLinear(mid, input_dim)
+        self.layer_norm = nn.LayerNorm(input_dim)
+        self.translate = SNLinear(input_dim, output_dim)
+
+    def forward(self, x):
+        y = self.c1(ops.gelu(x))
+        y = self.c2(ops.gelu(y))
+        y = self.c3(ops.gelu(y))
+        y = self.c4(ops.gelu(y))
+        out = ops.add_layer_norm(x, y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return self.translate(out)
+
+
+class _Pyramid(nn.Module):
+    def __init__(self, input_dim, output_dim, wrap):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        d = input_dim
+        while d >= output_dim:
+            blk = Block(d, d // 2, d // 2)
+            self.layers.append(nn.Sequential(blk) if wrap else blk)
+            d //= 2
+
+    def forward(self, output):
+        if output.dim() == 3:
+            output = output[:, 0]            # the reference takes the [CLS] row (:1846, :1864)
+        acts = []
+        for layer in self.layers:
+            acts.append(output)
+            output = layer(output)
+        return output, acts
+
+
+class DlsRec(_Pyramid):
+    def __init__(self, input_dim, output_dim, config=None):
+        super().__init__(input_dim, output_dim, wrap=False)
+
+
+class DlsPri(_Pyramid):
+    def __init__(self, input_dim, output_dim, config=None):
+        super().__init__(input_dim, output_dim, wrap=True)
+
+
+class DLSAuto(nn.Module):
+    """DLS_Auto.forward(output, rec_output, act1, act2, restarted) -> (z, rkl)  (dialog_models.py:3274-3352)."""
+
+    def __init__(self, input_dim, output_dim, config):
+        super().__init__()
+        self.config = config
+        self.layers, self.dis_layers, self.dis_layers2 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        cnt = 0
+        while input_dim <= output_dim:
+            self.layers.append(Block(input_dim, input_dim * 2, input_dim * 2))
+            k = 2 if cnt == 0 else 3
+            self.dis_layers.append(Block(input_dim * k, input_dim * 4, input_dim * 4))
+            self.dis_layers2.append(Block(input_dim * k, input_dim * 4, input_dim * 4))
+            input_dim *= 2
+            cnt += 1
+
+    def forward(self, output, rec_output, act1, act2, restarted=False, noise=None):
+        cfg = self.config
+        cip, ew, cw = getattr(cfg, "cip_weight", 1.0), cfg.expand_weight, cfg.converge_weight
+        rkl = ops.cons_loss(output, rec_output) * cip
+        last_sample = last_t = None
+        for i, (layer, dis, dis2) in enumerate(zip(self.layers, self.dis_layers, self.dis_layers2)):
+            a1, a2 = act1[-i - 1], act2[-i - 1]
+            train_branch = not restarted and not getattr(cfg, "ost", False)
+            if last_sample is None:
+                q_in, p_in = a1 + a2, a2
+            else:
+                q_in = torch.cat([a1 + a2, last_sample], -1)
+                p_in = torch.cat([a2, last_t if train_branch else last_sample], -1)
+            need_q = train_branch or self.training
+            t_mean, t_lv = dis2(p_in).chunk(2, -1)
+            if need_q:
+                mean, lv = dis(q_in).chunk(2, -1)
+            if train_branch:
+                eps = noise[i] if noise is not None else torch.rand_like(lv)
+                z, _ = ops.reparam_kl(mean, lv, None, None, eps, mode=1, want_kl=False)         # :3292 / :3299
+                last_sample = z + a2
+                last_t = t_mean
+                _, k1 = ops.reparam_kl(t_mean, t_lv, mean.detach(), lv.detach(), None, mode=1, want_z=False)
+                _, k2 = ops.reparam_kl(t_mean.detach(), t_lv.detach(), mean, lv, None, mode=1, want_z=False)
+                rkl = rkl + ew * ops.mean(k1) + cw * ops.mean(k2) + ops.cons_loss(a1, a2) * cip     # :3305-3307
+                output = layer(output) + last_sample                                               # :3310
+            else:
+                if self.training:
+                    eps = noise[i] if noise is not None else torch.rand_like(t_lv)
+                    z, _ = ops.reparam_kl(t_mean, t_lv, None, None, eps, mode=1, want_kl=False)    # :3346
+                    last_sample = z + a2
+                    _, k1 = ops.reparam_kl(t_mean, t_lv, mean.detach(), lv.detach(), None, mode=1, want_z=False)
+                    rkl = rkl + ew * ops.mean(k1)                                                  # :3347
+                else:
+                    last_sample = t_mean + a2                                                      # :3350
+                output = torch.nan_to_num(layer(output) + last_sample)                             # :3351
+        return output, rkl

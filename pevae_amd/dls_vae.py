@@ -9,14 +9,18 @@ dialog_models.py:3356-3437), so this is the build's documented
   * loss / Pack contract of DLS_VAE (dialog_models.py:3451-3465, :3569): Pack(vae_zkl, vae_nll, vae_PPL,
     vae_rnll, vae_rkl); valid_loss = vae_nll + vae_rkl in training, vae_nll in eval.
 Latent stack 'gauss' (flat): q(z|x) = Hidden2Gaussian(h_enc), p(z|u,i,r) = Hidden2Gaussian(tanh(W [u;i;r])),
-KL = NormKLLoss(q, p).  oracle/ref_step.py holds the same composition on the CPU oracle modules.
+KL = NormKLLoss(q, p).  Latent stack 'dls' (config.latent_stack = "dls"): the reference's DLS pyramid, wired as
+DLS_VAE.__init__ / forward do (dialog_models.py:3401-3417, :3529-3538): DlsRec / DlsPri over the response / condition
+states (H -> H/16, activations kept), DLS_Auto latent fusion over the three deepest levels -> z [B, H/4] and rkl, then
+x_init_connector = Block(H/4, H/2) -> Block(H/2, H) into the decoder state; rkl_weight fixed at 1 (the reference's
+adaptive rkl_weight, :3564-3567, uses attributes that are never defined).  oracle/ref_step.py holds the same composition on the CPU oracle modules.
 """
 from argparse import Namespace
 
 import torch
 import torch.nn as nn
 
-from . import criterions, nn_lib, ops
+from . import criterions, dls_latent as L, nn_lib, ops
 from .enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
 from .enc2dec.encoders import EncoderRNN
 from .utils import Pack
@@ -28,7 +32,8 @@ def default_config(**kw):
     cfg = Namespace(vocab_size=20004, embed_size=100, dec_cell_size=512, max_seq_len=50, n_user=30000,
                     n_item=20000, latent_size=64, dropout=0.3, rnn_cell="gru", num_layer=1, use_attention=False,
                     attn_type="cat", do_pred=False, beam_size=10, batch_size=256, init_lr=1e-4, grad_clip=5.0,
-                    warmup_steps=0, use_gpu=True)
+                    warmup_steps=0, use_gpu=True, latent_stack="gauss", expand_weight=0.5, converge_weight=0.1,
+                    cip_weight=1.0, ost=False)
     for k, v in kw.items():
         setattr(cfg, k, v)
     return cfg
@@ -49,10 +54,17 @@ class DLSVAE(nn.Module):
                                     n_layers=c.num_layer, rnn_cell=c.rnn_cell, input_dropout_p=c.dropout,
                                     dropout_p=c.dropout, use_attention=c.use_attention, attn_mode=c.attn_type,
                                     attn_size=H, use_gpu=c.use_gpu, embedding=self.x_embedding)               # :560-570
-        self.rec_head = nn_lib.Hidden2Gaussian(H, Z)
+        self.latent_stack = getattr(c, "latent_stack", "gauss")
+        if self.latent_stack == "dls":                                                   # dialog_models.py:3401-3417
+            self.rec_encoder = L.DlsRec(H, H // 16, c)
+            self.pri_encoder = L.DlsPri(H, H // 16, c)
+            self.sup_decoder = L.DLSAuto(H // 32, H // 8, c)
+            self.dls_connector = nn.Sequential(L.Block(H // 4, H // 2, H // 2), L.Block(H // 2, H, H))
         self.prior_fc = nn.Linear(3 * self.emb_size, H)
-        self.pri_head = nn_lib.Hidden2Gaussian(H, Z)
-        self.x_init_connector = nn_lib.LinearConnector(Z, H, c.rnn_cell == "lstm")      # :626
+        if self.latent_stack == "gauss":
+            self.rec_head = nn_lib.Hidden2Gaussian(H, Z)
+            self.pri_head = nn_lib.Hidden2Gaussian(H, Z)
+            self.x_init_connector = nn_lib.LinearConnector(Z, H, c.rnn_cell == "lstm")  # :626
         if c.do_pred:                                                                    # `self.dnn`, used at :815, never
             self.dnn = nn.Sequential(nn.Linear(2 * self.emb_size, H), nn.Linear(H, 1))  # defined by the reference
         self.nll_loss = criterions.NLLEntropy(PAD_ID, c)                                 # :634
@@ -83,18 +95,27 @@ class DLSVAE(nn.Module):
         words = ops.embedding(self.x_embedding.weight, data_feed["sentence_embeddings"], PAD_ID)
         enc_outs, enc_last = self.x_encoder(words)                                        # :765
         h = enc_last.transpose(0, 1).contiguous().squeeze(1)                              # :766
-        mu_q, lv_q = self.rec_head(h)
         prior_h = ops.tanh(ops.linear(torch.cat([user, item, rating], -1), self.prior_fc.weight, self.prior_fc.bias))
-        mu_p, lv_p = self.pri_head(prior_h)
         B = h.size(0)
-        if self.training:
-            if eps is None:
-                eps = torch.randn(B, mu_q.size(1), device=h.device)                       # :197
-            z, kl_row = ops.reparam_kl(mu_q, lv_q, mu_p, lv_p, eps, mode=0)               # :191-203 + criterions.py:145-155
-            rkl = ops.mean(kl_row)
+        if self.latent_stack == "dls":
+            z_pri, pri_state = self.pri_encoder(prior_h)                                   # :3529
+            z_rec, rec_state = self.rec_encoder(h)                                         # :3530
+            z, rkl = self.sup_decoder(z_pri, z_rec, rec_state, pri_state,
+                                      getattr(self, "restarted", False), noise=eps)        # :3535
+            if not self.training:
+                rkl = None                                                                 # :3571
+            dec_init = self.dls_connector(z).unsqueeze(0)                                  # :3473
         else:
-            z, rkl = mu_p, None                                                            # eval: condition on the prior mean
-        dec_init = self.x_init_connector(z)                                                # :711
+            mu_q, lv_q = self.rec_head(h)
+            mu_p, lv_p = self.pri_head(prior_h)
+            if self.training:
+                if eps is None:
+                    eps = torch.randn(B, mu_q.size(1), device=h.device)                   # :197
+                z, kl_row = ops.reparam_kl(mu_q, lv_q, mu_p, lv_p, eps, mode=0)           # :191-203 + criterions.py:145-155
+                rkl = ops.mean(kl_row)
+            else:
+                z, rkl = mu_p, None                                                        # eval: condition on the prior mean
+            dec_init = self.x_init_connector(z)                                            # :711
         attn_ctx = enc_outs if self.config.use_attention else None
         dec_outs, dec_last, dec_ctx = self.x_decoder(B, data_feed["input_ids"], dec_init, mode=mode,
                                                      gen_type=gen_type, beam_size=self.config.beam_size,

@@ -428,9 +428,10 @@ def embedding(weight, ids, padding_idx=None):
 # small exact-fp32 linear
 # ------------------------------------------------------------------------------------------------------------
 
-def _lin(A, sam, sak, Bm, sbk, sbn, bias, Cm, ldc, M, N, K, accumulate=0, alpha=1.0, batch=1, bsa=0, bsb=0, bsc=0):
-    _lib.call("pv_linear_f32", _p(A), sam, sak, _p(Bm), sbk, sbn, _p(bias), _p(Cm), ldc, M, N, K, alpha, accumulate,
-              batch, bsa, bsb, bsc, _stream())
+def _lin(A, sam, sak, Bm, sbk, sbn, bias, Cm, ldc, M, N, K, accumulate=0, alpha=1.0, batch=1, bsa=0, bsb=0, bsc=0,
+         alpha_dev=None):
+    _lib.call("pv_linear_f32", _p(A), sam, sak, _p(Bm), sbk, sbn, _p(bias), _p(Cm), ldc, M, N, K, alpha, _p(alpha_dev),
+              accumulate, batch, bsa, bsb, bsc, _stream())
 
 
 class LinearF32(torch.autograd.Function):
@@ -775,3 +776,180 @@ class GatherNLL(torch.autograd.Function):
         dl = torch.empty((T, V), dtype=torch.float32, device=dout.device)
         _lib.call("pv_pick_nll_bwd", _p(dout.contiguous()), _p(tgt), ignore, T, V, _p(dl), _stream())
         return dl, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# DLS latent pyramid pieces (Block / DlsRec / DlsPri / DLS_Auto, dialog_models.py:253-271, :1835-1870, :3161-3352)
+# ------------------------------------------------------------------------------------------------------------
+
+class AddLayerNorm(torch.autograd.Function):
+    """LayerNorm(x + res) * gamma + beta  (Block: self.layer_norm(x + xhat), dialog_models.py:269)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        _need_cuda(x, res, gamma, beta)
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D).contiguous()
+        r2 = None if res is None else res.reshape(-1, D).contiguous()
+        rows = x2.shape[0]
+        out = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        g, b = gamma.contiguous(), beta.contiguous()
+        _lib.call("pv_layernorm_fwd", _p(x2), _p(r2), _p(g), _p(b), rows, D, eps, _p(out), _p(mean), _p(rstd), _stream())
+        ctx.save_for_backward(x2, r2 if r2 is not None else x2, g, mean, rstd)
+        ctx.has_res = r2 is not None
+        ctx.params = (gamma, beta)
+        ctx.xshape = x.shape
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, r2, g, mean, rstd = ctx.saved_tensors
+        rows, D = x2.shape
+        d2 = dout.reshape(rows, D).contiguous()
+        ds = torch.empty_like(x2)
+        p_g, p_b = ctx.params
+        sg, sb = grad_sink(p_g, (D,)), grad_sink(p_b, (D,))
+        both = sg is not None and sb is not None
+        dg = sg if both else torch.empty(D, dtype=torch.float32, device=x2.device)
+        db = sb if both else torch.empty(D, dtype=torch.float32, device=x2.device)
+        _lib.call("pv_layernorm_bwd", _p(x2), _p(r2) if ctx.has_res else None, _p(g), _p(d2), _p(mean), _p(rstd), rows, D,
+                  _p(ds), _p(dg), _p(db), 1 if both else 0, _stream())
+        ds = ds.view(ctx.xshape)
+        return ds, (ds if ctx.has_res else None), (None if both else dg), (None if both else db), None
+
+
+def add_layer_norm(x, res, gamma, beta, eps=1e-5):
+    return AddLayerNorm.apply(x, res, gamma, beta, eps)
+
+
+class SNLinearFn(torch.autograd.Function):
+    """y = x (W / sigma)^T + b with sigma = u . (W v) from torch.nn.utils.spectral_norm's power iteration
+    (one iteration per TRAINING forward, u / v buffers updated in place, treated as constants by autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, u, v, do_iter, eps):
+        _need_cuda(x, weight, bias, u, v)
+        N, K = weight.shape
+        x2 = x.reshape(-1, K).contiguous()
+        M = x2.shape[0]
+        w = weight.contiguous()
+        inv_sigma = torch.empty(1, dtype=torch.float32, device=x.device)
+        _lib.call("pv_spectral_norm", _p(w), _p(u), _p(v), N, K, eps, 1 if do_iter else 0, _p(inv_sigma), _stream())
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        bc = None if bias is None else bias.contiguous()
+        _lin(x2, K, 1, w, 1, K, bc, y, N, M, N, K, alpha_dev=inv_sigma)
+        ctx.save_for_backward(x2, w, y, bc if bc is not None else inv_sigma, inv_sigma, u.clone(), v.clone())
+        ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
+        ctx.xshape = x.shape
+        return y.view(tuple(x.shape[:-1]) + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y, bc, inv_sigma, u, v = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dev = x2.device
+        dy2 = dy.reshape(M, N).contiguous()
+        p_w, p_b = ctx.params
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+            _lin(dy2, N, 1, w, K, 1, None, dx, K, M, K, N, alpha_dev=inv_sigma)          # dx = dy W / sigma
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            # dL/dW_orig = (G - <G, W_eff> u v^T) / sigma with G = dy^T x: the rank-1 term goes through a scratch copy
+            # so that accumulation into an existing .grad stays a pure add
+            g = torch.empty((N, K), dtype=torch.float32, device=dev)
+            _lin(dy2, 1, N, x2, K, 1, None, g, K, N, K, M, alpha_dev=inv_sigma)
+            scratch = torch.empty(1, dtype=torch.float32, device=dev)
+            _lib.call("pv_spectral_norm_bwd", _p(dy2), _p(y), _p(bc) if ctx.has_bias else None, M, N, K, _p(u), _p(v),
+                      _p(inv_sigma), _p(scratch), _p(g), _stream())
+            dw = g
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            sink = grad_sink(p_b, (N,))
+            db = sink if sink is not None else torch.empty(N, dtype=torch.float32, device=dev)
+            _lib.call("pv_colsum_f32", _p(dy2), M, N, N, _p(db), 1 if sink is not None else 0, _stream())
+            db = None if sink is not None else db
+        return dx, dw, db, None, None, None, None
+
+
+def sn_linear(x, weight_orig, bias, u, v, training, eps=1e-12):
+    return SNLinearFn.apply(x, weight_orig, bias, u, v, bool(training), eps)
+
+
+class L2NormRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x2 = x.contiguous()
+        rows, D = x2.shape
+        a = torch.empty_like(x2)
+        nrm = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.call("pv_l2norm_rows_fwd", _p(x2), rows, D, _p(a), _p(nrm), _stream())
+        ctx.save_for_backward(a, nrm)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        a, nrm = ctx.saved_tensors
+        dx = torch.empty_like(a)
+        _lib.call("pv_l2norm_rows_bwd", _p(a), _p(nrm), _p(da.contiguous()), a.shape[0], a.shape[1], _p(dx), _stream())
+        return dx
+
+
+class InfoNCE(torch.autograd.Function):
+    """(CE(log_softmax(S, rows), diag) + CE(log_softmax(S, cols), diag)) / 2 for a [B,B] score matrix."""
+
+    @staticmethod
+    def forward(ctx, S):
+        _need_cuda(S)
+        Sc = S.contiguous()
+        B = Sc.shape[0]
+        lr = torch.empty(B, dtype=torch.float32, device=S.device)
+        lc = torch.empty(B, dtype=torch.float32, device=S.device)
+        loss = torch.empty(1, dtype=torch.float32, device=S.device)
+        _lib.call("pv_infonce_fwd", _p(Sc), B, _p(lr), _p(lc), _p(loss), _stream())
+        ctx.save_for_backward(Sc, lr, lc)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        Sc, lr, lc = ctx.saved_tensors
+        dS = torch.empty_like(Sc)
+        _lib.call("pv_infonce_bwd", _p(Sc), _p(lr), _p(lc), _p(g.contiguous().view(1)), Sc.shape[0], _p(dS), _stream())
+        return dS
+
+
+class ScaledMatmulNT(torch.autograd.Function):
+    """alpha * a b^T in fp32 (the InfoNCE score matrix v1 @ v2^T * 1.1, dialog_models.py:3271)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b = a.contiguous(), b.contiguous()
+        M, K = a.shape
+        N = b.shape[0]
+        c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        _lin(a, K, 1, b, 1, K, None, c, N, M, N, K, alpha=alpha)
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        M, K = a.shape
+        N = b.shape[0]
+        dc = dc.contiguous()
+        da = torch.empty_like(a)
+        db = torch.empty_like(b)
+        _lin(dc, N, 1, b, K, 1, None, da, K, M, K, N, alpha=ctx.alpha)        # da = alpha dc b
+        _lin(dc, 1, N, a, K, 1, None, db, K, N, K, M, alpha=ctx.alpha)        # db = alpha dc^T a
+        return da, db, None
+
+
+def cons_loss(v1, v2):
+    """DLS_Auto.cons_loss (dialog_models.py:3266-3272) with batch_arrange = arange(B)."""
+    return InfoNCE.apply(ScaledMatmulNT.apply(L2NormRows.apply(v1), L2NormRows.apply(v2), 1.1))

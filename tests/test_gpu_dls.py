@@ -1,0 +1,112 @@
+"""GPU parity of the DLS latent pyramid (a15-a17): Block / DlsRec / DlsPri against the goldens generated from the
+reference's own classes, the DLS_Auto helpers against dls_helpers.npz, and DLSAuto + the composed 'dls' step against
+the CPU oracle.  Everything here is fp32 (f32-input MFMA for the linears): tolerance 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_params
+from oracle import ref_modules as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.array(a)).to(dev)
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_block_golden(dev):
+    from pevae_amd import dls_latent as L
+    g = load_golden("block")
+    blk = load_params(L.Block(32, 16, 24), g).to(dev)
+    blk.train()
+    x = T(g["x"], dev).requires_grad_()
+    y = blk(x)
+    (y * T(g["w"], dev)).sum().backward()
+    close(y, g["y"])
+    close(x.grad, g["dx"])
+    for k, p in blk.named_parameters():
+        close(p.grad, g["g." + k], rtol=3e-4, atol=2e-5)
+    for k, v in blk.state_dict().items():           # power-iteration buffers advanced identically
+        close(v, g["post." + k], rtol=1e-4, atol=1e-6)
+    close(blk(T(g["x"], dev)), g["y2"])
+    blk.eval()
+    close(blk(T(g["x"], dev)), g["y_eval"])
+
+
+@pytest.mark.parametrize("name", ["dlsrec", "dlspri"])
+def test_pyramid_golden(dev, name):
+    from pevae_amd import dls_latent as L
+    g = load_golden(name)
+    m = load_params((L.DlsRec if name == "dlsrec" else L.DlsPri)(64, 16), g).to(dev)
+    m.eval()
+    out, acts = m(T(g["x"], dev))
+    assert len(acts) == int(g["n_acts"])
+    close(out, g["out"])
+    for i, a in enumerate(acts):
+        close(a, g["act%d" % i])
+
+
+def test_cons_loss_and_kl_golden(dev):
+    from pevae_amd import ops
+    g = load_golden("dls_helpers")
+    v1, v2 = T(g["v1"], dev).requires_grad_(), T(g["v2"], dev).requires_grad_()
+    cl = ops.cons_loss(v1, v2)
+    cl.backward()
+    close(cl, g["cons"], rtol=1e-5)
+    close(v1.grad, g["dv1"], rtol=1e-4, atol=1e-6)
+    close(v2.grad, g["dv2"], rtol=1e-4, atol=1e-6)
+    ts = [T(g[k], dev).requires_grad_() for k in ("m1", "m2", "l1", "l2")]
+    _, kl = ops.reparam_kl(ts[0], ts[2] * 0.3, ts[1], ts[3] * 0.3, None, mode=1, want_z=False)
+    ops.mean(kl).backward()
+    close(ops.mean(kl), g["kl"], rtol=1e-5)
+    for n, t in zip(("dm1", "dm2", "dl1", "dl2"), ts):
+        close(t.grad, g[n], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("restarted,training", [(False, True), (True, True), (True, False)])
+def test_dls_auto_matches_oracle(dev, restarted, training):
+    from argparse import Namespace
+    from pevae_amd import dls_latent as L
+    cfg = Namespace(expand_weight=0.5, converge_weight=0.1, cip_weight=1.0, ost=False)
+    torch.manual_seed(3)
+    ref = R.DLSAuto(4, 16, cfg)
+    gpu = L.DLSAuto(4, 16, cfg)
+    gpu.load_state_dict(ref.state_dict())
+    gpu = gpu.to(dev)
+    ref.train(training)
+    gpu.train(training)
+    B = 12
+    gen = torch.Generator().manual_seed(4)
+    ins = [torch.randn(B, 4, generator=gen), torch.randn(B, 4, generator=gen)]
+    act1 = [torch.randn(B, d, generator=gen) for d in (32, 16, 8)]       # [-1] is the deepest level
+    act2 = [torch.randn(B, d, generator=gen) for d in (32, 16, 8)]
+    noise = [torch.rand(B, d, generator=gen) for d in (8, 16, 32)]
+    c = [t.clone().requires_grad_() for t in ins + act1 + act2]
+    z_r, rkl_r = ref(c[0], c[1], c[2:5], c[5:8], restarted, noise=noise)
+    (z_r.sum() * 0.1 + rkl_r).backward()
+    d = [t.to(dev).requires_grad_() for t in ins + act1 + act2]
+    z, rkl = gpu(d[0], d[1], d[2:5], d[5:8], restarted, noise=[n.to(dev) for n in noise])
+    (z.sum() * 0.1 + rkl).backward()
+    close(z, z_r.detach(), rtol=2e-4, atol=2e-5)
+    close(rkl, rkl_r.detach(), rtol=2e-4, atol=2e-5)
+    # gradients: 5e-4 relative plus 1e-4 of the tensor's largest entry (fp32 sums in a different order)
+    for a, b in zip(d, c):
+        if b.grad is not None:
+            close(a.grad, b.grad, rtol=5e-4, atol=5e-5 + 1e-4 * float(b.grad.abs().max()))
+    ref_p = dict(ref.named_parameters())
+    for n, p in gpu.named_parameters():
+        if ref_p[n].grad is not None:
+            close(p.grad, ref_p[n].grad, rtol=1e-3, atol=5e-5 + 1e-4 * float(ref_p[n].grad.abs().max()))

@@ -25,7 +25,7 @@ def _pair(cfg, dev):
     return gpu.to(dev), ref
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(use_attention=True), dict(do_pred=True)])
+@pytest.mark.parametrize("kw", [dict(), dict(use_attention=True), dict(do_pred=True), dict(latent_stack="dls")])
 def test_step_matches_oracle(dev, kw):
     from pevae_amd import ops
     from pevae_amd.dls_vae import default_config, synthetic_batch
@@ -37,7 +37,12 @@ def test_step_matches_oracle(dev, kw):
     ref.train()
     feed = synthetic_batch(cfg, 24, 99)
     feed_d = {k: v.to(dev) for k, v in feed.items()}
-    eps = torch.randn(24, 16, generator=torch.Generator().manual_seed(3))
+    gen = torch.Generator().manual_seed(3)
+    if kw.get("latent_stack") == "dls":        # uniform draws of the three DLS_Auto levels (H/16, H/8, H/4 wide)
+        eps = [torch.rand(24, d, generator=gen) for d in (4, 8, 16)]
+    else:
+        eps = torch.randn(24, 16, generator=gen)
+    to_dev = lambda e: [t.to(dev) for t in e] if isinstance(e, list) else e.to(dev)
 
     opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3)
     loss_r = ref(feed, eps=eps)
@@ -48,7 +53,7 @@ def test_step_matches_oracle(dev, kw):
 
     opt = FlatAdam(gpu.parameters(), lr=1e-3, max_norm=5.0, guards=False)     # grads now sink into the flat buffer
     opt.zero_grad()
-    loss = gpu(feed_d, eps=eps.to(dev))
+    loss = gpu(feed_d, eps=to_dev(eps))
     gpu.valid_loss(loss).backward()
     torch.cuda.synchronize()
     ops.gru_check_all()
