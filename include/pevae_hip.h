@@ -157,6 +157,17 @@ int pv_layernorm_bwd(const float* x, const float* y, const float* gamma, const f
  * dW -= <dy, y - bias> * inv_sigma * u v^T  (dW must already hold (dy^T x) * inv_sigma); scratch1: one float. */
 int pv_spectral_norm(const float* W, float* u, float* v, int n_out, int n_in, float eps, int do_iter, float* inv_sigma,
                      void* stream);
+/* Multi-tensor form: `descs` is a device array of `count` records {const float* W; float* u; float* v;
+ * float* inv_sigma; int64 n_out; int64 n_in} (48 bytes each); one workgroup per weight, one launch per step. */
+int pv_spectral_norm_multi(const void* descs, int count, int max_out, int max_in, float eps, int do_iter, void* stream);
+/* One pass over dy: db[n] (+)= sum_m dy (db may be NULL) and cpart[j] = sum over the j-th 64-column block of
+ * dy * (y - bias); sum_j cpart[j] = <dL/dW_eff, W_eff>, consumed by pv_linear_f32_fused's rank-1 epilogue. */
+int pv_spectral_norm_reduce(const float* dy, const float* y, const float* bias, int M, int N, float* db,
+                            int accumulate_db, float* cpart, void* stream);
+int pv_linear_f32_fused(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias,
+                        float* C, long ldc, int M, int N, int K, float alpha, const float* alpha_dev, int accumulate,
+                        int gelu_a, int gelu_b, const float* gelu_grad, const float* r1_c, int r1_nc,
+                        const float* r1_u, const float* r1_v, void* stream);
 int pv_spectral_norm_bwd(const float* dy, const float* y, const float* bias, long M, int n_out, int n_in, const float* u,
                          const float* v, const float* inv_sigma, float* scratch1, float* dW, void* stream);
 /* DLS_Auto.cons_loss (:3266-3272): row L2 normalisation and the symmetric InfoNCE over a [B][B] score matrix with

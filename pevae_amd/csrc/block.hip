@@ -97,9 +97,17 @@ __global__ void layernorm_bwd_params_kernel(const float* __restrict__ x, const f
 // torch.nn.utils.spectral_norm (hook form, one power iteration per training forward, dialog_models.py:258-263):
 //   training: v = normalize(W^T u), u = normalize(W v) (buffers updated in place);  sigma = u . (W v)
 // One block per matrix; writes 1/sigma.  W [out][in] row-major.
-__global__ __launch_bounds__(256) void spectral_iter_kernel(const float* __restrict__ W, float* __restrict__ u,
-                                                             float* __restrict__ v, int n_out, int n_in, float eps,
-                                                             int do_iter, float* __restrict__ inv_sigma) {
+struct SnDesc {             // one spectral-norm weight (device array for the multi-tensor launch)
+  const float* W;
+  float* u;
+  float* v;
+  float* inv_sigma;
+  long n_out, n_in;
+};
+
+__device__ __forceinline__ void spectral_iter_body(const float* __restrict__ W, float* __restrict__ u,
+                                                   float* __restrict__ v, int n_out, int n_in, float eps,
+                                                   int do_iter, float* __restrict__ inv_sigma) {
   extern __shared__ float sh[];           // u [n_out], v [n_in], wv [n_out], red [4]
   float* su = sh;
   float* sv = sh + n_out;
@@ -143,6 +151,44 @@ __global__ __launch_bounds__(256) void spectral_iter_kernel(const float* __restr
   for (int i = tid; i < n_out; i += 256) d += su[i] * swv[i];
   d = block_sum(d, red);
   if (tid == 0) inv_sigma[0] = 1.f / d;
+}
+
+__global__ __launch_bounds__(256) void spectral_iter_kernel(const float* __restrict__ W, float* __restrict__ u,
+                                                             float* __restrict__ v, int n_out, int n_in, float eps,
+                                                             int do_iter, float* __restrict__ inv_sigma) {
+  spectral_iter_body(W, u, v, n_out, n_in, eps, do_iter, inv_sigma);
+}
+// one workgroup per weight: every spectral-norm matrix of the model advances in ONE launch
+__global__ __launch_bounds__(256) void spectral_iter_multi_kernel(const SnDesc* __restrict__ desc, float eps, int do_iter) {
+  const SnDesc d = desc[blockIdx.x];
+  spectral_iter_body(d.W, d.u, d.v, (int)d.n_out, (int)d.n_in, eps, do_iter, d.inv_sigma);
+}
+
+// One pass over dy for a spectral-norm linear's backward: db[n] (+)= sum_m dy[m][n] and, per 64-column block,
+// cpart[block] = sum_{m, n in block} dy[m][n] * (y[m][n] - bias[n]); the sum of cpart is <dL/dW_eff, W_eff>.
+__global__ __launch_bounds__(256) void sn_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ bias, int M, int N,
+                                                         float* __restrict__ db, int accumulate_db,
+                                                         float* __restrict__ cpart) {
+  __shared__ float part[4][64];
+  __shared__ float red[4];
+  const int cl = threadIdx.x & 63, yy = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float s = 0.f, q = 0.f;
+  if (c < N) {
+    const float b = bias ? bias[c] : 0.f;
+    for (int r = yy; r < M; r += 4) {
+      const float d = dy[(size_t)r * N + c];
+      s += d;
+      q += d * (y[(size_t)r * N + c] - b);
+    }
+  }
+  part[yy][cl] = s;
+  q = block_sum(q, red);
+  if (threadIdx.x == 0) cpart[blockIdx.x] = q;
+  if (yy == 0 && c < N && db) {
+    const float t = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
+    db[c] = accumulate_db ? db[c] + t : t;
+  }
 }
 
 // c = sum_{m,n} dy[m][n] * (y[m][n] - bias[n])  =  <dL/dW_eff, W_eff>   (one block, fixed order)
@@ -254,6 +300,27 @@ int pv_spectral_norm(const float* W, float* u, float* v, int n_out, int n_in, fl
   hipLaunchKernelGGL(spectral_iter_kernel, dim3(1), dim3(256), smem, (hipStream_t)stream, W, u, v, n_out, n_in, eps,
                      do_iter, inv_sigma);
   PV_LAUNCH_CHECK("spectral_iter_kernel");
+  return PV_OK;
+}
+
+/* descs: device array of {W, u, v, inv_sigma (pointers), n_out, n_in (int64)} records, 48 bytes each */
+int pv_spectral_norm_multi(const void* descs, int count, int max_out, int max_in, float eps, int do_iter, void* stream) {
+  PV_REQUIRE(descs && count > 0 && max_out > 0 && max_in > 0, "pv_spectral_norm_multi: bad argument");
+  const size_t smem = (size_t)(2 * max_out + max_in + 4) * sizeof(float);
+  PV_REQUIRE(smem <= 64 * 1024, "pv_spectral_norm_multi: %d x %d exceeds the 64 KiB LDS staging", max_out, max_in);
+  hipLaunchKernelGGL(spectral_iter_multi_kernel, dim3(count), dim3(256), smem, (hipStream_t)stream, (const SnDesc*)descs,
+                     eps, do_iter);
+  PV_LAUNCH_CHECK("spectral_iter_multi_kernel");
+  return PV_OK;
+}
+
+/* db (optional) and the cdiv(N,64) partial sums of <dy, y - bias> in one pass over dy */
+int pv_spectral_norm_reduce(const float* dy, const float* y, const float* bias, int M, int N, float* db,
+                            int accumulate_db, float* cpart, void* stream) {
+  PV_REQUIRE(dy && y && cpart && M > 0 && N > 0, "pv_spectral_norm_reduce: bad argument");
+  hipLaunchKernelGGL(sn_reduce_kernel, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, dy, y, bias, M, N, db,
+                     accumulate_db, cpart);
+  PV_LAUNCH_CHECK("sn_reduce_kernel");
   return PV_OK;
 }
 

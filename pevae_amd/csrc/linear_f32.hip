@@ -33,7 +33,19 @@ struct LinArgs {
   const float* alpha_dev;   // optional device scalar multiplied into alpha (1/sigma of a spectral-norm weight)
   int accumulate;
   int modeA, modeB;
+  int gelu_a, gelu_b;       // apply GELU (erf form) to every A / B element as it is staged (Block: c(gelu(x)))
+  const float* gelu_grad;   // optional [M][N] (ld = N): C = result * gelu'(gelu_grad[m][n])  (backward through the GELU)
+  const float* r1_c;        // optional rank-1 correction (spectral-norm weight gradient):
+  const float* r1_u;        //   C -= (sum of r1_c[0..r1_nc)) * alpha_dev[0] * r1_u[m] * r1_v[n]
+  const float* r1_v;
+  int r1_nc;
 };
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
 
 // P[x*sx + k*sk] for x in [x0, x0+64), k in [k0, k0+32) -> 8 registers per thread
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, long sx, long sk, int X, int K, int x0, int k0,
@@ -111,6 +123,14 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
   const int nk = (g.K + TK - 1) / TK;
   tile_load(A, g.sam, g.sak, g.M, g.K, m0, 0, g.modeA, tid, ra);
   tile_load(B, g.sbn, g.sbk, g.N, g.K, n0, 0, g.modeB, tid, rb);
+  if (g.gelu_a) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ra[i] = gelu_f(ra[i]);      // gelu(0) = 0: zero padding stays zero
+  }
+  if (g.gelu_b) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rb[i] = gelu_f(rb[i]);
+  }
   tile_store(lds[0][0], g.modeA, tid, ra);
   tile_store(lds[0][1], g.modeB, tid, rb);
   __syncthreads();
@@ -132,12 +152,25 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
     }
     if (kt + 1 < nk) {
+      if (g.gelu_a) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ra[i] = gelu_f(ra[i]);
+      }
+      if (g.gelu_b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] = gelu_f(rb[i]);
+      }
       tile_store(lds[s ^ 1][0], g.modeA, tid, ra);
       tile_store(lds[s ^ 1][1], g.modeB, tid, rb);
     }
     __syncthreads();
   }
   const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+  float r1 = 0.f;
+  if (g.r1_c) {
+    for (int i = 0; i < g.r1_nc; ++i) r1 += g.r1_c[i];       // fixed order
+    r1 *= g.alpha_dev ? g.alpha_dev[0] : 1.f;
+  }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int n = n0 + wn * 32 + u * 16 + i16;
@@ -150,6 +183,8 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
         const int m = m0 + wm * 32 + t * 16 + kq * 4 + r;
         if (m >= g.M) continue;
         float v = alpha * acc[t][u][r] + bv;
+        if (g.gelu_grad) v *= gelu_df(g.gelu_grad[(long)m * g.N + n]);
+        if (g.r1_c) v -= r1 * g.r1_u[m] * g.r1_v[n];
         float* dst = C + (long)m * g.ldc + n;
         if (g.accumulate) v += *dst;
         *dst = v;
@@ -174,8 +209,24 @@ int pv_linear_f32(const float* A, long sam, long sak, const float* B, long sbk, 
                   int batch, long bsa, long bsb, long bsc, void* stream) {
   PV_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && ldc >= N, "pv_linear_f32: bad argument");
   LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, bsa, bsb, bsc, alpha, alpha_dev, accumulate,
-            pick_mode(A, sam, sak, bsa, batch), pick_mode(B, sbn, sbk, bsb, batch)};
+            pick_mode(A, sam, sak, bsa, batch), pick_mode(B, sbn, sbk, bsb, batch), 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
   hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv(N, TN), cdiv(M, TM), batch), dim3(256), 0, (hipStream_t)stream, g);
+  PV_LAUNCH_CHECK("linear_f32_kernel");
+  return PV_OK;
+}
+
+// The same GEMM with the Block fusions (dialog_models.py:258-269): gelu_a / gelu_b != 0 apply GELU to A / B while staged
+// (y = c(gelu(x)) in one launch); gelu_grad multiplies the result by gelu'(gelu_grad[m][n]) (backward through that
+// GELU); r1_* subtract the spectral-norm rank-1 term from a weight gradient (see pv_spectral_norm_reduce).
+int pv_linear_f32_fused(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias,
+                        float* C, long ldc, int M, int N, int K, float alpha, const float* alpha_dev, int accumulate,
+                        int gelu_a, int gelu_b, const float* gelu_grad, const float* r1_c, int r1_nc, const float* r1_u,
+                        const float* r1_v, void* stream) {
+  PV_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, "pv_linear_f32_fused: bad argument");
+  PV_REQUIRE(!r1_c || (r1_u && r1_v && r1_nc > 0), "pv_linear_f32_fused: rank-1 term needs c, u and v");
+  LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, 0, 0, 0, alpha, alpha_dev, accumulate,
+            pick_mode(A, sam, sak, 0, 1), pick_mode(B, sbn, sbk, 0, 1), gelu_a, gelu_b, gelu_grad, r1_c, r1_u, r1_v, r1_nc};
+  hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv(N, TN), cdiv(M, TM), 1), dim3(256), 0, (hipStream_t)stream, g);
   PV_LAUNCH_CHECK("linear_f32_kernel");
   return PV_OK;
 }

@@ -28,8 +28,13 @@ class SNLinear(nn.Module):
         self.register_buffer("weight_u", nn.functional.normalize(torch.randn(out_f), dim=0, eps=eps))
         self.register_buffer("weight_v", nn.functional.normalize(torch.randn(in_f), dim=0, eps=eps))
 
-    def forward(self, x):
-        return ops.sn_linear(x, self.weight_orig, self.bias, self.weight_u, self.weight_v, self.training, self.eps)
+        self._inv_sigma_pre = None      # set by ops.spectral_prepass for exactly one forward
+
+    def forward(self, x, gelu_in=False):
+        """(gelu(x) if gelu_in else x) @ (W / sigma)^T + b."""
+        pre, self._inv_sigma_pre = self._inv_sigma_pre, None
+        return ops.sn_linear(x, self.weight_orig, self.bias, self.weight_u, self.weight_v, self.training, self.eps,
+                             gelu_in=gelu_in, inv_sigma=pre)
 
 
 class Block(nn.Module):
@@ -44,10 +49,10 @@ class Block(nn.Module):
         self.translate = SNLinear(input_dim, output_dim)
 
     def forward(self, x):
-        y = self.c1(ops.gelu(x))
-        y = self.c2(ops.gelu(y))
-        y = self.c3(ops.gelu(y))
-        y = self.c4(ops.gelu(y))
+        y = self.c1(x, gelu_in=True)            # the GELUs are fused into the staging of each linear's input
+        y = self.c2(y, gelu_in=True)
+        y = self.c3(y, gelu_in=True)
+        y = self.c4(y, gelu_in=True)
         out = ops.add_layer_norm(x, y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         return self.translate(out)
 
@@ -80,6 +85,10 @@ class DlsRec(_Pyramid):
 class DlsPri(_Pyramid):
     def __init__(self, input_dim, output_dim, config=None):
         super().__init__(input_dim, output_dim, wrap=True)
+
+
+def spectral_modules(root):
+    return [m for m in root.modules() if isinstance(m, SNLinear)]
 
 
 class DLSAuto(nn.Module):

@@ -98,6 +98,9 @@ class DLSVAE(nn.Module):
         prior_h = ops.tanh(ops.linear(torch.cat([user, item, rating], -1), self.prior_fc.weight, self.prior_fc.bias))
         B = h.size(0)
         if self.latent_stack == "dls":
+            if getattr(self, "_sn_modules", None) is None:
+                self._sn_modules, self._sn_cache = L.spectral_modules(self), {}
+            ops.spectral_prepass(self._sn_modules, self.training, cache=self._sn_cache)    # all 105 power iterations, one launch
             z_pri, pri_state = self.pri_encoder(prior_h)                                   # :3529
             z_rec, rec_state = self.rec_encoder(h)                                         # :3530
             z, rkl = self.sup_decoder(z_pri, z_rec, rec_state, pri_state,

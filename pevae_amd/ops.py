@@ -824,24 +824,39 @@ def add_layer_norm(x, res, gamma, beta, eps=1e-5):
     return AddLayerNorm.apply(x, res, gamma, beta, eps)
 
 
+def _lin_fused(A, sam, sak, Bm, sbk, sbn, bias, Cm, ldc, M, N, K, alpha_dev=None, accumulate=0, gelu_a=0, gelu_b=0,
+               gelu_grad=None, r1_c=None, r1_u=None, r1_v=None):
+    _lib.call("pv_linear_f32_fused", _p(A), sam, sak, _p(Bm), sbk, sbn, _p(bias), _p(Cm), ldc, M, N, K, 1.0,
+              _p(alpha_dev), accumulate, gelu_a, gelu_b, _p(gelu_grad), _p(r1_c), 0 if r1_c is None else r1_c.numel(),
+              _p(r1_u), _p(r1_v), _stream())
+
+
 class SNLinearFn(torch.autograd.Function):
-    """y = x (W / sigma)^T + b with sigma = u . (W v) from torch.nn.utils.spectral_norm's power iteration
-    (one iteration per TRAINING forward, u / v buffers updated in place, treated as constants by autograd)."""
+    """y = act(x) (W / sigma)^T + b, act = GELU or identity, sigma = u . (W v) from torch.nn.utils.spectral_norm's power
+    iteration (one per TRAINING forward; u / v are constants for autograd).  `inv_sigma_pre` carries 1/sigma when the
+    model-wide multi-tensor pre-pass (spectral_prepass) has already advanced u / v for this step.  Backward is three
+    launches: one pass over dy (bias gradient + <dL/dW_eff, W_eff>), dx with the GELU derivative in the epilogue, and
+    dW with the rank-1 spectral term in the epilogue, accumulated straight into an existing .grad."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, u, v, do_iter, eps):
+    def forward(ctx, x, weight, bias, u, v, do_iter, eps, gelu_in, inv_sigma_pre):
         _need_cuda(x, weight, bias, u, v)
         N, K = weight.shape
         x2 = x.reshape(-1, K).contiguous()
         M = x2.shape[0]
         w = weight.contiguous()
-        inv_sigma = torch.empty(1, dtype=torch.float32, device=x.device)
-        _lib.call("pv_spectral_norm", _p(w), _p(u), _p(v), N, K, eps, 1 if do_iter else 0, _p(inv_sigma), _stream())
+        if inv_sigma_pre is None:
+            inv_sigma = torch.empty(1, dtype=torch.float32, device=x.device)
+            _lib.call("pv_spectral_norm", _p(w), _p(u), _p(v), N, K, eps, 1 if do_iter else 0, _p(inv_sigma), _stream())
+            u, v = u.clone(), v.clone()          # a later forward may advance the buffers before this backward runs
+        else:
+            inv_sigma = inv_sigma_pre            # u / v advance once per step, before any forward of that step
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         bc = None if bias is None else bias.contiguous()
-        _lin(x2, K, 1, w, 1, K, bc, y, N, M, N, K, alpha_dev=inv_sigma)
-        ctx.save_for_backward(x2, w, y, bc if bc is not None else inv_sigma, inv_sigma, u.clone(), v.clone())
+        _lin_fused(x2, K, 1, w, 1, K, bc, y, N, M, N, K, alpha_dev=inv_sigma, gelu_a=1 if gelu_in else 0)
+        ctx.save_for_backward(x2, w, y, bc if bc is not None else inv_sigma, inv_sigma, u, v)
         ctx.has_bias = bias is not None
+        ctx.gelu_in = gelu_in
         ctx.params = (weight, bias)
         ctx.xshape = x.shape
         return y.view(tuple(x.shape[:-1]) + (N,))
@@ -855,29 +870,56 @@ class SNLinearFn(torch.autograd.Function):
         dy2 = dy.reshape(M, N).contiguous()
         p_w, p_b = ctx.params
         dx = dw = db = None
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        cpart = torch.empty((N + 63) // 64, dtype=torch.float32, device=dev)
+        sink_b = grad_sink(p_b, (N,)) if want_b else None
+        if want_b and sink_b is None:
+            db = torch.empty(N, dtype=torch.float32, device=dev)
+        if want_w or want_b:
+            _lib.call("pv_spectral_norm_reduce", _p(dy2), _p(y), _p(bc) if ctx.has_bias else None, M, N,
+                      _p(sink_b if sink_b is not None else db), 1 if sink_b is not None else 0, _p(cpart), _stream())
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-            _lin(dy2, N, 1, w, K, 1, None, dx, K, M, K, N, alpha_dev=inv_sigma)          # dx = dy W / sigma
+            _lin_fused(dy2, N, 1, w, K, 1, None, dx, K, M, K, N, alpha_dev=inv_sigma,
+                       gelu_grad=x2 if ctx.gelu_in else None)                     # dx = (dy W / sigma) * act'(x)
             dx = dx.view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            # dL/dW_orig = (G - <G, W_eff> u v^T) / sigma with G = dy^T x: the rank-1 term goes through a scratch copy
-            # so that accumulation into an existing .grad stays a pure add
-            g = torch.empty((N, K), dtype=torch.float32, device=dev)
-            _lin(dy2, 1, N, x2, K, 1, None, g, K, N, K, M, alpha_dev=inv_sigma)
-            scratch = torch.empty(1, dtype=torch.float32, device=dev)
-            _lib.call("pv_spectral_norm_bwd", _p(dy2), _p(y), _p(bc) if ctx.has_bias else None, M, N, K, _p(u), _p(v),
-                      _p(inv_sigma), _p(scratch), _p(g), _stream())
-            dw = g
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            sink = grad_sink(p_b, (N,))
-            db = sink if sink is not None else torch.empty(N, dtype=torch.float32, device=dev)
-            _lib.call("pv_colsum_f32", _p(dy2), M, N, N, _p(db), 1 if sink is not None else 0, _stream())
-            db = None if sink is not None else db
-        return dx, dw, db, None, None, None, None
+        if want_w:
+            # dL/dW_orig = (dy^T act(x) - <dL/dW_eff, W_eff> u v^T) / sigma
+            sink = grad_sink(p_w, (N, K))
+            dw = sink if sink is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
+            _lin_fused(dy2, 1, N, x2, K, 1, None, dw, K, N, K, M, alpha_dev=inv_sigma, accumulate=1 if sink is not None else 0,
+                       gelu_b=1 if ctx.gelu_in else 0, r1_c=cpart, r1_u=u, r1_v=v)
+            dw = None if sink is not None else dw
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def sn_linear(x, weight_orig, bias, u, v, training, eps=1e-12):
-    return SNLinearFn.apply(x, weight_orig, bias, u, v, bool(training), eps)
+def sn_linear(x, weight_orig, bias, u, v, training, eps=1e-12, gelu_in=False, inv_sigma=None):
+    return SNLinearFn.apply(x, weight_orig, bias, u, v, bool(training), eps, bool(gelu_in), inv_sigma)
+
+
+def spectral_prepass(modules, training, eps=1e-12, cache=None):
+    """Advance the power iteration of EVERY spectral-norm weight of a model in one launch (one workgroup per weight)
+    and hand each module its 1/sigma for the forward that follows.  `modules`: objects with weight_orig, weight_u,
+    weight_v; `cache`: a dict kept by the caller (descriptor table, rebuilt only when a pointer moved)."""
+    import numpy as np
+    cache = {} if cache is None else cache
+    ptrs = tuple((m.weight_orig.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr()) for m in modules)
+    if cache.get("ptrs") != ptrs:
+        dev = modules[0].weight_orig.device
+        inv = torch.empty(len(modules), dtype=torch.float32, device=dev)
+        rec = np.zeros((len(modules), 6), dtype=np.int64)
+        for i, m in enumerate(modules):
+            assert m.weight_orig.is_contiguous()
+            n_out, n_in = m.weight_orig.shape
+            rec[i] = (ptrs[i][0], ptrs[i][1], ptrs[i][2], inv.data_ptr() + 4 * i, n_out, n_in)
+        cache.update(ptrs=ptrs, inv=inv, desc=torch.from_numpy(rec).to(dev), max_out=int(rec[:, 4].max()),
+                     max_in=int(rec[:, 5].max()))
+    _lib.call("pv_spectral_norm_multi", _p(cache["desc"]), len(modules), cache["max_out"], cache["max_in"], eps,
+              1 if training else 0, _stream())
+    for i, m in enumerate(modules):
+        m._inv_sigma_pre = cache["inv"][i:i + 1]
+    return cache
 
 
 class L2NormRows(torch.autograd.Function):
