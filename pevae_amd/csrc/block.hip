@@ -76,22 +76,49 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
-// dgamma[c] (+)= sum_r dout * xhat, dbeta[c] (+)= sum_r dout   (rows in order: reproducible)
-__global__ void layernorm_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                            const float* __restrict__ dout, const float* __restrict__ mean,
-                                            const float* __restrict__ rstd, int rows, int D, int accumulate,
-                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+// dgamma[c] (+)= sum_r dout * xhat, dbeta[c] (+)= sum_r dout.  Block = 64 columns x 4 row phases, the phases are
+// added in a fixed order (reproducible).
+__global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                    const float* __restrict__ dout,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, int rows, int D,
+                                                                    int accumulate, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta) {
+  __shared__ float pg[4][64], pb[4][64];
+  const int cl = threadIdx.x & 63, yy = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float g = 0.f, b = 0.f;
-  for (int r = 0; r < rows; ++r) {
-    const float s = x[(size_t)r * D + c] + (y ? y[(size_t)r * D + c] : 0.f);
-    const float d = dout[(size_t)r * D + c];
-    g += d * (s - mean[r]) * rstd[r];
-    b += d;
+  if (c < D) {
+    int r = yy;
+    for (; r + 12 < rows; r += 16) {
+      float sv[4], dv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const size_t o = (size_t)(r + 4 * k) * D + c;
+        sv[k] = x[o] + (y ? y[o] : 0.f);
+        dv[k] = dout[o];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g += dv[k] * (sv[k] - mean[r + 4 * k]) * rstd[r + 4 * k];
+        b += dv[k];
+      }
+    }
+    for (; r < rows; r += 4) {
+      const size_t o = (size_t)r * D + c;
+      const float d = dout[o];
+      g += d * (x[o] + (y ? y[o] : 0.f) - mean[r]) * rstd[r];
+      b += d;
+    }
   }
-  dgamma[c] = accumulate ? dgamma[c] + g : g;
-  dbeta[c] = accumulate ? dbeta[c] + b : b;
+  pg[yy][cl] = g;
+  pb[yy][cl] = b;
+  __syncthreads();
+  if (yy == 0 && c < D) {
+    const float tg = ((pg[0][cl] + pg[1][cl]) + pg[2][cl]) + pg[3][cl];
+    const float tb = ((pb[0][cl] + pb[1][cl]) + pb[2][cl]) + pb[3][cl];
+    dgamma[c] = accumulate ? dgamma[c] + tg : tg;
+    dbeta[c] = accumulate ? dbeta[c] + tb : tb;
+  }
 }
 
 // torch.nn.utils.spectral_norm (hook form, one power iteration per training forward, dialog_models.py:258-263):
@@ -119,9 +146,17 @@ __device__ __forceinline__ void spectral_iter_body(const float* __restrict__ W, 
   __syncthreads();
   if (do_iter) {
     float nn = 0.f;
-    for (int j = tid; j < n_in; j += 256) {        // v = W^T u   (coalesced over j)
+    for (int j = tid; j < n_in; j += 256) {        // v = W^T u   (coalesced over j, 8 rows in flight)
       float s = 0.f;
-      for (int i = 0; i < n_out; ++i) s += W[(size_t)i * n_in + j] * su[i];
+      int i = 0;
+      for (; i + 8 <= n_out; i += 8) {
+        float wv8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv8[k] = W[(size_t)(i + k) * n_in + j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += wv8[k] * su[i + k];
+      }
+      for (; i < n_out; ++i) s += W[(size_t)i * n_in + j] * su[i];
       sv[j] = s;
       nn += s * s;
     }
@@ -130,11 +165,19 @@ __device__ __forceinline__ void spectral_iter_body(const float* __restrict__ W, 
     for (int j = tid; j < n_in; j += 256) sv[j] *= inv;
     __syncthreads();
   }
-  for (int i = w; i < n_out; i += 4) {             // wv = W v   (one wave per row)
-    float s = 0.f;
-    for (int j = lane; j < n_in; j += 64) s += W[(size_t)i * n_in + j] * sv[j];
-    s = wave_sum(s);
-    if (lane == 0) swv[i] = s;
+  for (int i0 = w * 4; i0 < n_out; i0 += 16) {     // wv = W v   (one wave per 4 rows: 4 independent row sums)
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = lane; j < n_in; j += 64) {
+      const float vj = sv[j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k < n_out) s4[k] += W[(size_t)(i0 + k) * n_in + j] * vj;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float t = wave_sum(s4[k]);
+      if (lane == 0 && i0 + k < n_out) swv[i0 + k] = t;
+    }
   }
   __syncthreads();
   if (do_iter) {
@@ -176,7 +219,21 @@ __global__ __launch_bounds__(256) void sn_reduce_kernel(const float* __restrict_
   float s = 0.f, q = 0.f;
   if (c < N) {
     const float b = bias ? bias[c] : 0.f;
-    for (int r = yy; r < M; r += 4) {
+    int r = yy;
+    for (; r + 28 < M; r += 32) {                    // 16 independent loads in flight
+      float d[8], v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        d[k] = dy[(size_t)(r + 4 * k) * N + c];
+        v[k] = y[(size_t)(r + 4 * k) * N + c];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s += d[k];
+        q += d[k] * (v[k] - b);
+      }
+    }
+    for (; r < M; r += 4) {
       const float d = dy[(size_t)r * N + c];
       s += d;
       q += d * (y[(size_t)r * N + c] - b);
@@ -286,7 +343,7 @@ int pv_layernorm_bwd(const float* x, const float* y, const float* gamma, const f
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, y, gamma, dout, mean, rstd, rows, D, ds);
   PV_LAUNCH_CHECK("layernorm_bwd_kernel");
-  hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(cdiv(D, 64)), dim3(64), 0, st, x, y, dout, mean, rstd, rows, D,
+  hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, x, y, dout, mean, rstd, rows, D,
                      accumulate_params, dgamma, dbeta);
   PV_LAUNCH_CHECK("layernorm_bwd_params_kernel");
   return PV_OK;

@@ -119,29 +119,33 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ra[8], rb[8];
+  // Two K-tiles of global loads stay in flight: while tile kt is multiplied out of LDS, tile kt+1 sits in one
+  // register set (already requested a whole iteration ago) and tile kt+2 is being requested into the other.
+  float ra0[8], rb0[8], ra1[8], rb1[8];
   const int nk = (g.K + TK - 1) / TK;
-  tile_load(A, g.sam, g.sak, g.M, g.K, m0, 0, g.modeA, tid, ra);
-  tile_load(B, g.sbn, g.sbk, g.N, g.K, n0, 0, g.modeB, tid, rb);
-  if (g.gelu_a) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ra[i] = gelu_f(ra[i]);      // gelu(0) = 0: zero padding stays zero
-  }
-  if (g.gelu_b) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = gelu_f(rb[i]);
-  }
-  tile_store(lds[0][0], g.modeA, tid, ra);
-  tile_store(lds[0][1], g.modeB, tid, rb);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int s = kt & 1;
-    if (kt + 1 < nk) {
-      tile_load(A, g.sam, g.sak, g.M, g.K, m0, (kt + 1) * TK, g.modeA, tid, ra);
-      tile_load(B, g.sbn, g.sbk, g.N, g.K, n0, (kt + 1) * TK, g.modeB, tid, rb);
+  auto fetch = [&](int kt, float (&ra)[8], float (&rb)[8]) {
+    if (kt < nk) {
+      tile_load(A, g.sam, g.sak, g.M, g.K, m0, kt * TK, g.modeA, tid, ra);
+      tile_load(B, g.sbn, g.sbk, g.N, g.K, n0, kt * TK, g.modeB, tid, rb);
     }
-    const float* As = lds[s][0] + wm * 32 + i16;
-    const float* Bs = lds[s][1] + wn * 32 + i16;
+  };
+  auto stash = [&](int kt, float (&ra)[8], float (&rb)[8]) {      // registers -> LDS buffer kt & 1
+    if (kt < nk) {
+      if (g.gelu_a) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ra[i] = gelu_f(ra[i]);        // gelu(0) = 0: zero padding stays zero
+      }
+      if (g.gelu_b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] = gelu_f(rb[i]);
+      }
+      tile_store(lds[kt & 1][0], g.modeA, tid, ra);
+      tile_store(lds[kt & 1][1], g.modeB, tid, rb);
+    }
+  };
+  auto multiply = [&](int kt) {
+    const float* As = lds[kt & 1][0] + wm * 32 + i16;
+    const float* Bs = lds[kt & 1][1] + wn * 32 + i16;
 #pragma unroll
     for (int ks = 0; ks < TK / 4; ++ks) {
       const int kr = (ks * 4 + kq) * LS;
@@ -151,19 +155,22 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
-      if (g.gelu_a) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ra[i] = gelu_f(ra[i]);
-      }
-      if (g.gelu_b) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rb[i] = gelu_f(rb[i]);
-      }
-      tile_store(lds[s ^ 1][0], g.modeA, tid, ra);
-      tile_store(lds[s ^ 1][1], g.modeB, tid, rb);
-    }
+  };
+  fetch(0, ra0, rb0);
+  fetch(1, ra1, rb1);
+  stash(0, ra0, rb0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    fetch(kt + 2, ra0, rb0);          // set 0 is free: tile kt already sits in LDS
+    multiply(kt);
+    stash(kt + 1, ra1, rb1);
     __syncthreads();
+    if (kt + 1 < nk) {
+      fetch(kt + 3, ra1, rb1);
+      multiply(kt + 1);
+      stash(kt + 2, ra0, rb0);
+      __syncthreads();
+    }
   }
   const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
   float r1 = 0.f;
