@@ -166,7 +166,7 @@ int pv_spectral_norm_reduce(const float* dy, const float* y, const float* bias, 
                             int accumulate_db, float* cpart, void* stream);
 int pv_linear_f32_fused(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias,
                         float* C, long ldc, int M, int N, int K, float alpha, const float* alpha_dev, int accumulate,
-                        int gelu_a, int gelu_b, const float* gelu_grad, const float* r1_c, int r1_nc,
+                        float* gelu_out, const float* gelu_grad, const float* r1_c, int r1_nc,
                         const float* r1_u, const float* r1_v, void* stream);
 int pv_spectral_norm_bwd(const float* dy, const float* y, const float* bias, long M, int n_out, int n_in, const float* u,
                          const float* v, const float* inv_sigma, float* scratch1, float* dW, void* stream);

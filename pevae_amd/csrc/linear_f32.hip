@@ -33,7 +33,7 @@ struct LinArgs {
   const float* alpha_dev;   // optional device scalar multiplied into alpha (1/sigma of a spectral-norm weight)
   int accumulate;
   int modeA, modeB;
-  int gelu_a, gelu_b;       // apply GELU (erf form) to every A / B element as it is staged (Block: c(gelu(x)))
+  float* gelu_out;          // optional [M][N] (ld = N): also write gelu(C) (the next Block linear's input, erf form)
   const float* gelu_grad;   // optional [M][N] (ld = N): C = result * gelu'(gelu_grad[m][n])  (backward through the GELU)
   const float* r1_c;        // optional rank-1 correction (spectral-norm weight gradient):
   const float* r1_u;        //   C -= (sum of r1_c[0..r1_nc)) * alpha_dev[0] * r1_u[m] * r1_v[n]
@@ -47,43 +47,58 @@ __device__ __forceinline__ float gelu_df(float x) {
 }
 
 
-// P[x*sx + k*sk] for x in [x0, x0+64), k in [k0, k0+32) -> 8 registers per thread
+// P[x*sx + k*sk] for x in [x0, x0+64), k in [k0, k0+32) -> 8 registers per thread.
+// No load sits under a per-lane condition (hipcc would branch around each one and wait for it: 8 dependent L2
+// round trips per tile): interior tiles (a workgroup-uniform test) use unconditional 16-byte loads, edge tiles
+// load from clamped, always-valid addresses and zero the out-of-range values afterwards.
+template <int mode>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, long sx, long sk, int X, int K, int x0, int k0,
-                                          int mode, int tid, float (&r)[8]) {
-  if (mode == MODE_XFAST) {
+                                          int tid, float (&r)[8]) {
+  const bool interior = x0 + 64 <= X && k0 + 32 <= K;
+  if (mode == MODE_XFAST && interior) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int e = tid + p * 256, x = x0 + (e & 15) * 4, k = k0 + (e >> 4);
-      if (k < K && x + 3 < X) {
-        const float4 v = *(const float4*)(P + x + (long)k * sk);
-        r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) r[p * 4 + q] = (k < K && x + q < X) ? P[x + q + (long)k * sk] : 0.f;
-      }
+      const float4 v = *(const float4*)(P + x + (long)k * sk);
+      r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
     }
-  } else if (mode == MODE_KFAST) {
+  } else if (mode == MODE_KFAST && interior) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int e = tid + p * 256, x = x0 + (e & 63), k = k0 + (e >> 6) * 4;
-      if (x < X && k + 3 < K) {
-        const float4 v = *(const float4*)(P + (long)x * sx + k);
-        r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) r[p * 4 + q] = (x < X && k + q < K) ? P[(long)x * sx + k + q] : 0.f;
-      }
+      const float4 v = *(const float4*)(P + (long)x * sx + k);
+      r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
     }
   } else {
+    // element (p, q) of this thread, in the register order tile_store expects for `mode`
+    float v[8];
+    bool ok[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int e = tid + p * 256, x = x0 + (e & 63), k = k0 + (e >> 6);
-      r[p] = (x < X && k < K) ? P[(long)x * sx + (long)k * sk] : 0.f;
+    for (int i = 0; i < 8; ++i) {
+      int x, k;
+      if (mode == MODE_XFAST) {
+        const int e = tid + (i >> 2) * 256;
+        x = x0 + (e & 15) * 4 + (i & 3);
+        k = k0 + (e >> 4);
+      } else if (mode == MODE_KFAST) {
+        const int e = tid + (i >> 2) * 256;
+        x = x0 + (e & 63);
+        k = k0 + (e >> 6) * 4 + (i & 3);
+      } else {
+        const int e = tid + i * 256;
+        x = x0 + (e & 63);
+        k = k0 + (e >> 6);
+      }
+      ok[i] = x < X && k < K;
+      v[i] = P[(long)min(x, X - 1) * sx + (long)min(k, K - 1) * sk];
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = ok[i] ? v[i] : 0.f;
   }
 }
 
-__device__ __forceinline__ void tile_store(float* __restrict__ S, int mode, int tid, const float (&r)[8]) {
+template <int mode>
+__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const float (&r)[8]) {
   if (mode == MODE_XFAST) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -106,6 +121,8 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, int mode, int 
   }
 }
 
+// MA / MB: load pattern of the A / B operand (compile time: each instantiation is straight-line staging code)
+template <int MA, int MB>
 __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][TK * LS];      // [buffer][A|B][k][x]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
@@ -125,22 +142,14 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
   const int nk = (g.K + TK - 1) / TK;
   auto fetch = [&](int kt, float (&ra)[8], float (&rb)[8]) {
     if (kt < nk) {
-      tile_load(A, g.sam, g.sak, g.M, g.K, m0, kt * TK, g.modeA, tid, ra);
-      tile_load(B, g.sbn, g.sbk, g.N, g.K, n0, kt * TK, g.modeB, tid, rb);
+      tile_load<MA>(A, g.sam, g.sak, g.M, g.K, m0, kt * TK, tid, ra);
+      tile_load<MB>(B, g.sbn, g.sbk, g.N, g.K, n0, kt * TK, tid, rb);
     }
   };
   auto stash = [&](int kt, float (&ra)[8], float (&rb)[8]) {      // registers -> LDS buffer kt & 1
     if (kt < nk) {
-      if (g.gelu_a) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ra[i] = gelu_f(ra[i]);        // gelu(0) = 0: zero padding stays zero
-      }
-      if (g.gelu_b) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rb[i] = gelu_f(rb[i]);
-      }
-      tile_store(lds[kt & 1][0], g.modeA, tid, ra);
-      tile_store(lds[kt & 1][1], g.modeB, tid, rb);
+      tile_store<MA>(lds[kt & 1][0], tid, ra);
+      tile_store<MB>(lds[kt & 1][1], tid, rb);
     }
   };
   auto multiply = [&](int kt) {
@@ -195,8 +204,18 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
         float* dst = C + (long)m * g.ldc + n;
         if (g.accumulate) v += *dst;
         *dst = v;
+        if (g.gelu_out) g.gelu_out[(long)m * g.N + n] = gelu_f(v);
       }
   }
+}
+
+void launch_linear(const LinArgs& g, dim3 grid, hipStream_t st) {
+#define PV_LIN_CASE(a, b) \
+  if (g.modeA == a && g.modeB == b) { hipLaunchKernelGGL((linear_f32_kernel<a, b>), grid, dim3(256), 0, st, g); return; }
+  PV_LIN_CASE(0, 0) PV_LIN_CASE(0, 1) PV_LIN_CASE(0, 2)
+  PV_LIN_CASE(1, 0) PV_LIN_CASE(1, 1) PV_LIN_CASE(1, 2)
+  PV_LIN_CASE(2, 0) PV_LIN_CASE(2, 1) PV_LIN_CASE(2, 2)
+#undef PV_LIN_CASE
 }
 
 // which 16-byte load pattern an operand P[x*sx + k*sk] admits
@@ -216,24 +235,25 @@ int pv_linear_f32(const float* A, long sam, long sak, const float* B, long sbk, 
                   int batch, long bsa, long bsb, long bsc, void* stream) {
   PV_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && ldc >= N, "pv_linear_f32: bad argument");
   LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, bsa, bsb, bsc, alpha, alpha_dev, accumulate,
-            pick_mode(A, sam, sak, bsa, batch), pick_mode(B, sbn, sbk, bsb, batch), 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
-  hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv(N, TN), cdiv(M, TM), batch), dim3(256), 0, (hipStream_t)stream, g);
+            pick_mode(A, sam, sak, bsa, batch), pick_mode(B, sbn, sbk, bsb, batch), nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  launch_linear(g, dim3(cdiv(N, TN), cdiv(M, TM), batch), (hipStream_t)stream);
   PV_LAUNCH_CHECK("linear_f32_kernel");
   return PV_OK;
 }
 
-// The same GEMM with the Block fusions (dialog_models.py:258-269): gelu_a / gelu_b != 0 apply GELU to A / B while staged
-// (y = c(gelu(x)) in one launch); gelu_grad multiplies the result by gelu'(gelu_grad[m][n]) (backward through that
-// GELU); r1_* subtract the spectral-norm rank-1 term from a weight gradient (see pv_spectral_norm_reduce).
+// The same GEMM with the Block fusions (dialog_models.py:258-269): gelu_out also receives gelu(C) (the activation the
+// next linear consumes, computed once per element here instead of once per consuming tile); gelu_grad multiplies the
+// result by gelu'(gelu_grad[m][n]) (backward through that GELU); r1_* subtract the spectral-norm rank-1 term from a
+// weight gradient (see pv_spectral_norm_reduce).
 int pv_linear_f32_fused(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias,
                         float* C, long ldc, int M, int N, int K, float alpha, const float* alpha_dev, int accumulate,
-                        int gelu_a, int gelu_b, const float* gelu_grad, const float* r1_c, int r1_nc, const float* r1_u,
+                        float* gelu_out, const float* gelu_grad, const float* r1_c, int r1_nc, const float* r1_u,
                         const float* r1_v, void* stream) {
   PV_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, "pv_linear_f32_fused: bad argument");
   PV_REQUIRE(!r1_c || (r1_u && r1_v && r1_nc > 0), "pv_linear_f32_fused: rank-1 term needs c, u and v");
   LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, 0, 0, 0, alpha, alpha_dev, accumulate,
-            pick_mode(A, sam, sak, 0, 1), pick_mode(B, sbn, sbk, 0, 1), gelu_a, gelu_b, gelu_grad, r1_c, r1_u, r1_v, r1_nc};
-  hipLaunchKernelGGL(linear_f32_kernel, dim3(cdiv(N, TN), cdiv(M, TM), 1), dim3(256), 0, (hipStream_t)stream, g);
+            pick_mode(A, sam, sak, 0, 1), pick_mode(B, sbn, sbk, 0, 1), gelu_out, gelu_grad, r1_c, r1_u, r1_v, r1_nc};
+  launch_linear(g, dim3(cdiv(N, TN), cdiv(M, TM), 1), (hipStream_t)stream);
   PV_LAUNCH_CHECK("linear_f32_kernel");
   return PV_OK;
 }

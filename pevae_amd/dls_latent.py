@@ -30,11 +30,13 @@ class SNLinear(nn.Module):
 
         self._inv_sigma_pre = None      # set by ops.spectral_prepass for exactly one forward
 
-    def forward(self, x, gelu_in=False):
-        """(gelu(x) if gelu_in else x) @ (W / sigma)^T + b."""
+    def forward(self, x, x_act=None, emit_gelu=False):
+        """y = (x_act if given else x) @ (W / sigma)^T + b.  x_act = gelu(x) written by the producer of x; the gradient
+        flows to x through gelu'.  emit_gelu: return (y, gelu(y)) so that the next linear gets its activation for free."""
         pre, self._inv_sigma_pre = self._inv_sigma_pre, None
-        return ops.sn_linear(x, self.weight_orig, self.bias, self.weight_u, self.weight_v, self.training, self.eps,
-                             gelu_in=gelu_in, inv_sigma=pre)
+        y, gy = ops.sn_linear(x, self.weight_orig, self.bias, self.weight_u, self.weight_v, self.training, self.eps,
+                              x_act=x_act, emit_gelu=emit_gelu, inv_sigma=pre)
+        return (y, gy) if emit_gelu else y
 
 
 class Block(nn.Module):
@@ -48,13 +50,18 @@ class Block(nn.Module):
         self.layer_norm = nn.LayerNorm(input_dim)
         self.translate = SNLinear(input_dim, output_dim)
 
-    def forward(self, x):
-        y = self.c1(x, gelu_in=True)            # the GELUs are fused into the staging of each linear's input
-        y = self.c2(y, gelu_in=True)
-        y = self.c3(y, gelu_in=True)
-        y = self.c4(y, gelu_in=True)
+    def forward(self, x, x_act=None, emit_gelu=False):
+        """x_act: gelu(x) if the producer of x already wrote it (else one standalone GELU launch); emit_gelu: also
+        return gelu(output) for a following Block.  Each GELU is computed once, in the epilogue of the linear that
+        produces its argument."""
+        if x_act is None:
+            x_act = ops.gelu(x).detach()          # data for the GEMM; the gradient reaches x through c1's gelu' epilogue
+        y, g = self.c1(x, x_act, emit_gelu=True)
+        y, g = self.c2(y, g, emit_gelu=True)
+        y, g = self.c3(y, g, emit_gelu=True)
+        y = self.c4(y, g)
         out = ops.add_layer_norm(x, y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
-        return self.translate(out)
+        return self.translate(out, emit_gelu=emit_gelu)
 
 
 class _Pyramid(nn.Module):
@@ -70,10 +77,11 @@ class _Pyramid(nn.Module):
     def forward(self, output):
         if output.dim() == 3:
             output = output[:, 0]            # the reference takes the [CLS] row (:1846, :1864)
-        acts = []
+        acts, g = [], None
         for layer in self.layers:
             acts.append(output)
-            output = layer(output)
+            blk = layer[0] if isinstance(layer, nn.Sequential) else layer
+            output, g = blk(output, g, emit_gelu=True)       # each Block hands gelu(output) to the next one
         return output, acts
 
 

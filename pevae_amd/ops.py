@@ -824,25 +824,29 @@ def add_layer_norm(x, res, gamma, beta, eps=1e-5):
     return AddLayerNorm.apply(x, res, gamma, beta, eps)
 
 
-def _lin_fused(A, sam, sak, Bm, sbk, sbn, bias, Cm, ldc, M, N, K, alpha_dev=None, accumulate=0, gelu_a=0, gelu_b=0,
+def _lin_fused(A, sam, sak, Bm, sbk, sbn, bias, Cm, ldc, M, N, K, alpha_dev=None, accumulate=0, gelu_out=None,
                gelu_grad=None, r1_c=None, r1_u=None, r1_v=None):
     _lib.call("pv_linear_f32_fused", _p(A), sam, sak, _p(Bm), sbk, sbn, _p(bias), _p(Cm), ldc, M, N, K, 1.0,
-              _p(alpha_dev), accumulate, gelu_a, gelu_b, _p(gelu_grad), _p(r1_c), 0 if r1_c is None else r1_c.numel(),
+              _p(alpha_dev), accumulate, _p(gelu_out), _p(gelu_grad), _p(r1_c), 0 if r1_c is None else r1_c.numel(),
               _p(r1_u), _p(r1_v), _stream())
 
 
 class SNLinearFn(torch.autograd.Function):
-    """y = act(x) (W / sigma)^T + b, act = GELU or identity, sigma = u . (W v) from torch.nn.utils.spectral_norm's power
-    iteration (one per TRAINING forward; u / v are constants for autograd).  `inv_sigma_pre` carries 1/sigma when the
-    model-wide multi-tensor pre-pass (spectral_prepass) has already advanced u / v for this step.  Backward is three
-    launches: one pass over dy (bias gradient + <dL/dW_eff, W_eff>), dx with the GELU derivative in the epilogue, and
-    dW with the rank-1 spectral term in the epilogue, accumulated straight into an existing .grad."""
+    """y = a (W / sigma)^T + b with sigma = u . (W v) from torch.nn.utils.spectral_norm's power iteration (one per
+    TRAINING forward; u / v are constants for autograd).  The GEMM input `a` is either x itself or, for the Block's
+    c(gelu(x)) pattern, x_act = gelu(x) that the PRODUCER of x already wrote from its epilogue (`emit_gelu`): every
+    GELU is evaluated once per element, and the gradient returned for x is (dy W / sigma) * gelu'(x), applied in the
+    dx GEMM's epilogue.  `inv_sigma_pre` carries 1/sigma when the model-wide multi-tensor pre-pass (spectral_prepass)
+    has already advanced u / v for this step.  Backward is three launches: one pass over dy (bias gradient +
+    <dL/dW_eff, W_eff>), dx, and dW with the rank-1 spectral term in its epilogue, accumulated straight into an existing
+    .grad."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, u, v, do_iter, eps, gelu_in, inv_sigma_pre):
-        _need_cuda(x, weight, bias, u, v)
+    def forward(ctx, x, x_act, weight, bias, u, v, do_iter, eps, emit_gelu, inv_sigma_pre):
+        _need_cuda(x, x_act, weight, bias, u, v)
         N, K = weight.shape
         x2 = x.reshape(-1, K).contiguous()
+        a2 = x2 if x_act is None else x_act.reshape(-1, K).contiguous()
         M = x2.shape[0]
         w = weight.contiguous()
         if inv_sigma_pre is None:
@@ -852,26 +856,32 @@ class SNLinearFn(torch.autograd.Function):
         else:
             inv_sigma = inv_sigma_pre            # u / v advance once per step, before any forward of that step
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gy = torch.empty((M, N), dtype=torch.float32, device=x.device) if emit_gelu else None
         bc = None if bias is None else bias.contiguous()
-        _lin_fused(x2, K, 1, w, 1, K, bc, y, N, M, N, K, alpha_dev=inv_sigma, gelu_a=1 if gelu_in else 0)
-        ctx.save_for_backward(x2, w, y, bc if bc is not None else inv_sigma, inv_sigma, u, v)
+        _lin_fused(a2, K, 1, w, 1, K, bc, y, N, M, N, K, alpha_dev=inv_sigma, gelu_out=gy)
+        ctx.save_for_backward(x2, a2, w, y, bc if bc is not None else inv_sigma, inv_sigma, u, v)
         ctx.has_bias = bias is not None
-        ctx.gelu_in = gelu_in
+        ctx.act_in = x_act is not None
         ctx.params = (weight, bias)
         ctx.xshape = x.shape
-        return y.view(tuple(x.shape[:-1]) + (N,))
+        oshape = tuple(x.shape[:-1]) + (N,)
+        if emit_gelu:
+            gy = gy.view(oshape)
+            ctx.mark_non_differentiable(gy)
+            return y.view(oshape), gy
+        return y.view(oshape), None
 
     @staticmethod
-    def backward(ctx, dy):
-        x2, w, y, bc, inv_sigma, u, v = ctx.saved_tensors
+    def backward(ctx, dy, _dgy):
+        x2, a2, w, y, bc, inv_sigma, u, v = ctx.saved_tensors
         M, K = x2.shape
         N = w.shape[0]
         dev = x2.device
         dy2 = dy.reshape(M, N).contiguous()
         p_w, p_b = ctx.params
         dx = dw = db = None
-        want_w = ctx.needs_input_grad[1]
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        want_w = ctx.needs_input_grad[2]
+        want_b = ctx.has_bias and ctx.needs_input_grad[3]
         cpart = torch.empty((N + 63) // 64, dtype=torch.float32, device=dev)
         sink_b = grad_sink(p_b, (N,)) if want_b else None
         if want_b and sink_b is None:
@@ -882,20 +892,21 @@ class SNLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             _lin_fused(dy2, N, 1, w, K, 1, None, dx, K, M, K, N, alpha_dev=inv_sigma,
-                       gelu_grad=x2 if ctx.gelu_in else None)                     # dx = (dy W / sigma) * act'(x)
+                       gelu_grad=x2 if ctx.act_in else None)                      # dx = (dy W / sigma) * act'(x)
             dx = dx.view(ctx.xshape)
         if want_w:
-            # dL/dW_orig = (dy^T act(x) - <dL/dW_eff, W_eff> u v^T) / sigma
+            # dL/dW_orig = (dy^T a - <dL/dW_eff, W_eff> u v^T) / sigma
             sink = grad_sink(p_w, (N, K))
             dw = sink if sink is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
-            _lin_fused(dy2, 1, N, x2, K, 1, None, dw, K, N, K, M, alpha_dev=inv_sigma, accumulate=1 if sink is not None else 0,
-                       gelu_b=1 if ctx.gelu_in else 0, r1_c=cpart, r1_u=u, r1_v=v)
+            _lin_fused(dy2, 1, N, a2, K, 1, None, dw, K, N, K, M, alpha_dev=inv_sigma, accumulate=1 if sink is not None else 0,
+                       r1_c=cpart, r1_u=u, r1_v=v)
             dw = None if sink is not None else dw
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, None, dw, db, None, None, None, None, None, None
 
 
-def sn_linear(x, weight_orig, bias, u, v, training, eps=1e-12, gelu_in=False, inv_sigma=None):
-    return SNLinearFn.apply(x, weight_orig, bias, u, v, bool(training), eps, bool(gelu_in), inv_sigma)
+def sn_linear(x, weight_orig, bias, u, v, training, eps=1e-12, x_act=None, emit_gelu=False, inv_sigma=None):
+    """-> (y, gelu(y) or None)."""
+    return SNLinearFn.apply(x, x_act, weight_orig, bias, u, v, bool(training), eps, bool(emit_gelu), inv_sigma)
 
 
 def spectral_prepass(modules, training, eps=1e-12, cache=None):
