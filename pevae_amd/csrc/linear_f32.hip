@@ -136,9 +136,10 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // Two K-tiles of global loads stay in flight: while tile kt is multiplied out of LDS, tile kt+1 sits in one
-  // register set (already requested a whole iteration ago) and tile kt+2 is being requested into the other.
-  float ra0[8], rb0[8], ra1[8], rb1[8];
+  // FOUR K-tiles of global loads stay in flight (these GEMMs are a handful of dependent memory round trips long, so
+  // latency, not bandwidth, sets their time): tile t lives in register set t % 4 from its request until it is written
+  // to LDS buffer t % 2 one iteration before it is multiplied.
+  float ra0[8], rb0[8], ra1[8], rb1[8], ra2[8], rb2[8], ra3[8], rb3[8];
   const int nk = (g.K + TK - 1) / TK;
   auto fetch = [&](int kt, float (&ra)[8], float (&rb)[8]) {
     if (kt < nk) {
@@ -167,19 +168,30 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
   };
   fetch(0, ra0, rb0);
   fetch(1, ra1, rb1);
+  fetch(2, ra2, rb2);
+  fetch(3, ra3, rb3);
   stash(0, ra0, rb0);
   __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    fetch(kt + 2, ra0, rb0);          // set 0 is free: tile kt already sits in LDS
+  for (int kt = 0; kt < nk; kt += 4) {
+    fetch(kt + 4, ra0, rb0);          // set 0 is free: tile kt already sits in LDS
     multiply(kt);
     stash(kt + 1, ra1, rb1);
     __syncthreads();
-    if (kt + 1 < nk) {
-      fetch(kt + 3, ra1, rb1);
-      multiply(kt + 1);
-      stash(kt + 2, ra0, rb0);
-      __syncthreads();
-    }
+    if (kt + 1 >= nk) break;
+    fetch(kt + 5, ra1, rb1);
+    multiply(kt + 1);
+    stash(kt + 2, ra2, rb2);
+    __syncthreads();
+    if (kt + 2 >= nk) break;
+    fetch(kt + 6, ra2, rb2);
+    multiply(kt + 2);
+    stash(kt + 3, ra3, rb3);
+    __syncthreads();
+    if (kt + 3 >= nk) break;
+    fetch(kt + 7, ra3, rb3);
+    multiply(kt + 3);
+    stash(kt + 4, ra0, rb0);
+    __syncthreads();
   }
   const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
   float r1 = 0.f;

@@ -129,9 +129,13 @@ class DLSAuto(nn.Module):
                 q_in = torch.cat([a1 + a2, last_sample], -1)
                 p_in = torch.cat([a2, last_t if train_branch else last_sample], -1)
             need_q = train_branch or self.training
-            t_mean, t_lv = dis2(p_in).chunk(2, -1)
+            # the three Blocks of a level are independent: run them as parallel branches
+            branches = [lambda: dis2(p_in), lambda: layer(output)] + ([lambda: dis(q_in)] if need_q else [])
+            res = ops.parallel(*branches)
+            t_mean, t_lv = res[0].chunk(2, -1)
+            lay_out = res[1]
             if need_q:
-                mean, lv = dis(q_in).chunk(2, -1)
+                mean, lv = res[2].chunk(2, -1)
             if train_branch:
                 eps = noise[i] if noise is not None else torch.rand_like(lv)
                 z, _ = ops.reparam_kl(mean, lv, None, None, eps, mode=1, want_kl=False)         # :3292 / :3299
@@ -140,7 +144,7 @@ class DLSAuto(nn.Module):
                 _, k1 = ops.reparam_kl(t_mean, t_lv, mean.detach(), lv.detach(), None, mode=1, want_z=False)
                 _, k2 = ops.reparam_kl(t_mean.detach(), t_lv.detach(), mean, lv, None, mode=1, want_z=False)
                 rkl = rkl + ew * ops.mean(k1) + cw * ops.mean(k2) + ops.cons_loss(a1, a2) * cip     # :3305-3307
-                output = layer(output) + last_sample                                               # :3310
+                output = lay_out + last_sample                                                     # :3310
             else:
                 if self.training:
                     eps = noise[i] if noise is not None else torch.rand_like(t_lv)
@@ -150,5 +154,5 @@ class DLSAuto(nn.Module):
                     rkl = rkl + ew * ops.mean(k1)                                                  # :3347
                 else:
                     last_sample = t_mean + a2                                                      # :3350
-                output = torch.nan_to_num(layer(output) + last_sample)                             # :3351
+                output = torch.nan_to_num(lay_out + last_sample)                                   # :3351
         return output, rkl

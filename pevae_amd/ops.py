@@ -56,6 +56,33 @@ class timed(object):
         return False
 
 
+_SIDE_STREAMS = {}
+
+
+def parallel(*fns):
+    """Run independent sub-graphs (callables) on separate HIP streams, forked from and joined back into the current
+    stream.  Captured into a HIP graph they become parallel branches, and autograd replays each branch's backward on
+    the stream its forward ran on: chains of tiny dependent kernels (the two DLS pyramids, the per-level Blocks of
+    DLS_Auto) then overlap instead of leaving most CUs idle.  Outputs must stay referenced by the caller until they
+    have been consumed (they are: autograd saves them)."""
+    if len(fns) == 1:
+        return [fns[0]()]
+    cur = torch.cuda.current_stream()
+    dev = cur.device
+    pool = _SIDE_STREAMS.setdefault(dev, [])
+    while len(pool) < len(fns) - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    outs = [None] * len(fns)
+    for i, fn in enumerate(fns[1:]):
+        pool[i].wait_stream(cur)
+        with torch.cuda.stream(pool[i]):
+            outs[i + 1] = fn()
+    outs[0] = fns[0]()
+    for i in range(len(fns) - 1):
+        cur.wait_stream(pool[i])
+    return outs
+
+
 def workspace(tag, numel, dtype, device, zero=False):
     """Persistent scratch (reused every step, stream-ordered).  Never handed to autograd as saved state."""
     key = (tag, dtype, device)
