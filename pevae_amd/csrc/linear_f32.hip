@@ -18,7 +18,7 @@ namespace {
 // K-tile), so the global latency of these tiny, launch/latency-bound GEMMs overlaps the math.
 // The LDS image is [k][m] (row stride 80 floats: the 4 k-rows of one MFMA fragment land on disjoint banks),
 // filled from 16-byte global loads along whichever direction has unit stride.
-constexpr int TM = 64, TN = 64, TK = 32, LS = 80;
+constexpr int TK = 32;
 constexpr int MODE_SCALAR = 0, MODE_XFAST = 1, MODE_KFAST = 2;
 
 struct LinArgs {
@@ -47,123 +47,135 @@ __device__ __forceinline__ float gelu_df(float x) {
 }
 
 
-// P[x*sx + k*sk] for x in [x0, x0+64), k in [k0, k0+32) -> 8 registers per thread.
-// No load sits under a per-lane condition (hipcc would branch around each one and wait for it: 8 dependent L2
-// round trips per tile): interior tiles (a workgroup-uniform test) use unconditional 16-byte loads, edge tiles
-// load from clamped, always-valid addresses and zero the out-of-range values afterwards.
-template <int mode>
+// P[x*sx + k*sk] for x in [x0, x0+T), k in [k0, k0+32) -> T/8 registers per thread (T = tile edge, 64 or 32).
+// No load sits under a per-lane condition (hipcc would branch around each one and wait for it: dependent L2 round
+// trips per tile): interior tiles (a workgroup-uniform test) use unconditional 16-byte loads, edge tiles load from
+// clamped, always-valid addresses and zero the out-of-range values afterwards.
+template <int mode, int T>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, long sx, long sk, int X, int K, int x0, int k0,
-                                          int tid, float (&r)[8]) {
-  const bool interior = x0 + 64 <= X && k0 + 32 <= K;
+                                          int tid, float (&r)[T / 8]) {
+  constexpr int NR = T / 8;
+  const bool interior = x0 + T <= X && k0 + TK <= K;
   if (mode == MODE_XFAST && interior) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int e = tid + p * 256, x = x0 + (e & 15) * 4, k = k0 + (e >> 4);
+    for (int p = 0; p < NR / 4; ++p) {
+      const int e = tid + p * 256, x = x0 + (e % (T / 4)) * 4, k = k0 + e / (T / 4);
       const float4 v = *(const float4*)(P + x + (long)k * sk);
       r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
     }
   } else if (mode == MODE_KFAST && interior) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int e = tid + p * 256, x = x0 + (e & 63), k = k0 + (e >> 6) * 4;
+    for (int p = 0; p < NR / 4; ++p) {
+      const int e = tid + p * 256, x = x0 + e % T, k = k0 + (e / T) * 4;
       const float4 v = *(const float4*)(P + (long)x * sx + k);
       r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
     }
   } else {
-    // element (p, q) of this thread, in the register order tile_store expects for `mode`
-    float v[8];
-    bool ok[8];
+    // element i of this thread, in the register order tile_store expects for `mode`
+    float v[NR];
+    bool ok[NR];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NR; ++i) {
       int x, k;
       if (mode == MODE_XFAST) {
         const int e = tid + (i >> 2) * 256;
-        x = x0 + (e & 15) * 4 + (i & 3);
-        k = k0 + (e >> 4);
+        x = x0 + (e % (T / 4)) * 4 + (i & 3);
+        k = k0 + e / (T / 4);
       } else if (mode == MODE_KFAST) {
         const int e = tid + (i >> 2) * 256;
-        x = x0 + (e & 63);
-        k = k0 + (e >> 6) * 4 + (i & 3);
+        x = x0 + e % T;
+        k = k0 + (e / T) * 4 + (i & 3);
       } else {
         const int e = tid + i * 256;
-        x = x0 + (e & 63);
-        k = k0 + (e >> 6);
+        x = x0 + e % T;
+        k = k0 + e / T;
       }
       ok[i] = x < X && k < K;
       v[i] = P[(long)min(x, X - 1) * sx + (long)min(k, K - 1) * sk];
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = ok[i] ? v[i] : 0.f;
+    for (int i = 0; i < NR; ++i) r[i] = ok[i] ? v[i] : 0.f;
   }
 }
 
-template <int mode>
-__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const float (&r)[8]) {
+template <int mode, int T>
+__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const float (&r)[T / 8]) {
+  constexpr int NR = T / 8, LS = T + 16;
   if (mode == MODE_XFAST) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NR / 4; ++p) {
       const int e = tid + p * 256;
-      *(float4*)(S + (e >> 4) * LS + (e & 15) * 4) = make_float4(r[p * 4], r[p * 4 + 1], r[p * 4 + 2], r[p * 4 + 3]);
+      *(float4*)(S + (e / (T / 4)) * LS + (e % (T / 4)) * 4) = make_float4(r[p * 4], r[p * 4 + 1], r[p * 4 + 2], r[p * 4 + 3]);
     }
   } else if (mode == MODE_KFAST) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NR / 4; ++p) {
       const int e = tid + p * 256;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) S[((e >> 6) * 4 + q) * LS + (e & 63)] = r[p * 4 + q];
+      for (int q = 0; q < 4; ++q) S[((e / T) * 4 + q) * LS + e % T] = r[p * 4 + q];
     }
   } else {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < NR; ++p) {
       const int e = tid + p * 256;
-      S[(e >> 6) * LS + (e & 63)] = r[p];
+      S[(e / T) * LS + e % T] = r[p];
     }
   }
 }
 
-// MA / MB: load pattern of the A / B operand (compile time: each instantiation is straight-line staging code)
-template <int MA, int MB>
+// MA / MB: load pattern of the A / B operand (compile time: each instantiation is straight-line staging code).
+// T: tile edge.  T x T outputs per 256-thread workgroup, 4 waves as 2x2, each wave (T/2)x(T/2) in 16x16
+// v_mfma_f32_16x16x4_f32 accumulators (exact fp32 FMA chain in k order).  The f32 MFMA runs at 1/16 of the bf16 rate,
+// so these batch-256 GEMMs are bound by how many CUs they occupy: T = 32 quadruples the workgroup count and is used
+// whenever 64x64 tiles would leave most of the chip idle.
+template <int MA, int MB, int T>
 __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
+  constexpr int LS = T + 16, NR = T / 8, NF = T / 32;       // NF x NF 16x16 tiles per wave
   __shared__ __attribute__((aligned(16))) float lds[2][2][TK * LS];      // [buffer][A|B][k][x]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
   const int i16 = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
   const float* A = g.A + (long)blockIdx.z * g.bsa;
   const float* B = g.B + (long)blockIdx.z * g.bsb;
   float* C = g.C + (long)blockIdx.z * g.bsc;
-  f32x4 acc[2][2];
+  f32x4 acc[NF][NF];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NF; ++t)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NF; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
   // FOUR K-tiles of global loads stay in flight (these GEMMs are a handful of dependent memory round trips long, so
   // latency, not bandwidth, sets their time): tile t lives in register set t % 4 from its request until it is written
   // to LDS buffer t % 2 one iteration before it is multiplied.
-  float ra0[8], rb0[8], ra1[8], rb1[8], ra2[8], rb2[8], ra3[8], rb3[8];
+  float ra0[NR], rb0[NR], ra1[NR], rb1[NR], ra2[NR], rb2[NR], ra3[NR], rb3[NR];
   const int nk = (g.K + TK - 1) / TK;
-  auto fetch = [&](int kt, float (&ra)[8], float (&rb)[8]) {
+  auto fetch = [&](int kt, float (&ra)[NR], float (&rb)[NR]) {
     if (kt < nk) {
-      tile_load<MA>(A, g.sam, g.sak, g.M, g.K, m0, kt * TK, tid, ra);
-      tile_load<MB>(B, g.sbn, g.sbk, g.N, g.K, n0, kt * TK, tid, rb);
+      tile_load<MA, T>(A, g.sam, g.sak, g.M, g.K, m0, kt * TK, tid, ra);
+      tile_load<MB, T>(B, g.sbn, g.sbk, g.N, g.K, n0, kt * TK, tid, rb);
     }
   };
-  auto stash = [&](int kt, float (&ra)[8], float (&rb)[8]) {      // registers -> LDS buffer kt & 1
+  auto stash = [&](int kt, float (&ra)[NR], float (&rb)[NR]) {      // registers -> LDS buffer kt & 1
     if (kt < nk) {
-      tile_store<MA>(lds[kt & 1][0], tid, ra);
-      tile_store<MB>(lds[kt & 1][1], tid, rb);
+      tile_store<MA, T>(lds[kt & 1][0], tid, ra);
+      tile_store<MB, T>(lds[kt & 1][1], tid, rb);
     }
   };
   auto multiply = [&](int kt) {
-    const float* As = lds[kt & 1][0] + wm * 32 + i16;
-    const float* Bs = lds[kt & 1][1] + wn * 32 + i16;
+    const float* As = lds[kt & 1][0] + wm * (T / 2) + i16;
+    const float* Bs = lds[kt & 1][1] + wn * (T / 2) + i16;
 #pragma unroll
     for (int ks = 0; ks < TK / 4; ++ks) {
       const int kr = (ks * 4 + kq) * LS;
-      const float a0 = As[kr], a1 = As[kr + 16], b0 = Bs[kr], b1 = Bs[kr + 16];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[NF], b[NF];
+#pragma unroll
+      for (int t = 0; t < NF; ++t) {
+        a[t] = As[kr + 16 * t];
+        b[t] = Bs[kr + 16 * t];
+      }
+#pragma unroll
+      for (int t = 0; t < NF; ++t)
+#pragma unroll
+        for (int u = 0; u < NF; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
     }
   };
   fetch(0, ra0, rb0);
@@ -200,15 +212,15 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
     r1 *= g.alpha_dev ? g.alpha_dev[0] : 1.f;
   }
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int n = n0 + wn * 32 + u * 16 + i16;
+  for (int u = 0; u < NF; ++u) {
+    const int n = n0 + wn * (T / 2) + u * 16 + i16;
     if (n >= g.N) continue;
     const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NF; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 32 + t * 16 + kq * 4 + r;
+        const int m = m0 + wm * (T / 2) + t * 16 + kq * 4 + r;
         if (m >= g.M) continue;
         float v = alpha * acc[t][u][r] + bv;
         if (g.gelu_grad) v *= gelu_df(g.gelu_grad[(long)m * g.N + n]);
@@ -221,9 +233,17 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
   }
 }
 
-void launch_linear(const LinArgs& g, dim3 grid, hipStream_t st) {
-#define PV_LIN_CASE(a, b) \
-  if (g.modeA == a && g.modeB == b) { hipLaunchKernelGGL((linear_f32_kernel<a, b>), grid, dim3(256), 0, st, g); return; }
+void launch_linear(const LinArgs& g, int batch, hipStream_t st) {
+  // 32x32 tiles when 64x64 tiles would occupy fewer than ~half of the CUs
+  const bool small = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * batch < 128;
+  const int T = small ? 32 : 64;
+  const dim3 grid(cdiv(g.N, T), cdiv(g.M, T), batch);
+#define PV_LIN_CASE(a, b)                                                                           \
+  if (g.modeA == a && g.modeB == b) {                                                               \
+    if (small) hipLaunchKernelGGL((linear_f32_kernel<a, b, 32>), grid, dim3(256), 0, st, g);        \
+    else hipLaunchKernelGGL((linear_f32_kernel<a, b, 64>), grid, dim3(256), 0, st, g);              \
+    return;                                                                                         \
+  }
   PV_LIN_CASE(0, 0) PV_LIN_CASE(0, 1) PV_LIN_CASE(0, 2)
   PV_LIN_CASE(1, 0) PV_LIN_CASE(1, 1) PV_LIN_CASE(1, 2)
   PV_LIN_CASE(2, 0) PV_LIN_CASE(2, 1) PV_LIN_CASE(2, 2)
@@ -248,7 +268,7 @@ int pv_linear_f32(const float* A, long sam, long sak, const float* B, long sbk, 
   PV_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && ldc >= N, "pv_linear_f32: bad argument");
   LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, bsa, bsb, bsc, alpha, alpha_dev, accumulate,
             pick_mode(A, sam, sak, bsa, batch), pick_mode(B, sbn, sbk, bsb, batch), nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-  launch_linear(g, dim3(cdiv(N, TN), cdiv(M, TM), batch), (hipStream_t)stream);
+  launch_linear(g, batch, (hipStream_t)stream);
   PV_LAUNCH_CHECK("linear_f32_kernel");
   return PV_OK;
 }
@@ -265,7 +285,7 @@ int pv_linear_f32_fused(const float* A, long sam, long sak, const float* B, long
   PV_REQUIRE(!r1_c || (r1_u && r1_v && r1_nc > 0), "pv_linear_f32_fused: rank-1 term needs c, u and v");
   LinArgs g{A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, 0, 0, 0, alpha, alpha_dev, accumulate,
             pick_mode(A, sam, sak, 0, 1), pick_mode(B, sbn, sbk, 0, 1), gelu_out, gelu_grad, r1_c, r1_u, r1_v, r1_nc};
-  launch_linear(g, dim3(cdiv(N, TN), cdiv(M, TM), 1), (hipStream_t)stream);
+  launch_linear(g, 1, (hipStream_t)stream);
   PV_LAUNCH_CHECK("linear_f32_kernel");
   return PV_OK;
 }
