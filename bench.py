@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--dropout", type=float, default=0.3)
-    ap.add_argument("--latent", default="gauss", choices=["gauss", "dls"], help="latent stack of the composed step")
+    ap.add_argument("--latent", default="dls", choices=["gauss", "dls"],
+                    help="latent stack: 'dls' = the reference's DLS pyramid (DlsRec/DlsPri/DLS_Auto), 'gauss' = flat")
     ap.add_argument("--attention", type=int, default=0, help="decoder attention over encoder states (configs[2])")
     ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for per-kernel times")
     return ap.parse_args()

@@ -887,6 +887,7 @@ class SNLinearFn(torch.autograd.Function):
         bc = None if bias is None else bias.contiguous()
         _lin_fused(a2, K, 1, w, 1, K, bc, y, N, M, N, K, alpha_dev=inv_sigma, gelu_out=gy)
         ctx.save_for_backward(x2, a2, w, y, bc if bc is not None else inv_sigma, inv_sigma, u, v)
+        ctx.set_materialize_grads(False)      # no zero tensor for the non-differentiable gelu output
         ctx.has_bias = bias is not None
         ctx.act_in = x_act is not None
         ctx.params = (weight, bias)
@@ -901,6 +902,8 @@ class SNLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dgy):
         x2, a2, w, y, bc, inv_sigma, u, v = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 10
         M, K = x2.shape
         N = w.shape[0]
         dev = x2.device
