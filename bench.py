@@ -175,8 +175,14 @@ def main():
         alg_flop = 6.0 * T * H * V                       # fwd + dH + dW; the backward's logit recompute is NOT credited
         vocab_ms = sum(kern_ms[k]["ms_per_step"] for k in ("vocab_fwd", "vocab_bwd_prob", "vocab_dH", "vocab_dW"))
         ach = alg_flop / (vocab_ms * 1e-3) / 1e12
+        traffic = None          # HBM bytes per step of the group, from the committed rocprofv3 --pmc passes (this script
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")     # cannot run the profiler on itself)
+        if os.path.exists(pmc):
+            with open(pmc) as fh:
+                traffic = json.load(fh).get("vocab_group_hbm_bytes_per_step")
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=None,
+                    frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
+                    traffic_source="profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per step)",
                     kernel="gemm_nt_kernel<EpiSoftmax|EpiProb|EpiStore> (vocab projection+softmax+NLL fwd+bwd group)",
                     algorithmic_gflop_per_step=round(alg_flop / 1e9, 1), group_ms_per_step=round(vocab_ms, 4),
                     fwd_kernel_tflops=round(2.0 * T * H * V / (kern_ms["vocab_fwd"]["ms_per_step"] * 1e-3) / 1e12, 2))
