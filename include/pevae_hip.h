@@ -77,13 +77,15 @@ int pv_logsoftmax_bwd_bf16(const float* logp, const float* dlogp, int T, int V, 
  * hall [(L+1)][Bpad][H] fp32 states in processing order (slot 0 = h0) -- slots 1..L ARE the layer output
  * (out[b][t] = hall[t+1][b], or hall[L-t][b] when reverse != 0); gsaveT (optional, training) [L][4][H][Bpad];
  * hn [B][H]; sync: pv_gru_sync_bytes(B) bytes, word NG = error flag (1 = a bounded spin timed out).
- * reverse != 0 walks time backwards (bidirectional encoders).
+ * reverse != 0 walks time backwards (bidirectional encoders).  lengths (optional, int32 [B]): packed-sequence
+ * semantics of encoders.py:55-65 -- row b keeps its state at time steps t >= lengths[b] (the caller zeroes those
+ * output rows).
  * max_wgs <= 0 means "one workgroup per CU of the current device". */
 int pv_gru_geometry(int B, int H, int* Hk, int* K3, int* Bpad, int* NG);   /* host out-params */
 size_t pv_gru_sync_bytes(int B);
-int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0, int L, int B,
-               int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall, float* hn, void* sync, int max_wgs,
-               void* stream);
+int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0,
+               const int* lengths, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall,
+               float* hn, void* sync, int max_wgs, void* stream);
 /* Backward through time.  whhT_bf16 [H][K3] = W_hh^T.  Emits dgi_bf16 / dgh_bf16 [L][Bpad][K3] (gate
  * gradients w.r.t. the input / hidden pre-activations; GEMM operands for dW_ih, dx, dW_hh), dh0 [B][H],
  * db_ih / db_hh [3H].  dbias_part: NG*4*H floats of scratch. */

@@ -113,6 +113,7 @@ struct GruFwdArgs {
   u32* counters;          // [NG] zeroed
   u32* err;
   u32* stamps;            // diagnostic build only
+  const int* lens;        // optional [B]: row b is frozen (state kept, z saved as 1) at time steps t >= lens[b]
   int L, B, H, Hk, Bpad, NG, G, S, reverse, a_lds;
   unsigned hseq_bytes;
   int dbg;                // timing ablation bits (env PV_GRU_DBG; 0 in normal use, results are wrong otherwise)
@@ -308,6 +309,13 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
           zz[j] = fast_sigmoid(xzv[j] + acc[1][j] + bh_z);
           nn[j] = fast_tanh(xnv[j] + rr[j] * hn[j]);
           hv[j] = (rbase + j < a.B) ? nn[j] + zz[j] * (hp[j] - nn[j]) : 0.f;
+          if (a.lens && rbase + j < a.B && t >= a.lens[rbase + j]) {
+            // packed-sequence semantics (encoders.py:55-65): past its length a row keeps its state; saving z = 1 and
+            // zero gates makes the unchanged backward kernel pass dL/dh straight through this step
+            hv[j] = hp[j];
+            zz[j] = 1.f;
+            rr[j] = nn[j] = hn[j] = 0.f;
+          }
           hp[j] = hv[j];
         }
         const int lu = ut * 16 + c16, lr = mt * 16 + q4 * 4;
@@ -666,9 +674,9 @@ size_t pv_gru_sync_bytes(int B) {
 #endif
 }
 
-int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0, int L, int B,
-               int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall, float* hn, void* sync, int max_wgs,
-               void* stream) {
+int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0,
+               const int* lengths, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall,
+               float* hn, void* sync, int max_wgs, void* stream) {
   int Hk, K3, Bpad, NG;
   int rc = pv_gru_geometry(B, H, &Hk, &K3, &Bpad, &NG);
   if (rc) return rc;
@@ -704,7 +712,7 @@ int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float*
   const int a_lds = smem_base + smem_a <= 160 * 1024;       // share the group's h_{t-1} through LDS when it fits
   const size_t smem = smem_base + (a_lds ? smem_a : 0);
   GruFwdArgs a{xprojT, ldx, (const bf16_t*)whh_bf16, bhh, (bf16_t*)hseq_bf16, gsaveT, hn, hall,
-               counters, err, (u32*)sync + 64, L, B, H, Hk, Bpad, NGk, G, S, reverse, a_lds, (unsigned)hseq_bytes, 0};
+               counters, err, (u32*)sync + 64, lengths, L, B, H, Hk, Bpad, NGk, G, S, reverse, a_lds, (unsigned)hseq_bytes, 0};
   if (const char* e = getenv("PV_GRU_DBG")) a.dbg = atoi(e);
 #define PV_GRU_LAUNCH_F(UTv, NKv, MTv)                                                           \
   do {                                                                                           \

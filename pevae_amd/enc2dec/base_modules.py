@@ -35,12 +35,22 @@ class RNNWeights(nn.Module):
         tail = "_l{}{}".format(layer, "_reverse" if direction else "")
         return [getattr(self, n + tail) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
 
-    def forward(self, x, state=None):
-        """x [B,L,in] -> (out [B,L,H*dirs], h_n [layers*dirs,B,H], hseq_bf16 of the last layer or None)."""
+    def forward(self, x, state=None, lengths=None):
+        """x [B,L,in] -> (out [B,L,H*dirs], h_n [layers*dirs,B,H], hseq_bf16 of the last layer or None).
+        lengths (list / tensor [B]): pack_padded_sequence semantics (encoders.py:55-65): a row's state stops at its
+        length, outputs past it are zero and the time axis is cut to max(lengths); unidirectional only."""
         if self.cell != "gru":
             raise NotImplementedError("pevae_amd: only the GRU cell has a HIP kernel (the reference's README "
                                       "configuration, --rnn_cell gru); LSTM parameters load but do not run")
         ndir = 2 if self.bidirectional else 1
+        lens = mask = None
+        if lengths is not None:
+            if self.bidirectional:
+                raise NotImplementedError("pevae_amd: variable_lengths with a bidirectional RNN has no HIP path")
+            lens_l = torch.as_tensor(lengths, dtype=torch.int64)
+            x = x[:, :int(lens_l.max())]
+            lens = lens_l.to(device=x.device, dtype=torch.int32)
+            mask = (torch.arange(x.size(1), device=x.device).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1).to(x.dtype)
         save = torch.is_grad_enabled()
         finals, hseq = [], None
         for layer in range(self.num_layers):
@@ -49,7 +59,9 @@ class RNNWeights(nn.Module):
                 w_ih, w_hh, b_ih, b_hh = self.layer_weights(layer, d)
                 h0 = None if state is None else state[layer * ndir + d]
                 xin = x.flip(1) if d else x
-                out, hn, hs = ops.GRULayer.apply(xin, h0, w_ih, w_hh, b_ih, b_hh, save)
+                out, hn, hs = ops.GRULayer.apply(xin, h0, w_ih, w_hh, b_ih, b_hh, save, lens)
+                if mask is not None:
+                    out, hs = out * mask, None            # zero rows past each length (pad_packed_sequence)
                 outs.append(out.flip(1) if d else out)
                 finals.append(hn)
                 hseq = hs if ndir == 1 else None

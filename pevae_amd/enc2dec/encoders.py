@@ -18,12 +18,11 @@ class EncoderRNN(BaseRNN):
         self.output_size = hidden_size * 2 if bidirection else hidden_size
 
     def forward(self, input_var, input_lengths=None, init_state=None):
-        if self.variable_lengths:
-            # encoders.py:55-58 packs by length; the reference model never enables it
-            # (variable_lengths=False, dialog_models.py:534) and the HIP recurrence runs whole rows.
-            raise NotImplementedError("pevae_amd EncoderRNN: variable_lengths=True has no HIP path")
         embedded = self.input_dropout(input_var)
-        output, hidden, _ = self.rnn(embedded, init_state)
+        # encoders.py:55-65: pack_padded_sequence -> rnn -> pad_packed_sequence; the HIP recurrence freezes each row at
+        # its length instead of packing
+        lengths = input_lengths if self.variable_lengths else None
+        output, hidden, _ = self.rnn(embedded, init_state, lengths)
         return output, hidden
 
 

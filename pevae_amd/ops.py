@@ -335,8 +335,8 @@ class GRULayer(torch.autograd.Function):
     hseq bf16 [(L+1)*Bpad, Hk] = every state in time-major order, reusable as a GEMM operand)."""
 
     @staticmethod
-    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, save):
-        _need_cuda(x, w_ih, w_hh, b_ih, b_hh, h0)
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, save, lengths=None):
+        _need_cuda(x, w_ih, w_hh, b_ih, b_hh, h0, lengths)
         B, L, E = x.shape
         H = w_hh.shape[1]
         dev = x.device
@@ -355,7 +355,7 @@ class GRULayer(torch.autograd.Function):
         sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
         h0c = None if h0 is None else h0.contiguous()
         with timed("gru_fwd"):
-            _lib.call("pv_gru_fwd", _p(xprojT), L * Bpad, _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), L, B, H, 0,
+            _lib.call("pv_gru_fwd", _p(xprojT), L * Bpad, _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), _p(lengths), L, B, H, 0,
                       _p(hseq), _p(gsave), _p(hall), _p(hn), _p(sync), GRU_MAX_WGS, _stream())
         out = hall[1:, :B].transpose(0, 1)          # [B,L,H] view of the fp32 states: no second copy is written
         if save:
@@ -405,7 +405,7 @@ class GRULayer(torch.autograd.Function):
         dghT = transpose_to_bf16(dgh, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
         hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
         dw_hh = gemm_nt_wgrad(dghT, Tp, hpT, Tp, 3 * H, H, Tp, grad_sink(p_hh, (3 * H, H)))
-        return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None
+        return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------

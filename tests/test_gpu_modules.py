@@ -68,6 +68,34 @@ def test_encoder_rnn(dev, tag, kw):
     close(hn0, g["hn_nostate"], rtol=0, atol=3e-2)
 
 
+def test_encoder_varlen(dev):
+    """variable_lengths=True (encoders.py:55-65): golden from the reference's pack_padded path; gradients against the
+    oracle evaluated on the same bf16-rounded MFMA operands."""
+    from pevae_amd.enc2dec.encoders import EncoderRNN
+    from pevae_amd import ops
+    from oracle import ref_modules as R
+    g = load_golden("encoder_gru_varlen")
+    enc = load_params(EncoderRNN(8, 16, variable_lengths=True), g).to(dev)
+    lens = g["lens"].tolist()
+    x = T(g["x"], dev).requires_grad_()
+    out, hn = enc(x, input_lengths=lens)
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(2))
+    ((out * w.to(dev)).sum() + hn.sum()).backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    assert out.shape[1] == max(lens)
+    assert relmax(out, g["out"][:, :max(lens)]) < 3e-2 and relmax(hn, g["hn"]) < 3e-2      # bf16 operands vs fp32 golden
+    for b, n in enumerate(lens):
+        assert float(out[b, n:].abs().max()) == 0.0 if n < out.shape[1] else True          # zero past each length
+    ref = load_params(R.EncoderRNN(8, 16, variable_lengths=True), g)
+    xr = T(g["x"]).requires_grad_()
+    o_r, h_r = ref(xr, input_lengths=lens)
+    ((o_r * w).sum() + h_r.sum()).backward()
+    assert relmax(x.grad, xr.grad) < 5e-2
+    for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert relmax(p.grad, q.grad) < 5e-2, n
+
+
 def test_encoder_errors(dev):
     from pevae_amd.enc2dec.encoders import EncoderRNN
     with pytest.raises(ValueError):
