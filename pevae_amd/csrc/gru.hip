@@ -114,6 +114,8 @@ struct GruFwdArgs {
   u32* err;
   u32* stamps;            // diagnostic build only
   const int* lens;        // optional [B]: row b is frozen (state kept, z saved as 1) at time steps t >= lens[b]
+  float* cstate;          // LSTM only: [B][H] cell state, ends as c_n
+  float* call;            // LSTM only: [(L+1)][Bpad][H] fp32 cell states (slot 0 pre-filled with c0)
   int L, B, H, Hk, Bpad, NG, G, S, reverse, a_lds;
   unsigned hseq_bytes;
   int dbg;                // timing ablation bits (env PV_GRU_DBG; 0 in normal use, results are wrong otherwise)
@@ -133,9 +135,13 @@ constexpr int NT_F = 512, NSTORE = 192;
 
 // MT: 16-row MFMA tiles per batch group (group = 16*MT rows).  MT = 1 halves a group's work so that a workgroup
 // can own TWO groups and process them alternately: the hand-off latency of one hides behind the other's work.
-template <int UT, int NKS_C, int MT>
+// NGT: gates per unit.  3 = GRU (r, z, n; base_modules.py:42 with rnn_cell 'gru'), 4 = LSTM (i, f, g, o; rnn_cell
+// 'lstm'): same tiling, hand-off and staging; the LSTM additionally carries the fp32 cell state c (never
+// exchanged: c of a unit is only ever needed by the wave that owns the unit) and saves i, f, g, o in gsaveT.
+template <int UT, int NKS_C, int MT, int NGT>
 __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
   constexpr int U = UT * 16, RW = MT * 16;
+  constexpr bool LSTM = NGT == 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q4 = lane >> 4;
@@ -145,34 +151,37 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
   const int sid = tid - (NT_F - NSTORE);
   const int g = blockIdx.x / a.S, s = blockIdx.x % a.S, u0 = s * U;
   const int Hk = NKS_C ? NKS_C * 32 : a.Hk, H = a.H, nch = Hk / 8, mask = swz_mask_for(nch), NKS = Hk / 32;
-  char* wl = smem;                                            // [3U][Hk] bf16, swizzled
-  bf16_t* tile = (bf16_t*)(smem + (size_t)3 * U * Hk * 2);    // [RW][U] bf16: h_t of this slice
-  float* sg = (float*)(tile + RW * U);                      // [4][U][RW] fp32: r, z, n, hn (row fastest)
+  char* wl = smem;                                            // [NGT*U][Hk] bf16, swizzled
+  bf16_t* tile = (bf16_t*)(smem + (size_t)NGT * U * Hk * 2);  // [RW][U] bf16: h_t of this slice
+  float* sg = (float*)(tile + RW * U);                      // [4][U][RW] fp32: r, z, n, hn | i, f, g, o (row fastest)
   float* shv = sg + 4 * U * RW;                             // [RW][U] fp32: h_t
-  char* al = (char*)(shv + RW * U);                         // [RW][Hk] bf16, swizzled: h_{t-1} of the group (a_lds)
+  float* scv = shv + RW * U;                                // [RW][U] fp32: c_t (LSTM only)
+  char* al = (char*)(scv + (LSTM ? RW * U : 0));            // [RW][Hk] bf16, swizzled: h_{t-1} of the group (a_lds)
 
-  for (int i = tid; i < 3 * U * nch; i += NT_F) {             // resident weight slice
+  for (int i = tid; i < NGT * U * nch; i += NT_F) {           // resident weight slice
     const int n = i / nch, ch = i % nch, gate = n / U, u = n % U;
     const uint4 v = *(const uint4*)(a.whh + (size_t)(gate * H + u0 + u) * Hk + ch * 8);
     *(uint4*)(wl + (size_t)n * Hk * 2 + ((ch ^ (n & mask)) * 16)) = v;
   }
   const int utc = active ? ut : 0;
   const int unit = u0 + utc * 16 + c16;
-  const float bh_r = a.bhh[unit], bh_z = a.bhh[H + unit], bh_n = a.bhh[2 * H + unit];
+  float bh[NGT];
+#pragma unroll
+  for (int gt = 0; gt < NGT; ++gt) bh[gt] = a.bhh[gt * H + unit];
   // LDS fragment offsets: 16-byte chunk c of row n sits at chunk (c ^ (n & mask)); with c = ks*4 + q4 the XOR only
   // touches the low 4 bits, so offset = row base + (ks>>2)*256 + off[ks&3]  (immediates in the unrolled loop)
   const int m16 = c16 & mask;
-  int boff[3][4], aoff[4];
+  int boff[NGT][4], aoff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int sw = ((j * 4 + q4) ^ m16) * 16;
 #pragma unroll
-    for (int gt = 0; gt < 3; ++gt) boff[gt][j] = (gt * U + utc * 16 + c16) * Hk * 2 + sw;
+    for (int gt = 0; gt < NGT; ++gt) boff[gt][j] = (gt * U + utc * 16 + c16) * Hk * 2 + sw;
     aoff[j] = (mt * 16 + c16) * Hk * 2 + sw;
   }
   const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hseq, 0, a.hseq_bytes, 0x00020000);
   const bool single = a.NG <= a.G;                            // one row group per workgroup: state stays in registers
-  float hp[4] = {0.f, 0.f, 0.f, 0.f};
+  float hp[4] = {0.f, 0.f, 0.f, 0.f}, cp[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 #ifdef PV_GRU_STAMPS
   unsigned stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -184,17 +193,22 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
     for (int rg = g; rg < a.NG; rg += a.G) {
       const int row0 = rg * RW, rbase = row0 + mt * 16 + q4 * 4;
       // (a) independent of h_{t-1}: this lane's input projections, 4 batch rows per 16-byte load
-      float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), xz = xr, xn = xr;
+      f32x4 xg[NGT];
+#pragma unroll
+      for (int gt = 0; gt < NGT; ++gt) xg[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (active && !(a.dbg & 64)) {
         const float* xp = a.xprojT + (size_t)unit * a.ldx + (size_t)t * a.Bpad + rbase;
-        xr = *(const float4*)xp;
-        xz = *(const float4*)(xp + (size_t)H * a.ldx);
-        xn = *(const float4*)(xp + (size_t)2 * H * a.ldx);
+#pragma unroll
+        for (int gt = 0; gt < NGT; ++gt) xg[gt] = *(const f32x4*)(xp + (size_t)gt * H * a.ldx);
         if (step == 0 || !single) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < 4; ++j) {
             hp[j] = single ? a.hall[((size_t)rbase + j) * H + unit]
                            : (rbase + j < a.B ? a.hstate[(size_t)(rbase + j) * H + unit] : 0.f);
+            if constexpr (LSTM)
+              cp[j] = single ? a.call[((size_t)rbase + j) * H + unit]
+                             : (rbase + j < a.B ? a.cstate[(size_t)(rbase + j) * H + unit] : 0.f);
+          }
         }
       }
       STAMP(0);
@@ -204,9 +218,9 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
       __syncthreads();
       STAMP(2);
       // (c) three gate tiles over the full K
-      f32x4 acc[3];
+      f32x4 acc[NGT];
 #pragma unroll
-      for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int gt = 0; gt < NGT; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (a.a_lds) {
         // the group's h_{t-1} (RW x Hk bf16) is fetched ONCE per workgroup with sc1 loads and shared through LDS
         if (compute && !(a.dbg & 2)) {
@@ -235,12 +249,12 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
             // fragments of 2 k-steps per chunk, read one chunk ahead of the MFMAs that consume them
             constexpr int NC = NKS_C / 2;
             static_assert(NKS_C % 4 == 0, "compile-time k-step count must be a multiple of 4");
-            bf16x8 fa[2][2], fb[2][3][2];
+            bf16x8 fa[2][2], fb[2][NGT][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               fa[0][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(al + aoff[j]));
 #pragma unroll
-              for (int gt = 0; gt < 3; ++gt) fb[0][gt][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[gt][j]));
+              for (int gt = 0; gt < NGT; ++gt) fb[0][gt][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[gt][j]));
             }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
                   const int ks = (c + 1) * 2 + j, o = (ks >> 2) * 256;
                   fa[nxt][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(al + aoff[ks & 3] + o));
 #pragma unroll
-                  for (int gt = 0; gt < 3; ++gt)
+                  for (int gt = 0; gt < NGT; ++gt)
                     fb[nxt][gt][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[gt][ks & 3] + o));
                 }
               }
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
 #pragma unroll
               for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int gt = 0; gt < 3; ++gt)
+                for (int gt = 0; gt < NGT; ++gt)
                   acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][j], fb[cur][gt][j], acc[gt], 0, 0, 0);
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
               const int o = (ks >> 2) * 256;
               const bf16x8 av = __builtin_bit_cast(bf16x8, *(const uint4*)(al + aoff[ks & 3] + o));
 #pragma unroll
-              for (int gt = 0; gt < 3; ++gt) {
+              for (int gt = 0; gt < NGT; ++gt) {
                 const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[gt][ks & 3] + o));
                 acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b, acc[gt], 0, 0, 0);
               }
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
             if (ks0 + kk < NKS) {
               const int o = ks0 * 64 + (kk >> 2) * 256;
 #pragma unroll
-              for (int gt = 0; gt < 3; ++gt) {
+              for (int gt = 0; gt < NGT; ++gt) {
                 const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[gt][kk & 3] + o));
                 acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[kk]), b, acc[gt], 0, 0, 0);
               }
@@ -298,16 +312,28 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
       }
       STAMP(4);
       // (d) gate math on the accumulator layout: lane (c16, q4) holds rows rbase..rbase+3 of unit `unit`
-      float hv[4];
+      float hv[4], cv[4] = {0.f, 0.f, 0.f, 0.f};
       if (active) {
-        const float xrv[4] = {xr.x, xr.y, xr.z, xr.w}, xzv[4] = {xz.x, xz.y, xz.z, xz.w}, xnv[4] = {xn.x, xn.y, xn.z, xn.w};
+        // rr, zz, nn, hn: the four saved per-step quantities (GRU r, z, n, W_hn h + b_hn | LSTM i, f, g, o)
         float rr[4], zz[4], nn[4], hn[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          hn[j] = acc[2][j] + bh_n;
-          rr[j] = fast_sigmoid(xrv[j] + acc[0][j] + bh_r);
-          zz[j] = fast_sigmoid(xzv[j] + acc[1][j] + bh_z);
-          nn[j] = fast_tanh(xnv[j] + rr[j] * hn[j]);
+          if constexpr (LSTM) {
+            rr[j] = fast_sigmoid(xg[0][j] + acc[0][j] + bh[0]);       // input gate
+            zz[j] = fast_sigmoid(xg[1][j] + acc[1][j] + bh[1]);       // forget gate
+            nn[j] = fast_tanh(xg[2][j] + acc[2][j] + bh[2]);          // cell candidate
+            hn[j] = fast_sigmoid(xg[NGT - 1][j] + acc[NGT - 1][j] + bh[NGT - 1]);   // output gate
+            const bool live = rbase + j < a.B;
+            cv[j] = live ? zz[j] * cp[j] + rr[j] * nn[j] : 0.f;
+            hv[j] = live ? hn[j] * fast_tanh(cv[j]) : 0.f;
+            cp[j] = cv[j];
+            hp[j] = hv[j];
+            continue;
+          }
+          hn[j] = acc[2][j] + bh[2];
+          rr[j] = fast_sigmoid(xg[0][j] + acc[0][j] + bh[0]);
+          zz[j] = fast_sigmoid(xg[1][j] + acc[1][j] + bh[1]);
+          nn[j] = fast_tanh(xg[2][j] + rr[j] * hn[j]);
           hv[j] = (rbase + j < a.B) ? nn[j] + zz[j] * (hp[j] - nn[j]) : 0.f;
           if (a.lens && rbase + j < a.B && t >= a.lens[rbase + j]) {
             // packed-sequence semantics (encoders.py:55-65): past its length a row keeps its state; saving z = 1 and
@@ -323,6 +349,7 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
         for (int j = 0; j < 4; ++j) {
           tile[(lr + j) * U + lu] = f2bf(hv[j]);
           shv[(lr + j) * U + lu] = hv[j];
+          if constexpr (LSTM) scv[(lr + j) * U + lu] = cv[j];
         }
         if (a.gsaveT) {
           *(float4*)(sg + (0 * U + lu) * RW + lr) = make_float4(rr[0], rr[1], rr[2], rr[3]);
@@ -367,13 +394,18 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
           const int i = sid + k * NSTORE;            // float4 index into shv: [row][unit/4]
           if (i < NH4) {
             const int row = i / (U / 4), c4 = i % (U / 4);
-            *(float4*)(a.hall + ((size_t)(step + 1) * a.Bpad + row0 + row) * H + u0 + c4 * 4) = *(const float4*)(shv + i * 4);
+            const size_t o = ((size_t)(step + 1) * a.Bpad + row0 + row) * H + u0 + c4 * 4;
+            *(float4*)(a.hall + o) = *(const float4*)(shv + i * 4);
+            if constexpr (LSTM) *(float4*)(a.call + o) = *(const float4*)(scv + i * 4);
           }
         }
       } else if (active && (!single || step == a.L - 1)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (rbase + j < a.B) a.hstate[(size_t)(rbase + j) * H + unit] = hv[j];
+          if (rbase + j < a.B) {
+            a.hstate[(size_t)(rbase + j) * H + unit] = hv[j];
+            if constexpr (LSTM) a.cstate[(size_t)(rbase + j) * H + unit] = cv[j];
+          }
       }
       STAMP(8);
     }
@@ -393,7 +425,10 @@ struct GruBwdArgs {
   const bf16_t* whhT;     // [H][K3] bf16: whhT[u][k] = W_hh[k][u], columns >= 3H zero
   bf16_t* dgi;            // [L][Bpad][K3] bf16: (dr, dz, dn)       rows >= B zero
   bf16_t* dgh;            // [L][Bpad][K3] bf16: (dr, dz, dn * r)   exchange buffer
-  float* dcarry;          // [B][H] fp32 scratch; ends as dL/dh0
+  float* dcarry;          // [B][H] fp32 scratch; ends as dL/dh0 (GRU) | dL/dc0 (LSTM: the directly carried gradient is dc)
+  const float* call;      // LSTM only: [(L+1)][Bpad][H] fp32 cell states
+  const float* dcn;       // LSTM only, optional [B][H]: dL/dc_n
+  float* dh0;             // LSTM only: [B][H] dL/dh0
   float* dbias_part;      // [G][4][H]: sums over rows & time of dr, dz, dn, dn*r
   u32* counters;          // [NG] zeroed
   u32* err;
@@ -406,9 +441,13 @@ struct GruBwdArgs {
 // (wave (mt, ut) owns tile (mt, ut) as in the forward kernel), then the bf16 gate gradients go through an
 // LDS tile so that the exchanged copy (dgh) leaves as 16-byte write-through stores; the same hand-off
 // protocol as the forward kernel.
-template <int UT, int NKS_C>
+// NGT = 4 (LSTM): one gate-gradient image (di, df, dg, do) serves both the exchange and the weight-gradient
+// GEMMs (dgi is not written), K = 4H, and the carried gradient is dL/dc while dL/dh arrives only through
+// the recurrent term.
+template <int UT, int NKS_C, int NGT>
 __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   constexpr int U = UT * 16, NTILE = 2 * UT;
+  constexpr bool LSTM = NGT == 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q4 = lane >> 4;
@@ -418,9 +457,9 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   const int K3 = NKS_C ? NKS_C * 32 : a.K3, nch = K3 / 8, mask = swz_mask_for(nch), NKS = K3 / 32, H = a.H;
   char* wl = smem;                                                   // [U][K3] bf16 swizzled (W_hh^T slice)
   f32x4* part = (f32x4*)(smem + (size_t)U * K3 * 2);                 // [4 waves][NTILE][64 lanes]
-  bf16_t* tgh = (bf16_t*)(part + 4 * NTILE * 64);                    // [ROWS][3][U] bf16: dr, dz, dn*r
-  bf16_t* tgi = tgh + ROWS * 3 * U;                                  // [ROWS][3][U] bf16: dr, dz, dn
-  float* bred = (float*)(tgi + ROWS * 3 * U);                        // [8][4][U] bias-grad reduction
+  bf16_t* tgh = (bf16_t*)(part + 4 * NTILE * 64);                    // [ROWS][NGT][U] bf16: dr, dz, dn*r | di, df, dg, do
+  bf16_t* tgi = tgh + ROWS * NGT * U;                                // [ROWS][3][U] bf16: dr, dz, dn (GRU only)
+  float* bred = (float*)(tgi + (LSTM ? 0 : ROWS * NGT * U));         // [8][4][U] bias-grad reduction
 
   for (int i = tid; i < U * nch; i += 256) {
     const int n = i / nch, ch = i % nch;
@@ -447,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     for (int rg = g; rg < a.NG; rg += a.G) {
       const int row0 = rg * ROWS, rbase = row0 + mt * 16 + q4 * 4;
       // (a) independent of the exchange: saved gates / states / upstream gradients of this lane's 4 rows
-      float gr[4], gz[4], gn[4], ghn[4], ghp[4], gdo[4];
+      float gr[4], gz[4], gn[4], ghn[4], ghp[4], gdo[4], gtc[4];   // LSTM: ghp = c_{t-1}, gtc = tanh(c_t)
       if (active && step < a.L) {
         const float* gs = a.gsaveT + ((size_t)t * 4 * H + unit) * a.Bpad + rbase;
         const size_t gq = (size_t)H * a.Bpad;
@@ -463,13 +502,19 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        ghp[j] = gdo[j] = 0.f;
+        ghp[j] = gdo[j] = gtc[j] = 0.f;
         const int brow = rbase + j;
         if (active && brow < a.B && step < a.L) {
-          ghp[j] = a.hall[((size_t)ti * a.Bpad + brow) * H + unit];
+          if constexpr (LSTM) {
+            ghp[j] = a.call[((size_t)ti * a.Bpad + brow) * H + unit];
+            gtc[j] = fast_tanh(a.call[((size_t)(ti + 1) * a.Bpad + brow) * H + unit]);
+          } else {
+            ghp[j] = a.hall[((size_t)ti * a.Bpad + brow) * H + unit];
+          }
           if (a.dout) gdo[j] = a.dout[brow * a.dout_sb + t * a.dout_st + unit];
           if (step == 0) {
             if (a.dhn) gdo[j] += a.dhn[(size_t)brow * H + unit];
+            if constexpr (LSTM) carry[j] = a.dcn ? a.dcn[(size_t)brow * H + unit] : 0.f;
           } else if (!single) {
             carry[j] = a.dcarry[(size_t)brow * H + unit];
           }
@@ -532,7 +577,12 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
           const int brow = rbase + j;
           if (active && brow < a.B) {
             const float prev = single ? carry[j] : a.dcarry[(size_t)brow * H + unit];
-            a.dcarry[(size_t)brow * H + unit] = prev + rec[j];
+            if constexpr (LSTM) {
+              a.dcarry[(size_t)brow * H + unit] = prev;
+              a.dh0[(size_t)brow * H + unit] = rec[j];
+            } else {
+              a.dcarry[(size_t)brow * H + unit] = prev + rec[j];
+            }
           }
         }
         __syncthreads();          // the partial buffer is reused by the next row group
@@ -542,34 +592,50 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool live = active && rbase + j < a.B;
-        const float dh = rec[j] + gdo[j] + (step > 0 ? carry[j] : 0.f);
-        dn[j] = dh * (1.f - gz[j]) * (1.f - gn[j] * gn[j]);
-        dz[j] = dh * (ghp[j] - gn[j]) * gz[j] * (1.f - gz[j]);
-        dr[j] = dn[j] * ghn[j] * gr[j] * (1.f - gr[j]);
-        dnr[j] = dn[j] * gr[j];
+        if constexpr (LSTM) {
+          // saved slots: gr = i, gz = f, gn = g, ghn = o.  (dr, dz, dn, dnr) carry (di, df, dg, do) pre-activation
+          const float dh = rec[j] + gdo[j];
+          const float dc = dh * ghn[j] * (1.f - gtc[j] * gtc[j]) + carry[j];
+          dr[j] = dc * gn[j] * gr[j] * (1.f - gr[j]);
+          dz[j] = dc * ghp[j] * gz[j] * (1.f - gz[j]);
+          dn[j] = dc * gr[j] * (1.f - gn[j] * gn[j]);
+          dnr[j] = dh * gtc[j] * ghn[j] * (1.f - ghn[j]);
+          carry[j] = dc * gz[j];
+        } else {
+          const float dh = rec[j] + gdo[j] + (step > 0 ? carry[j] : 0.f);
+          dn[j] = dh * (1.f - gz[j]) * (1.f - gn[j] * gn[j]);
+          dz[j] = dh * (ghp[j] - gn[j]) * gz[j] * (1.f - gz[j]);
+          dr[j] = dn[j] * ghn[j] * gr[j] * (1.f - gr[j]);
+          dnr[j] = dn[j] * gr[j];
+          carry[j] = dh * gz[j];
+        }
         if (!live) dn[j] = dz[j] = dr[j] = dnr[j] = 0.f;
-        carry[j] = dh * gz[j];
         bsum[0] += dr[j];
         bsum[1] += dz[j];
         bsum[2] += dn[j];
         bsum[3] += dnr[j];
         if (active) {
-          const int o = (mt * 16 + q4 * 4 + j) * 3 * U + ut * 16 + c16;
+          const int o = (mt * 16 + q4 * 4 + j) * NGT * U + ut * 16 + c16;
           const bf16_t br = f2bf(dr[j]), bz = f2bf(dz[j]);
           tgh[o] = br;
           tgh[o + U] = bz;
-          tgh[o + 2 * U] = f2bf(dnr[j]);
-          tgi[o] = br;
-          tgi[o + U] = bz;
-          tgi[o + 2 * U] = f2bf(dn[j]);
+          if constexpr (LSTM) {
+            tgh[o + 2 * U] = f2bf(dn[j]);
+            tgh[o + (NGT - 1) * U] = f2bf(dnr[j]);
+          } else {
+            tgh[o + 2 * U] = f2bf(dnr[j]);
+            tgi[o] = br;
+            tgi[o + U] = bz;
+            tgi[o + 2 * U] = f2bf(dn[j]);
+          }
         }
       }
       __syncthreads();
       // (d) publish dgh (write-through), drain, barrier, arrive; then the copies nobody waits for
-      constexpr int NCH = ROWS * 3 * U / 8;                  // 16-byte chunks per image
+      constexpr int NCH = ROWS * NGT * U / 8;                // 16-byte chunks per image
       for (int c = tid; c < NCH; c += 256) {
-        const int row = c / (3 * U / 8), rem = c % (3 * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
-        const u32x4 v = *(const u32x4*)(tgh + row * 3 * U + gt * U + ch * 8);
+        const int row = c / (NGT * U / 8), rem = c % (NGT * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
+        const u32x4 v = *(const u32x4*)(tgh + row * NGT * U + gt * U + ch * 8);
         const unsigned off = (unsigned)((((size_t)t * a.Bpad + row0 + row) * K3 + gt * H + u0 + ch * 8) * 2);
         __builtin_amdgcn_raw_buffer_store_b128(v, grsrc, off, 0, AUX_SC1);
       }
@@ -577,10 +643,12 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(a.counters + rg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("" ::: "memory");
-      for (int c = tid; c < NCH; c += 256) {
-        const int row = c / (3 * U / 8), rem = c % (3 * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
-        const uint4 v = *(const uint4*)(tgi + row * 3 * U + gt * U + ch * 8);
-        *(uint4*)(a.dgi + ((size_t)t * a.Bpad + row0 + row) * K3 + gt * H + u0 + ch * 8) = v;
+      if constexpr (!LSTM) {
+        for (int c = tid; c < NCH; c += 256) {
+          const int row = c / (3 * U / 8), rem = c % (3 * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
+          const uint4 v = *(const uint4*)(tgi + row * 3 * U + gt * U + ch * 8);
+          *(uint4*)(a.dgi + ((size_t)t * a.Bpad + row0 + row) * K3 + gt * H + u0 + ch * 8) = v;
+        }
       }
       if (!single) {
 #pragma unroll
@@ -616,14 +684,19 @@ __global__ void gru_pack_h0_kernel(const float* __restrict__ h0, int B, int H, i
   if (hall0) hall0[i] = v;
 }
 
-__global__ void gru_bias_reduce_kernel(const float* __restrict__ part, int G, int H, float* __restrict__ db_ih,
+__global__ void gru_bias_reduce_kernel(const float* __restrict__ part, int G, int H, int lstm, float* __restrict__ db_ih,
                                        float* __restrict__ db_hh) {
-  // part [G][4][H] -> db_ih [3H] = (dr, dz, dn), db_hh [3H] = (dr, dz, dn*r)
+  // part [G][4][H] -> GRU: db_ih [3H] = (dr, dz, dn), db_hh [3H] = (dr, dz, dn*r);  LSTM: db_ih = db_hh = all four
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 4 * H) return;
   float sacc = 0.f;
   for (int gidx = 0; gidx < G; ++gidx) sacc += part[(size_t)gidx * 4 * H + i];
   const int gt = i / H, u = i % H;
+  if (lstm) {
+    db_ih[i] = sacc;
+    db_hh[i] = sacc;
+    return;
+  }
   if (gt < 3) db_ih[gt * H + u] = sacc;
   if (gt < 2) db_hh[gt * H + u] = sacc;
   if (gt == 3) db_hh[2 * H + u] = sacc;
@@ -652,19 +725,32 @@ int cu_count() {
   return g_cu_count;
 }
 
-}  // namespace
+// c0 -> cell-state slot 0 and the running cell state (LSTM)
+__global__ void lstm_pack_c0_kernel(const float* __restrict__ c0, int B, int H, float* __restrict__ cstate,
+                                    float* __restrict__ call0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H) return;
+  const float v = c0 ? c0[i] : 0.f;
+  cstate[i] = v;
+  call0[i] = v;
+}
 
-extern "C" {
-
-int pv_gru_geometry(int B, int H, int* Hk, int* K3, int* Bpad, int* NG) {
-  PV_REQUIRE(B > 0 && H > 0 && H % 16 == 0, "pv_gru: hidden size %d must be a positive multiple of 16", H);
-  PV_REQUIRE(H <= 1024, "pv_gru: hidden size %d > 1024 not supported (LDS-resident weight slice)", H);
+int rnn_geometry(int ngt, int B, int H, int* Hk, int* KG, int* Bpad, int* NG) {
+  PV_REQUIRE(B > 0 && H > 0 && H % 16 == 0, "pv_gru/pv_lstm: hidden size %d must be a positive multiple of 16", H);
+  PV_REQUIRE(H <= 1024, "pv_gru/pv_lstm: hidden size %d > 1024 not supported (LDS-resident weight slice)", H);
   if (Hk) *Hk = round_up(H, 64);      // also the K of GEMMs that consume the bf16 state sequence
-  if (K3) *K3 = round_up(3 * H, 64);
+  if (KG) *KG = round_up(ngt * H, 64);
   if (Bpad) *Bpad = round_up(B, ROWS);
   if (NG) *NG = cdiv(B, ROWS);
   return PV_OK;
 }
+
+}  // namespace
+
+extern "C" {
+
+int pv_gru_geometry(int B, int H, int* Hk, int* K3, int* Bpad, int* NG) { return rnn_geometry(3, B, H, Hk, K3, Bpad, NG); }
+int pv_lstm_geometry(int B, int H, int* Hk, int* K4, int* Bpad, int* NG) { return rnn_geometry(4, B, H, Hk, K4, Bpad, NG); }
 
 size_t pv_gru_sync_bytes(int B) {
 #ifdef PV_GRU_STAMPS
@@ -674,13 +760,19 @@ size_t pv_gru_sync_bytes(int B) {
 #endif
 }
 
-int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0,
-               const int* lengths, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall,
-               float* hn, void* sync, int max_wgs, void* stream) {
+}  // extern "C"
+
+namespace {
+
+int rnn_fwd(int ngt, const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0,
+            const float* c0, const int* lengths, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT,
+            float* hall, float* call, float* hn, float* cn, void* sync, int max_wgs, void* stream) {
   int Hk, K3, Bpad, NG;
-  int rc = pv_gru_geometry(B, H, &Hk, &K3, &Bpad, &NG);
+  int rc = rnn_geometry(ngt, B, H, &Hk, &K3, &Bpad, &NG);
   if (rc) return rc;
-  PV_REQUIRE(xprojT && whh_bf16 && bhh && hseq_bf16 && hall && hn && sync && L > 0, "pv_gru_fwd: null/empty argument");
+  PV_REQUIRE(xprojT && whh_bf16 && bhh && hseq_bf16 && hall && hn && sync && L > 0, "pv_gru_fwd/pv_lstm_fwd: null/empty argument");
+  PV_REQUIRE(ngt == 3 || (call && cn), "pv_lstm_fwd: null cell-state buffer");
+  PV_REQUIRE(ngt == 3 || !lengths, "pv_lstm_fwd: variable lengths are not supported for the LSTM cell");
   PV_REQUIRE(((uintptr_t)whh_bf16 & 15) == 0 && ((uintptr_t)hseq_bf16 & 15) == 0, "pv_gru_fwd: bf16 buffers must be 16-byte aligned");
   PV_REQUIRE(ldx >= (long)L * Bpad && ldx % 4 == 0 && ((uintptr_t)xprojT & 15) == 0 && ((uintptr_t)gsaveT & 15) == 0,
              "pv_gru_fwd: xprojT needs ldx >= L*Bpad = %ld, ldx %% 4 == 0 and 16-byte alignment (also gsaveT)", (long)L * Bpad);
@@ -688,7 +780,9 @@ int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float*
   const size_t hseq_bytes = (size_t)(L + 1) * Bpad * Hk * 2;
   PV_REQUIRE(hseq_bytes < (1ull << 31), "pv_gru_fwd: state sequence of %zu bytes exceeds the 2 GiB buffer-addressing limit", hseq_bytes);
   int UT = (H % 32 == 0) ? 2 : 1;
-  if (UT == 2 && (size_t)3 * 32 * Hk * 2 + ROWS * 32 * 2 + 5 * 32 * ROWS * 4 > 160 * 1024) UT = 1;   // weight slice must fit the 160 KiB LDS
+  // the weight slice, the staging areas and (preferably) the shared h_{t-1} copy must fit the 160 KiB LDS
+  const size_t nstage = ngt == 4 ? 6 : 5;
+  if (UT == 2 && (size_t)ngt * 32 * Hk * 2 + ROWS * 32 * 2 + nstage * 32 * ROWS * 4 + (ngt == 4 ? (size_t)ROWS * Hk * 2 : 0) > 160 * 1024) UT = 1;
   const int U = UT * 16, S = H / U;
   const int cap = max_wgs > 0 ? max_wgs : cu_count();
   PV_REQUIRE(S <= cap, "pv_gru_fwd: %d unit slices exceed the %d co-resident workgroups available", S, cap);
@@ -696,7 +790,7 @@ int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float*
   // alternately, were measured slower at B=256, H=512 -- 544 vs 430 us -- because the per-group cost is dominated by
   // fixed barrier / latency terms, not by rows; kept selectable with PV_GRU_MT=1 for experiments.)
   int MT = 2;
-  if (const char* e = getenv("PV_GRU_MT")) MT = atoi(e) == 1 ? 1 : 2;
+  if (const char* e = getenv("PV_GRU_MT")) MT = (atoi(e) == 1 && ngt == 3) ? 1 : 2;
   const int RW = MT * 16, NGk = Bpad / RW;
   int G = NGk < cap / S ? NGk : cap / S;
   if (MT == 1 && G > (NGk + 1) / 2) G = (NGk + 1) / 2;         // two groups per workgroup
@@ -705,22 +799,37 @@ int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float*
   u32* counters = err + 1;
   PV_HIP(hipMemsetAsync(sync, 0, pv_gru_sync_bytes(B), st));
   if (Hk != H || Bpad != B) PV_HIP(hipMemsetAsync(hseq_bf16, 0, (size_t)(L + 1) * Bpad * Hk * 2, st));
+  if (Bpad != B) {
+    PV_HIP(hipMemsetAsync(hall, 0, (size_t)Bpad * H * sizeof(float), st));      // slot 0 rows >= B are read as states
+    if (ngt == 4) PV_HIP(hipMemsetAsync(call, 0, (size_t)Bpad * H * sizeof(float), st));
+  }
   hipLaunchKernelGGL(gru_pack_h0_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, h0, B, H, Hk, (bf16_t*)hseq_bf16, hn, hall);
   PV_LAUNCH_CHECK("gru_pack_h0_kernel");
-  const size_t smem_base = (size_t)3 * U * Hk * 2 + (size_t)RW * U * 2 + (size_t)5 * U * RW * 4,
+  if (ngt == 4) {
+    hipLaunchKernelGGL(lstm_pack_c0_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, c0, B, H, cn, call);
+    PV_LAUNCH_CHECK("lstm_pack_c0_kernel");
+  }
+  const size_t smem_base = (size_t)ngt * U * Hk * 2 + (size_t)RW * U * 2 + nstage * U * RW * 4,
                smem_a = (size_t)RW * Hk * 2;
   const int a_lds = smem_base + smem_a <= 160 * 1024;       // share the group's h_{t-1} through LDS when it fits
   const size_t smem = smem_base + (a_lds ? smem_a : 0);
   GruFwdArgs a{xprojT, ldx, (const bf16_t*)whh_bf16, bhh, (bf16_t*)hseq_bf16, gsaveT, hn, hall,
-               counters, err, (u32*)sync + 64, lengths, L, B, H, Hk, Bpad, NGk, G, S, reverse, a_lds, (unsigned)hseq_bytes, 0};
+               counters, err, (u32*)sync + 64, lengths, cn, call, L, B, H, Hk, Bpad, NGk, G, S, reverse, a_lds,
+               (unsigned)hseq_bytes, 0};
   if (const char* e = getenv("PV_GRU_DBG")) a.dbg = atoi(e);
-#define PV_GRU_LAUNCH_F(UTv, NKv, MTv)                                                           \
-  do {                                                                                           \
-    static size_t seen = 0;                                                                      \
-    if ((rc = ensure_lds(gru_fwd_kernel<UTv, NKv, MTv>, smem, &seen))) return rc;                \
-    hipLaunchKernelGGL((gru_fwd_kernel<UTv, NKv, MTv>), dim3(G * S), dim3(NT_F), smem, st, a);   \
+#define PV_GRU_LAUNCH_F4(UTv, NKv, MTv, NGv)                                                          \
+  do {                                                                                                \
+    static size_t seen = 0;                                                                           \
+    if ((rc = ensure_lds(gru_fwd_kernel<UTv, NKv, MTv, NGv>, smem, &seen))) return rc;                \
+    hipLaunchKernelGGL((gru_fwd_kernel<UTv, NKv, MTv, NGv>), dim3(G * S), dim3(NT_F), smem, st, a);   \
   } while (0)
-  if (MT == 1) {
+#define PV_GRU_LAUNCH_F(UTv, NKv, MTv) PV_GRU_LAUNCH_F4(UTv, NKv, MTv, 3)
+  if (ngt == 4) {
+    if (UT == 1 && Hk == 512 && a_lds) PV_GRU_LAUNCH_F4(1, 16, 2, 4);
+    else if (UT == 2 && Hk == 256 && a_lds) PV_GRU_LAUNCH_F4(2, 8, 2, 4);
+    else if (UT == 2) PV_GRU_LAUNCH_F4(2, 0, 2, 4);
+    else PV_GRU_LAUNCH_F4(1, 0, 2, 4);
+  } else if (MT == 1) {
     if (UT == 2 && Hk == 512 && a_lds) PV_GRU_LAUNCH_F(2, 16, 1);
     else if (UT == 2 && Hk == 256 && a_lds) PV_GRU_LAUNCH_F(2, 8, 1);
     else if (UT == 2) PV_GRU_LAUNCH_F(2, 0, 1);
@@ -732,25 +841,27 @@ int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float*
     else PV_GRU_LAUNCH_F(1, 0, 2);
   }
 #undef PV_GRU_LAUNCH_F
+#undef PV_GRU_LAUNCH_F4
   PV_LAUNCH_CHECK("gru_fwd_kernel");
   return PV_OK;
 }
 
-int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsaveT,
-               const float* hall, const void* whhT_bf16, int L, int B, int H, int reverse, void* dgi_bf16,
-               void* dgh_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
-               int max_wgs, void* stream) {
+int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float* dhn, const float* dcn,
+            const float* gsaveT, const float* hall, const float* call, const void* whhT_bf16, int L, int B, int H,
+            int reverse, void* dgi_bf16, void* dgh_bf16, float* dh0, float* dc0, float* dbias_part, float* db_ih,
+            float* db_hh, void* sync, int max_wgs, void* stream) {
   int Hk, K3, Bpad, NG;
-  int rc = pv_gru_geometry(B, H, &Hk, &K3, &Bpad, &NG);
+  int rc = rnn_geometry(ngt, B, H, &Hk, &K3, &Bpad, &NG);
   if (rc) return rc;
-  PV_REQUIRE(gsaveT && hall && whhT_bf16 && dgi_bf16 && dgh_bf16 && dh0 && dbias_part && db_ih && db_hh && sync && L > 0,
-             "pv_gru_bwd: null/empty argument");
+  PV_REQUIRE(gsaveT && hall && whhT_bf16 && dgh_bf16 && dh0 && dbias_part && db_ih && db_hh && sync && L > 0,
+             "pv_gru_bwd/pv_lstm_bwd: null/empty argument");
+  PV_REQUIRE(ngt == 4 ? (call && dc0) : (dgi_bf16 != nullptr), "pv_gru_bwd/pv_lstm_bwd: null/empty argument");
   hipStream_t st = (hipStream_t)stream;
   const size_t dg_bytes = (size_t)L * Bpad * K3 * 2;
   PV_REQUIRE(dg_bytes < (1ull << 31), "pv_gru_bwd: gate-gradient buffer of %zu bytes exceeds the 2 GiB buffer-addressing limit", dg_bytes);
   auto lds_need = [&](int ut) {
     const size_t u = (size_t)ut * 16;
-    return u * K3 * 2 + (size_t)4 * 2 * ut * 64 * 16 + 2 * (size_t)ROWS * 3 * u * 2 + (size_t)8 * 4 * u * 4;
+    return u * K3 * 2 + (size_t)4 * 2 * ut * 64 * 16 + (ngt == 4 ? 1 : 2) * (size_t)ROWS * ngt * u * 2 + (size_t)8 * 4 * u * 4;
   };
   int UT = (H % 32 == 0) ? 2 : 1;
   if (UT == 2 && lds_need(2) > 160 * 1024) UT = 1;
@@ -764,29 +875,71 @@ int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, 
   u32* counters = err + 1;
   PV_HIP(hipMemsetAsync(sync, 0, pv_gru_sync_bytes(B), st));
   PV_HIP(hipMemsetAsync(dh0, 0, (size_t)B * H * sizeof(float), st));
+  if (ngt == 4) PV_HIP(hipMemsetAsync(dc0, 0, (size_t)B * H * sizeof(float), st));
   PV_HIP(hipMemsetAsync(dbias_part, 0, (size_t)NG * 4 * H * sizeof(float), st));
-  if (K3 != 3 * H || Bpad != B) {
-    PV_HIP(hipMemsetAsync(dgi_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
+  if (K3 != ngt * H || Bpad != B) {
+    if (dgi_bf16) PV_HIP(hipMemsetAsync(dgi_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
     PV_HIP(hipMemsetAsync(dgh_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
   }
   GruBwdArgs a{dout, dout_sb, dout_st, dhn, gsaveT, hall, (const bf16_t*)whhT_bf16, (bf16_t*)dgi_bf16,
-               (bf16_t*)dgh_bf16, dh0, dbias_part, counters, err, L, B, H, K3, Bpad, NG, G, S, reverse,
-               (unsigned)dg_bytes};
-#define PV_GRU_LAUNCH_B(UTv, NKv)                                                             \
-  do {                                                                                        \
-    static size_t seen = 0;                                                                   \
-    if ((rc = ensure_lds(gru_bwd_kernel<UTv, NKv>, smem, &seen))) return rc;                  \
-    hipLaunchKernelGGL((gru_bwd_kernel<UTv, NKv>), dim3(G * S), dim3(256), smem, st, a);      \
+               (bf16_t*)dgh_bf16, ngt == 4 ? dc0 : dh0, call, dcn, dh0, dbias_part, counters, err, L, B, H, K3, Bpad,
+               NG, G, S, reverse, (unsigned)dg_bytes};
+#define PV_GRU_LAUNCH_B4(UTv, NKv, NGv)                                                            \
+  do {                                                                                             \
+    static size_t seen = 0;                                                                        \
+    if ((rc = ensure_lds(gru_bwd_kernel<UTv, NKv, NGv>, smem, &seen))) return rc;                  \
+    hipLaunchKernelGGL((gru_bwd_kernel<UTv, NKv, NGv>), dim3(G * S), dim3(256), smem, st, a);      \
   } while (0)
-  if (UT == 2 && K3 == 1536) PV_GRU_LAUNCH_B(2, 48);
+#define PV_GRU_LAUNCH_B(UTv, NKv) PV_GRU_LAUNCH_B4(UTv, NKv, 3)
+  if (ngt == 4) {
+    if (UT == 2 && K3 == 2048) PV_GRU_LAUNCH_B4(2, 64, 4);
+    else if (UT == 2) PV_GRU_LAUNCH_B4(2, 0, 4);
+    else PV_GRU_LAUNCH_B4(1, 0, 4);
+  } else if (UT == 2 && K3 == 1536) PV_GRU_LAUNCH_B(2, 48);
   else if (UT == 2 && K3 == 768) PV_GRU_LAUNCH_B(2, 24);
   else if (UT == 2) PV_GRU_LAUNCH_B(2, 0);
   else PV_GRU_LAUNCH_B(1, 0);
 #undef PV_GRU_LAUNCH_B
+#undef PV_GRU_LAUNCH_B4
   PV_LAUNCH_CHECK("gru_bwd_kernel");
-  hipLaunchKernelGGL(gru_bias_reduce_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, dbias_part, G, H, db_ih, db_hh);
+  hipLaunchKernelGGL(gru_bias_reduce_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, dbias_part, G, H, ngt == 4 ? 1 : 0,
+                     db_ih, db_hh);
   PV_LAUNCH_CHECK("gru_bias_reduce_kernel");
   return PV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0,
+               const int* lengths, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall,
+               float* hn, void* sync, int max_wgs, void* stream) {
+  return rnn_fwd(3, xprojT, ldx, whh_bf16, bhh, h0, nullptr, lengths, L, B, H, reverse, hseq_bf16, gsaveT, hall, nullptr,
+                 hn, nullptr, sync, max_wgs, stream);
+}
+
+int pv_lstm_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0,
+                const float* c0, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall,
+                float* call, float* hn, float* cn, void* sync, int max_wgs, void* stream) {
+  return rnn_fwd(4, xprojT, ldx, whh_bf16, bhh, h0, c0, nullptr, L, B, H, reverse, hseq_bf16, gsaveT, hall, call, hn, cn,
+                 sync, max_wgs, stream);
+}
+
+int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsaveT,
+               const float* hall, const void* whhT_bf16, int L, int B, int H, int reverse, void* dgi_bf16,
+               void* dgh_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
+               int max_wgs, void* stream) {
+  return rnn_bwd(3, dout, dout_sb, dout_st, dhn, nullptr, gsaveT, hall, nullptr, whhT_bf16, L, B, H, reverse, dgi_bf16,
+                 dgh_bf16, dh0, nullptr, dbias_part, db_ih, db_hh, sync, max_wgs, stream);
+}
+
+int pv_lstm_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* dcn,
+                const float* gsaveT, const float* hall, const float* call, const void* whhT_bf16, int L, int B, int H,
+                int reverse, void* dg_bf16, float* dh0, float* dc0, float* dbias_part, float* db_ih, float* db_hh,
+                void* sync, int max_wgs, void* stream) {
+  return rnn_bwd(4, dout, dout_sb, dout_st, dhn, dcn, gsaveT, hall, call, whhT_bf16, L, B, H, reverse, nullptr, dg_bf16,
+                 dh0, dc0, dbias_part, db_ih, db_hh, sync, max_wgs, stream);
 }
 
 }  // extern "C"

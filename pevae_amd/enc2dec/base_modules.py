@@ -1,5 +1,5 @@
 """BaseRNN with the reference's constructor and state_dict layout (models/enc2dec/base_modules.py:9-81),
-running its recurrence on the persistent HIP GRU kernel instead of cuDNN."""
+running its recurrence on the persistent HIP GRU / LSTM kernels instead of cuDNN."""
 import math
 
 import torch
@@ -36,12 +36,12 @@ class RNNWeights(nn.Module):
         return [getattr(self, n + tail) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
 
     def forward(self, x, state=None, lengths=None):
-        """x [B,L,in] -> (out [B,L,H*dirs], h_n [layers*dirs,B,H], hseq_bf16 of the last layer or None).
+        """x [B,L,in] -> (out [B,L,H*dirs], h_n [layers*dirs,B,H] (LSTM: (h_n, c_n)), hseq_bf16 of the last layer or None).
         lengths (list / tensor [B]): pack_padded_sequence semantics (encoders.py:55-65): a row's state stops at its
         length, outputs past it are zero and the time axis is cut to max(lengths); unidirectional only."""
-        if self.cell != "gru":
-            raise NotImplementedError("pevae_amd: only the GRU cell has a HIP kernel (the reference's README "
-                                      "configuration, --rnn_cell gru); LSTM parameters load but do not run")
+        lstm = self.cell == "lstm"
+        if lstm and lengths is not None:
+            raise NotImplementedError("pevae_amd: variable_lengths with the LSTM cell has no HIP path")
         ndir = 2 if self.bidirectional else 1
         lens = mask = None
         if lengths is not None:
@@ -52,14 +52,20 @@ class RNNWeights(nn.Module):
             lens = lens_l.to(device=x.device, dtype=torch.int32)
             mask = (torch.arange(x.size(1), device=x.device).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1).to(x.dtype)
         save = torch.is_grad_enabled()
-        finals, hseq = [], None
+        finals, cfinals, hseq = [], [], None
         for layer in range(self.num_layers):
             outs = []
             for d in range(ndir):
                 w_ih, w_hh, b_ih, b_hh = self.layer_weights(layer, d)
-                h0 = None if state is None else state[layer * ndir + d]
                 xin = x.flip(1) if d else x
-                out, hn, hs = ops.GRULayer.apply(xin, h0, w_ih, w_hh, b_ih, b_hh, save, lens)
+                if lstm:                                      # state is (h_0, c_0), returns (h_n, c_n)
+                    h0 = None if state is None else state[0][layer * ndir + d]
+                    c0 = None if state is None else state[1][layer * ndir + d]
+                    out, hn, cn, hs = ops.LSTMLayer.apply(xin, h0, c0, w_ih, w_hh, b_ih, b_hh, save)
+                    cfinals.append(cn)
+                else:
+                    h0 = None if state is None else state[layer * ndir + d]
+                    out, hn, hs = ops.GRULayer.apply(xin, h0, w_ih, w_hh, b_ih, b_hh, save, lens)
                 if mask is not None:
                     out, hs = out * mask, None            # zero rows past each length (pad_packed_sequence)
                 outs.append(out.flip(1) if d else out)
@@ -69,6 +75,8 @@ class RNNWeights(nn.Module):
             if self.dropout > 0 and self.training and layer < self.num_layers - 1:
                 x = F.dropout(x, self.dropout, True)
                 hseq = None
+        if lstm:
+            return x, (torch.stack(finals, dim=0), torch.stack(cfinals, dim=0)), hseq
         return x, torch.stack(finals, dim=0), hseq
 
 

@@ -106,6 +106,12 @@ def gru_geometry(B, H):
     return hk.value, k3.value, bp.value, ng.value
 
 
+def lstm_geometry(B, H):
+    hk, k4, bp, ng = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    _lib.call("pv_lstm_geometry", B, H, C.byref(hk), C.byref(k4), C.byref(bp), C.byref(ng))
+    return hk.value, k4.value, bp.value, ng.value
+
+
 # ------------------------------------------------------------------------------------------------------------
 # layout helpers
 # ------------------------------------------------------------------------------------------------------------
@@ -406,6 +412,86 @@ class GRULayer(torch.autograd.Function):
         hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
         dw_hh = gemm_nt_wgrad(dghT, Tp, hpT, Tp, 3 * H, H, Tp, grad_sink(p_hh, (3 * H, H)))
         return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None, None
+
+
+class LSTMLayer(torch.autograd.Function):
+    """One unidirectional LSTM layer over x [B,L,E] (batch_first), torch.nn.LSTM semantics (rnn_cell 'lstm':
+    base_modules.py:42-51; encoders.py:59-62; decoders.py:182).  Returns (out [B,L,H], h_n [B,H], c_n [B,H],
+    hseq bf16 as GRULayer).  One gate-gradient image feeds dx, dW_ih and dW_hh; db_ih == db_hh."""
+
+    @staticmethod
+    def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, save):
+        _need_cuda(x, w_ih, w_hh, b_ih, b_hh, h0, c0)
+        B, L, E = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        Hk, K4, Bpad, NG = lstm_geometry(B, H)
+        Ep = round_up(E, 64)
+        x_bf = cast_pack(x, L, B, Bpad, E, x.stride(1), x.stride(0), x.stride(2), Ep)
+        wih_bf = pack_matrix(w_ih, Ep)
+        whh_bf = pack_matrix(w_hh, Hk)
+        xprojT = gemm_nt(wih_bf, Ep, x_bf, Ep, 4 * H, L * Bpad, Ep, bias=b_ih.contiguous(), bias_per_row=True,
+                         out=workspace("lstm_xprojT", 4 * H * L * Bpad, torch.float32, dev).view(4 * H, L * Bpad))
+        hseq = torch.empty(((L + 1) * Bpad, Hk), dtype=BF16, device=dev)
+        hn = torch.empty((B, H), dtype=torch.float32, device=dev)
+        cn = torch.empty((B, H), dtype=torch.float32, device=dev)
+        gsave = torch.empty((L * 4 * H, Bpad), dtype=torch.float32, device=dev) if save else None
+        hall = torch.empty(((L + 1), Bpad, H), dtype=torch.float32, device=dev)
+        call = torch.empty(((L + 1), Bpad, H), dtype=torch.float32, device=dev)
+        sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
+        h0c = None if h0 is None else h0.contiguous()
+        c0c = None if c0 is None else c0.contiguous()
+        with timed("lstm_fwd"):
+            _lib.call("pv_lstm_fwd", _p(xprojT), L * Bpad, _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), _p(c0c), L, B, H, 0,
+                      _p(hseq), _p(gsave), _p(hall), _p(call), _p(hn), _p(cn), _p(sync), GRU_MAX_WGS, _stream())
+        out = hall[1:, :B].transpose(0, 1)
+        if save:
+            ctx.save_for_backward(x_bf, hseq, gsave, hall, call, w_ih, w_hh)
+        if len(LAST_GRU_SYNC) < 64:
+            LAST_GRU_SYNC.append((sync, NG, "pv_lstm_fwd"))
+        ctx.dims = (B, L, E, H, Hk, K4, Bpad, NG, Ep)
+        ctx.params = (w_ih, w_hh)
+        ctx.has_state = (h0 is not None, c0 is not None)
+        ctx.mark_non_differentiable(hseq)
+        return out, hn, cn, hseq
+
+    @staticmethod
+    def backward(ctx, dout, dhn, dcn, _dhseq):
+        x_bf, hseq, gsave, hall, call, w_ih, w_hh = ctx.saved_tensors
+        B, L, E, H, Hk, K4, Bpad, NG, Ep = ctx.dims
+        dev = x_bf.device
+        whhT = transpose_to_bf16(w_hh.contiguous(), 4 * H, H, H, K4)
+        dg = torch.empty((L * Bpad, K4), dtype=BF16, device=dev)
+        dh0 = torch.empty((B, H), dtype=torch.float32, device=dev)
+        dc0 = torch.empty((B, H), dtype=torch.float32, device=dev)
+        dbp = workspace("gru_dbias_part", NG * 4 * H, torch.float32, dev)
+        db_ih = torch.empty(4 * H, dtype=torch.float32, device=dev)
+        db_hh = torch.empty(4 * H, dtype=torch.float32, device=dev)
+        sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
+        if dout is not None:
+            dout = dout if dout.stride(2) == 1 else dout.contiguous()
+        dhn_c = None if dhn is None else dhn.contiguous()
+        dcn_c = None if dcn is None else dcn.contiguous()
+        with timed("lstm_bwd"):
+            _lib.call("pv_lstm_bwd", _p(dout), 0 if dout is None else dout.stride(0),
+                      0 if dout is None else dout.stride(1), _p(dhn_c), _p(dcn_c), _p(gsave), _p(hall), _p(call),
+                      _p(whhT), L, B, H, 0, _p(dg), _p(dh0), _p(dc0), _p(dbp), _p(db_ih), _p(db_hh), _p(sync),
+                      GRU_MAX_WGS, _stream())
+        if len(LAST_GRU_SYNC) < 64:
+            LAST_GRU_SYNC.append((sync, NG, "pv_lstm_bwd"))
+        Tt = L * Bpad
+        Tp = round_up(Tt, 64)
+        wihT = transpose_to_bf16(w_ih.contiguous(), 4 * H, E, E, K4)
+        dx_tm = gemm_nt(dg, K4, wihT, K4, Tt, E, K4)
+        dx = dx_tm.view(L, Bpad, E)[:, :B].transpose(0, 1)
+        dgT = transpose_to_bf16(dg, Tt, 4 * H, K4, Tp, out=workspace("lstm_dgT", 4 * H * Tp, BF16, dev).view(4 * H, Tp))
+        xT = transpose_to_bf16(x_bf, Tt, E, Ep, Tp, out=workspace("gru_xT", E * Tp, BF16, dev).view(E, Tp))
+        hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
+        p_ih, p_hh = ctx.params
+        dw_ih = gemm_nt_wgrad(dgT, Tp, xT, Tp, 4 * H, E, Tp, grad_sink(p_ih, (4 * H, E)))
+        dw_hh = gemm_nt_wgrad(dgT, Tp, hpT, Tp, 4 * H, H, Tp, grad_sink(p_hh, (4 * H, H)))
+        has_h0, has_c0 = ctx.has_state
+        return dx, (dh0 if has_h0 else None), (dc0 if has_c0 else None), dw_ih, dw_hh, db_ih, db_hh, None
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -68,6 +68,60 @@ def test_encoder_rnn(dev, tag, kw):
     close(hn0, g["hn_nostate"], rtol=0, atol=3e-2)
 
 
+def test_encoder_lstm(dev):
+    """rnn_cell='lstm' (base_modules.py:42-51): (h, c) state in and out, golden from the reference's nn.LSTM path."""
+    from pevae_amd.enc2dec.encoders import EncoderRNN
+    from pevae_amd import ops
+    g = load_golden("encoder_lstm")
+    B, L, E = g["x"].shape
+    H = g["h0"].shape[-1]
+    enc = load_params(EncoderRNN(E, H, rnn_cell="lstm"), g).to(dev)
+    x = T(g["x"], dev).requires_grad_()
+    out, (hn, cn) = enc(x, init_state=(T(g["h0"], dev), T(g["c0"], dev)))
+    w_hid = T(g["w_hid"], dev)
+    ((out * T(g["w_out"], dev)).sum() + (hn * w_hid).sum() + (cn * w_hid).sum() * 0.5).backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    close(out, g["out"], rtol=0, atol=3e-2)
+    close(hn, g["hn"], rtol=0, atol=3e-2)
+    close(cn, g["cn"], rtol=0, atol=3e-2)
+    assert relmax(x.grad, g["dx"]) < 4e-2
+    check_grads(enc, g, 4e-2)
+    out0, (hn0, _) = enc(T(g["x"], dev))
+    close(out0, g["out_nostate"], rtol=0, atol=3e-2)
+    close(hn0, g["hn_nostate"], rtol=0, atol=3e-2)
+    with pytest.raises(NotImplementedError):
+        EncoderRNN(E, H, rnn_cell="lstm", variable_lengths=True).to(dev)(T(g["x"], dev), input_lengths=[L] * B)
+
+
+@pytest.mark.parametrize("B,L,E,H", [(70, 6, 40, 64), (33, 4, 24, 512)])
+def test_lstm_layer_vs_oracle(dev, B, L, E, H):
+    """Larger LSTM shapes (several row groups / unit slices, the H=512 compile-time variant) against torch's CPU
+    nn.LSTM (the ATen kernels the reference calls) with the weights rounded to bf16 as the MFMA operands are."""
+    from pevae_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    ref = torch.nn.LSTM(E, H, batch_first=True)
+    for p in ref.parameters():
+        p.data = bf(torch.empty_like(p).uniform_(-0.08, 0.08, generator=gen))
+    x = bf(torch.randn(B, L, E, generator=gen))
+    h0, c0 = torch.randn(B, H, generator=gen) * 0.5, torch.randn(B, H, generator=gen) * 0.5
+    w_o, w_h, w_c = torch.randn(B, L, H, generator=gen), torch.randn(B, H, generator=gen), torch.randn(B, H, generator=gen)
+    xr, hr, cr = x.clone().requires_grad_(), h0.clone().requires_grad_(), c0.clone().requires_grad_()
+    o_r, (hn_r, cn_r) = ref(xr, (hr.unsqueeze(0), cr.unsqueeze(0)))
+    ((o_r * w_o).sum() + (hn_r[0] * w_h).sum() + (cn_r[0] * w_c).sum()).backward()
+    prm = [p.detach().clone().to(dev).requires_grad_() for p in (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)]
+    xg, hg, cg = x.to(dev).requires_grad_(), h0.to(dev).requires_grad_(), c0.to(dev).requires_grad_()
+    out, hn, cn, _ = ops.LSTMLayer.apply(xg, hg, cg, *prm, True)
+    ((out * w_o.to(dev)).sum() + (hn * w_h.to(dev)).sum() + (cn * w_c.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    assert relmax(out, o_r.detach()) < 2e-2 and relmax(hn, hn_r[0].detach()) < 2e-2 and relmax(cn, cn_r[0].detach()) < 2e-2
+    assert relmax(xg.grad, xr.grad) < 4e-2 and relmax(hg.grad, hr.grad) < 4e-2 and relmax(cg.grad, cr.grad) < 4e-2
+    for p, q, n in zip(prm, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0), "w_ih w_hh b_ih b_hh".split()):
+        assert relmax(p.grad, q.grad) < 4e-2, n
+
+
 def test_encoder_varlen(dev):
     """variable_lengths=True (encoders.py:55-65): golden from the reference's pack_padded path; gradients against the
     oracle evaluated on the same bf16-rounded MFMA operands."""
@@ -86,7 +140,7 @@ def test_encoder_varlen(dev):
     assert out.shape[1] == max(lens)
     assert relmax(out, g["out"][:, :max(lens)]) < 3e-2 and relmax(hn, g["hn"]) < 3e-2      # bf16 operands vs fp32 golden
     for b, n in enumerate(lens):
-        assert float(out[b, n:].abs().max()) == 0.0 if n < out.shape[1] else True          # zero past each length
+        assert float(out.detach()[b, n:].abs().max()) == 0.0 if n < out.shape[1] else True          # zero past each length
     ref = load_params(R.EncoderRNN(8, 16, variable_lengths=True), g)
     xr = T(g["x"]).requires_grad_()
     o_r, h_r = ref(xr, input_lengths=lens)
@@ -151,6 +205,27 @@ def test_decoder_teacher_forcing(dev, tag, kw, lat):
     for (k, p), (k2, p2) in zip(dec.named_parameters(), ref.named_parameters()):
         assert k == k2
         assert relmax(p.grad, p2.grad.numpy()) < 5e-2, k
+
+
+def test_decoder_teacher_forcing_lstm(dev):
+    """rnn_cell='lstm' through DecoderRNN (decoders.py:214-223: tuple state): golden log-probs, (h, c), gradients."""
+    from pevae_amd.enc2dec import decoders as D
+    from pevae_amd import ops
+    g = load_golden("decoder_tf_lstm")
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="lstm", use_gpu=True, embedding=emb), g).to(dev)
+    h0, c0 = T(g["h0"], dev).requires_grad_(), T(g["c0"], dev).requires_grad_()
+    outs, (hid, hid_c), ret = dec(B, T(g["ids"], dev), (h0, c0), mode=D.TEACH_FORCE)
+    logp = outs.materialize()
+    (logp * T(g["w"], dev)).sum().backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    close(logp, g["logp"], rtol=0, atol=3e-2)
+    close(hid, g["hid"], rtol=0, atol=3e-2)
+    close(hid_c, g["hid_c"], rtol=0, atol=3e-2)
+    assert relmax(h0.grad, g["dh0"]) < 4e-2 and relmax(c0.grad, g["dc0"]) < 4e-2
+    check_grads(dec, g, 4e-2)
 
 
 @pytest.mark.parametrize("tag,mask_unk", [("greedy", False), ("greedy_maskunk", True)])
