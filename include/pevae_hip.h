@@ -173,8 +173,10 @@ int pv_layernorm_bwd(const float* x, const float* y, const float* gamma, const f
 int pv_spectral_norm(const float* W, float* u, float* v, int n_out, int n_in, float eps, int do_iter, float* inv_sigma,
                      void* stream);
 /* Multi-tensor form: `descs` is a device array of `count` records {const float* W; float* u; float* v;
- * float* inv_sigma; int64 n_out; int64 n_in} (48 bytes each); one workgroup per weight, one launch per step. */
-int pv_spectral_norm_multi(const void* descs, int count, int max_out, int max_in, float eps, int do_iter, void* stream);
+ * float* inv_sigma; int64 n_out; int64 n_in; float* Wt} (56 bytes each); one workgroup per weight, one launch per step.
+ * transpose != 0: records with Wt != NULL also get Wt [n_in][n_out] = W^T (the weight layout pv_block_fwd streams). */
+int pv_spectral_norm_multi(const void* descs, int count, int max_out, int max_in, float eps, int do_iter, int transpose,
+                           void* stream);
 /* One pass over dy: db[n] (+)= sum_m dy (db may be NULL) and cpart[j] = sum over the j-th 64-column block of
  * dy * (y - bias); sum_j cpart[j] = <dL/dW_eff, W_eff>, consumed by pv_linear_f32_fused's rank-1 epilogue. */
 int pv_spectral_norm_reduce(const float* dy, const float* y, const float* bias, int M, int N, float* db,
@@ -185,6 +187,23 @@ int pv_linear_f32_fused(const float* A, long sam, long sak, const float* B, long
                         const float* r1_u, const float* r1_v, void* stream);
 int pv_spectral_norm_bwd(const float* dy, const float* y, const float* bias, long M, int n_out, int n_in, const float* u,
                          const float* v, const float* inv_sigma, float* scratch1, float* dW, void* stream);
+/* A whole Block (:253-271) per launch: a workgroup owns 16 batch rows and walks gelu -> c1 -> gelu -> c2 -> gelu ->
+ * c3 -> gelu -> c4 -> +x -> LayerNorm -> translate with the activations in LDS (every step is row-independent once
+ * 1/sigma is known).  W / bias / inv_sigma / u / v / dW / db: HOST arrays of five device pointers in the order c1, c2,
+ * c3, c4, translate (weight_orig [out][in]; pv_block_fwd takes the TRANSPOSED copies Wt [in][out] written by
+ * pv_spectral_norm_multi, so that every weight access of both passes is a contiguous 256-byte run).  Widths must be multiples of 16 and <= 512.  pv_block_layout gives the
+ * per-row float counts of `save` (activations kept for the backward pass), `dY` (gradients of the four inner linears)
+ * and of one workgroup's row in `ppart` (cdiv(M,16) rows); `cpart` holds 5 * cdiv(M,16) floats.  pv_block_bwd writes dx
+ * and (accumulate != 0: adds to) every parameter gradient, including the spectral-norm rank-1 term of the weights. */
+int pv_block_layout(int Din, int mid, int Dout, int* save_width, int* grad_width, int* part_width);
+int pv_block_fwd(const float* x, long ldx, int M, int Din, int mid, int Dout, const float* const* Wt,
+                 const float* const* bias, const float* const* inv_sigma, const float* gamma, const float* beta, float eps,
+                 float* save, float* mean, float* rstd, float* out, long ldo, void* stream);
+int pv_block_bwd(const float* dout, long lddo, const float* x, long ldx, const float* out, long ldo, int M, int Din,
+                 int mid, int Dout, const float* const* W, const float* const* bias, const float* const* inv_sigma,
+                 const float* gamma, const float* save, const float* mean, const float* rstd, float* dx, long lddx,
+                 float* dY, float* cpart, float* ppart, const float* const* u, const float* const* v, float* const* dW,
+                 float* const* db, float* dgamma, float* dbeta, int accumulate, void* stream);
 /* DLS_Auto.cons_loss (:3266-3272): row L2 normalisation and the symmetric InfoNCE over a [B][B] score matrix with
  * the diagonal as targets: loss = (CE(log_softmax rows) + CE(log_softmax columns)) / 2. */
 int pv_l2norm_rows_fwd(const float* x, int rows, int D, float* a, float* nrm, void* stream);

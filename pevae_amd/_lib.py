@@ -31,6 +31,10 @@ SIGNATURES = {
     "pv_gru_sync_bytes": (sz, [i32]),
     "pv_gru_fwd": (i32, [vp, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     "pv_gru_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "pv_block_layout": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "pv_block_fwd": (i32, [vp, lng, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, lng, vp]),
+    "pv_block_bwd": (i32, [vp, lng, vp, lng, vp, lng, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, lng, vp, vp, vp,
+                           vp, vp, vp, vp, vp, vp, i32, vp]),
     "pv_lstm_geometry": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "pv_lstm_fwd": (i32, [vp, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pv_lstm_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
@@ -53,7 +57,7 @@ SIGNATURES = {
     "pv_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     "pv_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp]),
     "pv_spectral_norm": (i32, [vp, vp, vp, i32, i32, f32, i32, vp, vp]),
-    "pv_spectral_norm_multi": (i32, [vp, i32, i32, i32, f32, i32, vp]),
+    "pv_spectral_norm_multi": (i32, [vp, i32, i32, i32, f32, i32, i32, vp]),
     "pv_spectral_norm_reduce": (i32, [vp, vp, vp, i32, i32, vp, i32, vp, vp]),
     "pv_linear_f32_fused": (i32, [vp, lng, lng, vp, lng, lng, vp, vp, lng, i32, i32, i32, f32, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
     "pv_spectral_norm_bwd": (i32, [vp, vp, vp, lng, i32, i32, vp, vp, vp, vp, vp, vp]),

@@ -130,6 +130,7 @@ struct SnDesc {             // one spectral-norm weight (device array for the mu
   float* v;
   float* inv_sigma;
   long n_out, n_in;
+  float* Wt;                // optional [n_in][n_out]: W^T, rewritten every call (operand layout of pv_block_fwd)
 };
 
 __device__ __forceinline__ void spectral_iter_body(const float* __restrict__ W, float* __restrict__ u,
@@ -205,6 +206,31 @@ __global__ __launch_bounds__(256) void spectral_iter_kernel(const float* __restr
 __global__ __launch_bounds__(256) void spectral_iter_multi_kernel(const SnDesc* __restrict__ desc, float eps, int do_iter) {
   const SnDesc d = desc[blockIdx.x];
   spectral_iter_body(d.W, d.u, d.v, (int)d.n_out, (int)d.n_in, eps, do_iter, d.inv_sigma);
+}
+
+// W^T of every described weight (32x32 tiles through LDS; blockIdx.y = weight, blockIdx.x walks its tiles)
+__global__ __launch_bounds__(256) void sn_transpose_multi_kernel(const SnDesc* __restrict__ desc) {
+  __shared__ float tile[32][33];
+  const SnDesc d = desc[blockIdx.y];
+  if (!d.Wt) return;
+  const int n_out = (int)d.n_out, n_in = (int)d.n_in;
+  const int tx = (n_in + 31) / 32, ty = (n_out + 31) / 32;
+  const int cx = threadIdx.x & 31, cy = threadIdx.x >> 5;           // 32 x 8
+  for (int t = blockIdx.x; t < tx * ty; t += gridDim.x) {
+    const int i0 = (t / tx) * 32, j0 = (t % tx) * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + cy + 8 * r, j = j0 + cx;
+      if (i < n_out && j < n_in) tile[cy + 8 * r][cx] = d.W[(size_t)i * n_in + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = j0 + cy + 8 * r, i = i0 + cx;
+      if (i < n_out && j < n_in) d.Wt[(size_t)j * n_out + i] = tile[cx][cy + 8 * r];
+    }
+    __syncthreads();
+  }
 }
 
 // One pass over dy for a spectral-norm linear's backward: db[n] (+)= sum_m dy[m][n] and, per 64-column block,
@@ -360,14 +386,21 @@ int pv_spectral_norm(const float* W, float* u, float* v, int n_out, int n_in, fl
   return PV_OK;
 }
 
-/* descs: device array of {W, u, v, inv_sigma (pointers), n_out, n_in (int64)} records, 48 bytes each */
-int pv_spectral_norm_multi(const void* descs, int count, int max_out, int max_in, float eps, int do_iter, void* stream) {
+/* descs: device array of {W, u, v, inv_sigma (pointers), n_out, n_in (int64), Wt (pointer or 0)} records, 56 bytes each */
+int pv_spectral_norm_multi(const void* descs, int count, int max_out, int max_in, float eps, int do_iter, int transpose,
+                           void* stream) {
   PV_REQUIRE(descs && count > 0 && max_out > 0 && max_in > 0, "pv_spectral_norm_multi: bad argument");
   const size_t smem = (size_t)(2 * max_out + max_in + 4) * sizeof(float);
   PV_REQUIRE(smem <= 64 * 1024, "pv_spectral_norm_multi: %d x %d exceeds the 64 KiB LDS staging", max_out, max_in);
   hipLaunchKernelGGL(spectral_iter_multi_kernel, dim3(count), dim3(256), smem, (hipStream_t)stream, (const SnDesc*)descs,
                      eps, do_iter);
   PV_LAUNCH_CHECK("spectral_iter_multi_kernel");
+  if (transpose) {
+    const int tiles = cdiv(max_out, 32) * cdiv(max_in, 32);
+    hipLaunchKernelGGL(sn_transpose_multi_kernel, dim3(tiles < 64 ? tiles : 64, count), dim3(256), 0, (hipStream_t)stream,
+                       (const SnDesc*)descs);
+    PV_LAUNCH_CHECK("sn_transpose_multi_kernel");
+  }
   return PV_OK;
 }
 

@@ -1,0 +1,805 @@
+// One launch per Block forward, three per Block backward (dialog_models.py:253-271).
+//
+// A Block is  out = translate(LayerNorm(x + c4(gelu(c3(gelu(c2(gelu(c1(gelu(x))))))))))  with five spectral-norm
+// linears.  At batch 256 every one of its GEMMs is a few hundred kFLOP..MFLOP: run as separate launches the step
+// spends its time in launch boundaries and dependent memory round trips (~600 launches of 3-10 us for the whole DLS
+// latent stack).  Every operation of the Block is ROW-independent once 1/sigma of each weight is known (the
+// multi-tensor power iteration runs before, pv_spectral_norm_multi), so a workgroup that owns 16 batch rows can walk
+// the whole Block without talking to any other workgroup: activations stay in LDS, weights stream from L2 straight
+// into MFMA B-operand registers (16 workgroups share them), and the only global traffic besides the weights is the
+// activations the backward pass needs.
+//
+//   block_fwd_kernel   : x -> out, saving a0 = gelu(x), y1, a1, y2, a2, y3, a3, y4, o = LN(x + y4), mean, rstd
+//   block_bwd_dx_kernel: dL/dout -> dL/dx, storing dy1..dy4 for the weight gradients and, per workgroup, partial
+//                        column sums (bias / LayerNorm parameter gradients) and partial <dy, y - b> (spectral term)
+//   block_param_reduce_kernel: fixed-order sum of the per-workgroup partials into the bias / gamma / beta gradients
+//   (+ pv_linear_f32_group: the five weight-gradient GEMMs dy^T a with the spectral rank-1 epilogue, one launch)
+//
+// Arithmetic: exact fp32 (v_mfma_f32_16x16x4_f32), like the unfused path; sums run in a different order.
+#include "common.h"
+#include "linear_group.h"
+#include "../../include/pevae_hip.h"
+
+namespace {
+
+constexpr int RB = 16;          // batch rows per workgroup = one MFMA row tile
+constexpr int NTC = 256;        // compute threads: waves 0-3
+constexpr int NT = 320;         // + wave 4, the storer
+
+struct BlockDesc {
+  const float* W[5];            // c1, c2, c3, c4, translate: weight_orig [out][in] row-major
+  const float* bias[5];
+  const float* inv_sigma[5];    // device scalars (1 / sigma)
+  const float* gamma;
+  const float* beta;
+  int Din, mid, Dout;
+  float eps;
+};
+
+// erf to ~1 ulp, branch-free (both ranges are evaluated and selected): at one wave per SIMD a library erff is a
+// ~100-deep dependent chain with data-dependent branches, which made GELU the largest cost of these kernels; straight-
+// line code lets the compiler interleave the chains of a lane's independent elements.  Two minimax polynomials
+// (|x| <= 0.927734375: odd polynomial in x; above: 1 - exp(p(|x|))), the split and degrees of the widely used
+// single-precision erf of N. Juffa.
+__device__ __forceinline__ float erf_fast(float a) {
+  const float t = fabsf(a), s = a * a;
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  r = copysignf(1.0f - __expf(r), a);
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  q = fmaf(q, a, a);
+  return t > 0.927734375f ? r : q;
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float x) {
+  return 0.5f * (1.f + erf_fast(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for this wave's global stores (the saved
+// activations), a write round trip per layer that nothing here depends on.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// sum over the 16 lanes that share lane >> 4 (every lane gets the result)
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Diagnostic build only (-DPV_BLOCK_STAMPS, `make stamps`): wave 0 of workgroup 0 records the wall clock (100 MHz) at
+// phase boundaries; read back with pv_block_stamps_read.  Never compiled into the shipped library.
+#ifdef PV_BLOCK_STAMPS
+__device__ unsigned long long g_block_stamps[2][32];
+#define BSTAMP_DECL(ptr) unsigned long long* bst = (unsigned long long*)(ptr);
+#define BSTAMP(k, i)                                                  \
+  do {                                                                \
+    if (k == 0 && threadIdx.x == 0) bst[i] = wall_clock64();          \
+  } while (0)
+#define BSTAMP_FLUSH(k)                                                                 \
+  do {                                                                                  \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                                            \
+      for (int i__ = 0; i__ < 16; ++i__) g_block_stamps[k][i__] = bst[i__];             \
+  } while (0)
+#else
+#define BSTAMP_DECL(ptr)
+#define BSTAMP(k, i)
+#define BSTAMP_FLUSH(k)
+#endif
+
+// offsets (floats per row) of the saved activations
+struct SaveLayout {
+  int a0, y1, a1, y2, a2, y3, a3, y4, o, width;
+  __host__ __device__ SaveLayout(int Din, int mid) {
+    a0 = 0; y1 = Din; a1 = 2 * Din; y2 = 3 * Din; a2 = y2 + mid; y3 = a2 + mid; a3 = y3 + mid; y4 = a3 + mid;
+    o = y4 + Din; width = o + Din;
+  }
+};
+// dY row: dy1 (Din) | dy2 (mid) | dy3 (mid) | dy4 (Din)
+struct GradLayout {
+  int d1, d2, d3, d4, width;
+  __host__ __device__ GradLayout(int Din, int mid) { d1 = 0; d2 = Din; d3 = Din + mid; d4 = Din + 2 * mid; width = 2 * Din + 2 * mid; }
+};
+// per-workgroup partial row: db1 (Din) | db2 (mid) | db3 (mid) | db4 (Din) | dbt (Dout) | dgamma (Din) | dbeta (Din)
+struct PartLayout {
+  int b1, b2, b3, b4, bt, dg, dbe, width;
+  __host__ __device__ PartLayout(int Din, int mid, int Dout) {
+    b1 = 0; b2 = Din; b3 = b2 + mid; b4 = b3 + mid; bt = b4 + Din; dg = bt + Dout; dbe = dg + Din; width = dbe + Din;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// One layer of the calling wave:  out[16][N] = in[16][K] * Wop  with, FWD: Wop[k][n] = W[n*K + k] (y = a W^T), else
+// Wop[k][n] = W[k*N + n] (dx = dy W).  A wave works on 64-column super-tiles n0 = 64*w, 64*(w+4), ...; the lane
+// (c16, q4) owns columns n0 + 4*c16 + e (e = 0..3, one accumulator each) and, inside a 16-deep k chunk, supplies
+// k = 4*q4 + j at MFMA step j for BOTH operands (a k permutation common to A and B), so every operand access is one
+// 16-byte load:
+//   FWD: p[e] + ch*16       -> W[col e][16*ch + 4*q4 .. +3]          (element j = step j)
+//   BWD: p[j] + ch*16*N     -> W[16*ch + 4*q4 + j][n0 + 4*c16 .. +3] (element e = accumulator e)
+// Columns past N use clamped (valid) addresses; their results are dropped by the epilogue.
+//
+// Weights stream global -> VGPR through a ring of RD chunks: the slot a chunk's 16 MFMAs have just read is refilled
+// with the chunk RD ahead (clamped to the last one: no load sits under a condition), so ~4000 MFMA cycles of loads are
+// in flight (measured: with 4 chunks the layers ran at 2.2x their MFMA time, bound by HBM latency x bytes in flight).  After the last k loop of a layer the ring is refilled with the NEXT layer's first chunks, whose
+// latency then hides behind the epilogue and the barrier.  The code is kept SMALL on purpose (one copy of this function
+// per kernel, layers walked by a run-time loop): a first version with one inlined copy per layer was instruction-fetch
+// bound (a workgroup runs through its code once).
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef PV_BLOCK_ABL
+#define PV_BLOCK_ABL 0           // timing ablations of the diagnostic build: 1 = no weight refills, 2 = no MFMAs
+#endif
+constexpr int RD = 4;            // ring depth in chunks: 16 loads of 16 bytes per lane in flight (8 measured no faster)
+
+// Where a lane finds its B-operand values: Wop[k][n] = W[k*N + n] (a [K][N] row-major matrix: the weight itself for
+// dx = dy W, its transposed copy for y = a W^T).  p[j] + ch*16*N -> W[16*ch + 4*q4 + j][n0 + 4*c16 .. +3]: a 16-lane
+// group reads 256 contiguous bytes (element e = accumulator e).
+struct WPtr {
+  const float* p[4];
+  long step;
+};
+
+__device__ __forceinline__ WPtr wptr(const float* __restrict__ W, int N, int n0, int c16, int q4) {
+  WPtr s;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s.p[j] = W + (size_t)(4 * q4 + j) * N + min(n0 + 4 * c16, N - 4);
+  s.step = (long)16 * N;
+  return s;
+}
+
+__device__ __forceinline__ void ring_fill(const WPtr& s, int nch, f32x4 (&ring)[RD][4]) {
+#pragma unroll
+  for (int t = 0; t < RD; ++t) {
+    const long o = (long)min(t, nch - 1) * s.step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ring[t][i] = *(const f32x4*)(s.p[i] + o);
+  }
+}
+
+// One layer of the calling compute wave:  out[16][N] = in[16][K] * Wop,  Wop [K][N] row-major.  `in` is the LDS image
+// [16][LD] of the layer input.  A wave works on 64-column super-tiles n0 = 64*w, 64*(w+4), ...; the lane (c16, q4) owns
+// columns n0 + 4*c16 + e (e = 0..3, one accumulator each) and, inside a 16-deep k chunk, supplies k = 4*q4 + j at MFMA
+// step j for BOTH operands (a k permutation common to A and B), so every operand access is one 16-byte load.  Columns
+// past N use clamped (valid) addresses; their results are dropped by the epilogue.
+//
+// Weights stream global -> VGPR through a ring of RD chunks: the slot a chunk's 16 MFMAs have just read is refilled
+// with the chunk RD ahead (clamped to the last one: no load sits under a condition).  On entry the ring holds chunks
+// 0..RD-1 of super-tile n0 = 64*w (requested by the previous layer / the prologue); after the last k loop it is
+// refilled with the NEXT layer's first chunks (Wn, Nn, Kn; Wn == nullptr: none), whose latency hides behind the
+// epilogue and the barrier.  pre(n0) runs before a super-tile's k loop (issue the epilogue's global loads there);
+// epi(acc, n0): acc[e][j] = out[row 4*q4 + j][col n0 + 4*c16 + e].
+// The code is kept SMALL on purpose (one copy per kernel, layers walked by a run-time loop).
+template <class Pre, class Epi>
+__device__ __forceinline__ void dense16(const float* __restrict__ in, const int LD, const float* __restrict__ W, const int N,
+                                        const int K, const float* __restrict__ Wn, const int Nn, const int Kn, const int w,
+                                        const int lane, f32x4 (&ring)[RD][4], Pre pre, Epi epi) {
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const float* ap = in + c16 * LD + 4 * q4;
+  const int nch = K / 16;
+  for (int n0 = w * 64; n0 < N; n0 += 256) {
+    const WPtr s = wptr(W, N, n0, c16, q4);
+    if (n0 != w * 64) ring_fill(s, nch, ring);
+    pre(n0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 av = *(const f32x4*)ap;
+    for (int ch = 0; ch < nch; ch += RD) {
+#pragma unroll
+      for (int t = 0; t < RD; ++t) {
+        const int c = ch + t;
+        const f32x4 avn = *(const f32x4*)(ap + min(c + 1, nch - 1) * 16);
+        if (c < nch) {
+#if PV_BLOCK_ABL == 2
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ring[t][i]), "v"(av));
+#else
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], ring[t][j][e], acc[e], 0, 0, 0);
+#endif
+        }
+#if PV_BLOCK_ABL != 1
+        const long o = (long)min(c + RD, nch - 1) * s.step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[t][i] = *(const f32x4*)(s.p[i] + o);
+#endif
+        av = avn;
+      }
+    }
+    if (n0 + 256 >= N && Wn) ring_fill(wptr(Wn, Nn, w * 64, c16, q4), Kn / 16, ring);
+    epi(acc, n0);
+  }
+  if (w * 64 >= N && Wn) ring_fill(wptr(Wn, Nn, w * 64, c16, q4), Kn / 16, ring);   // idle wave this layer
+}
+
+// ---- the storer wave's helpers (wave 4: every global store of saved state leaves from here, so that no compute wave
+// ever has a slow store queued in front of a weight load it waits for: vmcnt retires in issue order) ----------------
+__device__ __forceinline__ void wave_copy_out(const float* __restrict__ buf, int LD, float* __restrict__ g, size_t gs,
+                                              int ncols, int r0, int M, int lane) {
+  const int nq = RB * ncols / 4, per = ncols / 4;
+  for (int i = lane; i < nq; i += 64) {
+    const int row = i / per, c4 = (i % per) * 4;
+    if (r0 + row < M) *(f32x4*)(g + (size_t)(r0 + row) * gs + c4) = *(const f32x4*)(buf + row * LD + c4);
+  }
+}
+// column sums over the workgroup's 16 rows of an LDS image (rows past M hold zeros)
+__device__ __forceinline__ void wave_colsum(const float* __restrict__ buf, int LD, int N, float* __restrict__ dst, int lane) {
+  for (int c = lane * 4; c < N; c += 256) {
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < RB; ++r) sum += *(const f32x4*)(buf + r * LD + c);
+    *(f32x4*)(dst + c) = sum;
+  }
+}
+// biases / gamma / beta -> LDS (PartLayout offsets), all loads of the wave issued before the first LDS write
+__device__ __forceinline__ void wave_stage_params(const BlockDesc& d, const PartLayout& P, float* par, int lane) {
+  const int nq = P.width / 4;                     // <= 704 for widths <= 512
+  const float* src[7] = {d.bias[0], d.bias[1], d.bias[2], d.bias[3], d.bias[4], d.gamma, d.beta};
+  const int beg[8] = {P.b1, P.b2, P.b3, P.b4, P.bt, P.dg, P.dbe, P.width};
+  f32x4 v[11];
+#pragma unroll
+  for (int u = 0; u < 11; ++u) {
+    const int c = min(lane + 64 * u, nq - 1) * 4;
+    const float* ptr = src[0] + c;
+#pragma unroll
+    for (int k = 1; k < 7; ++k)
+      if (c >= beg[k]) ptr = src[k] + (c - beg[k]);
+    v[u] = *(const f32x4*)ptr;
+  }
+#pragma unroll
+  for (int u = 0; u < 11; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nq) *(f32x4*)(par + i * 4) = v[u];
+  }
+  if (lane < 5) par[P.width + lane] = d.inv_sigma[lane][0];
+}
+
+struct BlockFwdArgs {
+  const float* x;
+  long ldx;
+  int M;
+  BlockDesc d;      // d.W: the TRANSPOSED effective-layout copies W_i^T [in][out] (from pv_spectral_norm_multi)
+  float* save;      // [M][SaveLayout.width]
+  float* mean;      // [M]
+  float* rstd;      // [M]
+  float* out;       // [M][ldo]
+  long ldo;
+  int LD;           // LDS row stride (floats) = max width + 4
+};
+
+__global__ __launch_bounds__(NT) void block_fwd_kernel(BlockFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, q4 = lane >> 4;
+  const bool compute = w < 4;
+  const int Din = a.d.Din, mid = a.d.mid, Dout = a.d.Dout, LD = a.LD, M = a.M;
+  const int r0 = blockIdx.x * RB;
+  float* buf0 = lds;
+  float* buf1 = lds + RB * LD;
+  float* yb0 = lds + 2 * RB * LD;                 // the layer's pre-activation y, parked for the storer wave
+  float* yb1 = lds + 3 * RB * LD;
+  float* par = lds + 4 * RB * LD;
+  const SaveLayout L(Din, mid);
+  const PartLayout P(Din, mid, Dout);
+  const float* isg = par + P.width;
+  float* rowstat = par + P.width + 8;             // mean[16], rstd[16]
+  const size_t SW = L.width;
+  BSTAMP_DECL(par + P.width + 8 + 2 * RB)
+  BSTAMP(0, 0);
+#ifdef PV_BLOCK_STAMPS
+  if (threadIdx.x == 0) bst[14] = clock64();
+#endif
+
+  f32x4 ring[RD][4];
+  if (compute) {
+    ring_fill(wptr(a.d.W[0], Din, w * 64, c16, q4), Din / 16, ring);
+    // x rows: a0 = gelu(x) -> buf0 (all of a thread's loads are issued first: widths <= 512 -> at most 8 per thread)
+    const int nq = RB * Din / 4, per = Din / 4;
+    f32x4 xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(tid + u * NTC, nq - 1);
+      xv[u] = *(const f32x4*)(a.x + (size_t)min(r0 + i / per, M - 1) * a.ldx + (i % per) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * NTC;
+      if (i < nq) {
+        const f32x4 v = xv[u];
+        *(f32x4*)(buf0 + (i / per) * LD + (i % per) * 4) = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+      }
+    }
+  } else {
+    wave_stage_params(a.d, P, par, lane);
+  }
+  lds_barrier();
+  BSTAMP(0, 1);
+
+  // layers c1, c2, c3 (y -> yb, gelu(y) -> next input), c4 (y -> yb, x + y -> LayerNorm input), translate (-> out);
+  // the storer wave runs one layer behind: it writes out what the previous layer left in LDS.
+  for (int li = 0; li < 5; ++li) {
+    const int N = li == 0 || li == 3 ? Din : (li == 4 ? Dout : mid);
+    const int K = li == 0 || li == 1 || li == 4 ? Din : mid;
+    const int Nn = li == 0 || li == 1 ? mid : (li == 2 ? Din : Dout), Kn = li == 0 || li == 3 ? Din : mid;
+    const float* in = li == 4 ? buf1 : ((li & 1) ? buf1 : buf0);
+    float* outb = (li & 1) ? buf0 : buf1;
+    float* yb = (li & 1) ? yb1 : yb0;
+    if (compute) {
+      const float* Wn = li < 4 ? a.d.W[li + 1] : nullptr;
+      const int off_b = li == 0 ? P.b1 : li == 1 ? P.b2 : li == 2 ? P.b3 : li == 3 ? P.b4 : P.bt;
+      const float is = isg[li];
+      f32x4 xs[4];
+      dense16(in, LD, a.d.W[li], N, K, Wn, Nn, Kn, w, lane, ring,
+              [&](int n0) __attribute__((always_inline)) {
+                if (li != 3) return;                  // the residual input, requested before the k loop
+                const int col = min(n0 + 4 * c16, N - 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  xs[j] = *(const f32x4*)(a.x + (size_t)min(r0 + q4 * 4 + j, M - 1) * a.ldx + col);
+              },
+              [&](f32x4 (&acc)[4], int n0) __attribute__((always_inline)) {
+                const int col = n0 + 4 * c16;
+                if (col >= N) return;
+                const f32x4 bv = *(const f32x4*)(par + off_b + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const int row = q4 * 4 + j, gr = r0 + row;
+                  const f32x4 y = {acc[0][j] * is + bv[0], acc[1][j] * is + bv[1], acc[2][j] * is + bv[2],
+                                   acc[3][j] * is + bv[3]};
+                  if (li < 3) {
+                    *(f32x4*)(yb + row * LD + col) = y;
+                    *(f32x4*)(outb + row * LD + col) = f32x4{gelu_f(y[0]), gelu_f(y[1]), gelu_f(y[2]), gelu_f(y[3])};
+                  } else if (li == 3) {
+                    *(f32x4*)(yb + row * LD + col) = y;
+                    *(f32x4*)(buf0 + row * LD + col) = xs[j] + y;
+                  } else if (gr < M) {
+                    *(f32x4*)(a.out + (size_t)gr * a.ldo + col) = y;
+                  }
+                }
+              });
+    } else {
+      if (li == 0) {
+        wave_copy_out(buf0, LD, a.save + L.a0, SW, Din, r0, M, lane);
+      } else if (li < 4) {
+        // outputs of layer li - 1: y in the other yb, gelu(y) in this layer's input
+        const int pN = li == 1 ? Din : mid;
+        const int off_y = li == 1 ? L.y1 : li == 2 ? L.y2 : L.y3, off_a = li == 1 ? L.a1 : li == 2 ? L.a2 : L.a3;
+        wave_copy_out((li & 1) ? yb0 : yb1, LD, a.save + off_y, SW, pN, r0, M, lane);
+        wave_copy_out(in, LD, a.save + off_a, SW, pN, r0, M, lane);
+      } else {
+        wave_copy_out(buf1, LD, a.save + L.o, SW, Din, r0, M, lane);
+        if (lane < RB && r0 + lane < M) {
+          a.mean[r0 + lane] = rowstat[lane];
+          a.rstd[r0 + lane] = rowstat[RB + lane];
+        }
+      }
+    }
+    BSTAMP(0, 2 + 2 * li);
+    if (li == 4) break;
+    lds_barrier();
+    BSTAMP(0, 3 + 2 * li);
+    if (li == 3) {
+      if (compute) {
+        // LayerNorm of s = x + y4 (buf0; biased variance, two passes as nn.LayerNorm) -> buf1: 16 lanes per row, the
+        // wave's four rows side by side
+        const int row = w * 4 + q4;
+        const float* srow = buf0 + row * LD;
+        float sm = 0.f;
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 v = *(const f32x4*)(srow + c);
+          sm += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        const float mu = group16_sum(sm) / Din;
+        float q = 0.f;
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 v = *(const f32x4*)(srow + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q += (v[e] - mu) * (v[e] - mu);
+        }
+        const float rs = rsqrtf(group16_sum(q) / Din + a.d.eps);
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 v = *(const f32x4*)(srow + c), gm = *(const f32x4*)(par + P.dg + c), bt = *(const f32x4*)(par + P.dbe + c);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu) * rs * gm[e] + bt[e];
+          *(f32x4*)(buf1 + row * LD + c) = o;
+        }
+        if (c16 == 0) {
+          rowstat[row] = mu;
+          rowstat[RB + row] = rs;
+        }
+      } else {
+        wave_copy_out(yb1, LD, a.save + L.y4, SW, Din, r0, M, lane);
+      }
+      lds_barrier();
+      BSTAMP(0, 12);
+    }
+  }
+#ifdef PV_BLOCK_STAMPS
+  if (threadIdx.x == 0) bst[15] = clock64();
+#endif
+  BSTAMP_FLUSH(0);
+}
+
+struct BlockBwdArgs {
+  const float* dout;   // [M][lddo]   dL/d out
+  long lddo;
+  const float* x;      // [M][ldx]
+  long ldx;
+  const float* out;    // [M][ldo]    forward output (for the translate layer's spectral term)
+  long ldo;
+  int M;
+  BlockDesc d;         // d.W: weight_orig [out][in]
+  const float* save;
+  const float* mean;
+  const float* rstd;
+  float* dx;           // [M][lddx]
+  long lddx;
+  float* dY;           // [M][GradLayout.width]
+  float* cpart;        // [5][nwg]   partial <dy_i, y_i - b_i>
+  float* ppart;        // [nwg][PartLayout.width]
+  int LD;
+};
+
+__global__ __launch_bounds__(NT) void block_bwd_dx_kernel(BlockBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, q4 = lane >> 4;
+  const bool compute = w < 4;
+  const int Din = a.d.Din, mid = a.d.mid, Dout = a.d.Dout, LD = a.LD, M = a.M;
+  const int r0 = blockIdx.x * RB, nwg = gridDim.x;
+  float* buf0 = lds;
+  float* buf1 = lds + RB * LD;
+  float* buf2 = lds + 2 * RB * LD;
+  float* sbuf = lds + 3 * RB * LD;                              // s = x + y4 (the LayerNorm input)
+  float* par = lds + 4 * RB * LD;
+  const SaveLayout L(Din, mid);
+  const GradLayout G(Din, mid);
+  const PartLayout P(Din, mid, Dout);
+  const float* isg = par + P.width;
+  float* rowstat = par + P.width + 8;                           // mean[16], rstd[16]
+  float (*cred)[5] = (float (*)[5])(par + P.width + 8 + 2 * RB);   // [4 waves][5]: <dy_i, y_i - b_i>, i = c1..c4, translate
+  volatile int* flag = (volatile int*)(par + P.width + 8 + 2 * RB + 20);   // storer -> compute: LayerNorm column sums read
+  const size_t SW = L.width, GW = G.width;
+  float* prow = a.ppart + (size_t)blockIdx.x * P.width;
+
+  f32x4 ring[RD][4];
+  if (compute) {
+    ring_fill(wptr(a.d.W[4], Din, w * 64, c16, q4), Dout / 16, ring);
+    // dL/dout rows -> buf0 (zero past M) with the translate layer's spectral term; s = x + y4 -> sbuf.  Loads first.
+    const int nqo = RB * Dout / 4, pero = Dout / 4, nqi = RB * Din / 4, peri = Din / 4;
+    f32x4 dv[8], ov[8], bv[8], xv[8], yv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(tid + u * NTC, nqo - 1), gr = min(r0 + i / pero, M - 1), c4 = (i % pero) * 4;
+      dv[u] = *(const f32x4*)(a.dout + (size_t)gr * a.lddo + c4);
+      ov[u] = *(const f32x4*)(a.out + (size_t)gr * a.ldo + c4);
+      bv[u] = *(const f32x4*)(a.d.bias[4] + c4);
+      const int k = min(tid + u * NTC, nqi - 1), gk = min(r0 + k / peri, M - 1), k4 = (k % peri) * 4;
+      xv[u] = *(const f32x4*)(a.x + (size_t)gk * a.ldx + k4);
+      yv[u] = *(const f32x4*)(a.save + (size_t)gk * SW + L.y4 + k4);
+    }
+    float c4s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * NTC;
+      if (i < nqo) {
+        const int row = i / pero;
+        f32x4 v = dv[u];
+        if (r0 + row >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c4s += v[e] * (ov[u][e] - bv[u][e]);
+        *(f32x4*)(buf0 + row * LD + (i % pero) * 4) = v;
+      }
+      if (i < nqi) *(f32x4*)(sbuf + (i / peri) * LD + (i % peri) * 4) = xv[u] + yv[u];
+    }
+    c4s = wave_sum(c4s);
+    if (lane == 0) cred[w][4] = c4s;
+  } else {
+    wave_stage_params(a.d, P, par, lane);
+    if (lane < RB) {
+      const int grc = min(r0 + lane, M - 1);
+      rowstat[lane] = a.mean[grc];
+      rowstat[RB + lane] = a.rstd[grc];
+    }
+    if (lane == 0) *flag = 0;
+  }
+  lds_barrier();
+
+  // step 0: do = dout W_t / sigma_t -> buf1, then the LayerNorm backward (ds = dy4 -> buf2);
+  // steps 1..3: dy_i = (dy_{i+1} W_{i+1} / sigma_{i+1}) * gelu'(y_i) for y3, y2, y1 (buffers 2 -> 0 -> 1 -> 0);
+  // step 4: dx = ds + (dy1 W_1 / sigma_1) * gelu'(x), and the c4 spectral term (y4 - b4 = s - x - b4).
+  // The storer wave runs one step behind: gradients of the inner linears -> dY, column sums -> this workgroup's
+  // partial row of the bias / LayerNorm parameter gradients.
+  for (int st = 0; st < 5; ++st) {
+    const int li = 4 - st;                                  // the linear whose weight this step multiplies by
+    const int N = st == 0 || st >= 3 ? Din : mid;
+    const int K = st == 0 ? Dout : (st == 1 || st == 4 ? Din : mid);
+    const int Nn = st == 0 || st == 1 ? mid : Din, Kn = st == 0 || st == 3 ? Din : mid;
+    const float* in = st == 0 ? buf0 : st == 1 ? buf2 : st == 2 ? buf0 : st == 3 ? buf1 : buf0;
+    float* outb = st == 0 ? buf1 : st == 1 ? buf0 : st == 2 ? buf1 : buf0;
+    if (compute) {
+      const float* Wn = st < 4 ? a.d.W[li - 1] : nullptr;
+      const int off_y = st == 1 ? L.y3 : st == 2 ? L.y2 : L.y1;
+      const int off_b = st == 1 ? P.b3 : st == 2 ? P.b2 : st == 3 ? P.b1 : P.b4;
+      // what the epilogue multiplies by gelu'(.): saved y_i (steps 1..3) or x (step 4), requested before the k loop
+      const float* pbase = st == 4 ? a.x : a.save + off_y;
+      const long pstride = st == 4 ? a.ldx : (long)SW;
+      const float is = isg[li];
+      float csum = 0.f;
+      f32x4 ys[4];
+      dense16(in, LD, a.d.W[li], N, K, Wn, Nn, Kn, w, lane, ring,
+              [&](int n0) __attribute__((always_inline)) {
+                if (st == 0) return;
+                const int col = min(n0 + 4 * c16, N - 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  ys[j] = *(const f32x4*)(pbase + (size_t)min(r0 + q4 * 4 + j, M - 1) * pstride + col);
+              },
+              [&](f32x4 (&acc)[4], int n0) __attribute__((always_inline)) {
+                const int col = n0 + 4 * c16;
+                if (col >= N) return;
+                if (st == 0) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    *(f32x4*)(outb + (q4 * 4 + j) * LD + col) = f32x4{acc[0][j] * is, acc[1][j] * is, acc[2][j] * is, acc[3][j] * is};
+                  return;
+                }
+                if (st == 1)                                 // buf0 still feeds the storer's dgamma column sums
+                  while (*flag == 0) __builtin_amdgcn_s_sleep(1);
+                const f32x4 bv = *(const f32x4*)(par + off_b + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const int row = q4 * 4 + j, gr = r0 + row;
+                  if (st < 4) {
+                    f32x4 dy = {0.f, 0.f, 0.f, 0.f};
+                    if (gr < M) {
+#pragma unroll
+                      for (int e = 0; e < 4; ++e) {
+                        dy[e] = acc[e][j] * is * gelu_df(ys[j][e]);
+                        csum += dy[e] * (ys[j][e] - bv[e]);
+                      }
+                    }
+                    *(f32x4*)(outb + row * LD + col) = dy;
+                  } else if (gr < M) {
+                    const f32x4 ds = *(const f32x4*)(buf2 + row * LD + col), sv = *(const f32x4*)(sbuf + row * LD + col);
+                    f32x4 r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                      r[e] = ds[e] + acc[e][j] * is * gelu_df(ys[j][e]);
+                      csum += ds[e] * (sv[e] - ys[j][e] - bv[e]);
+                    }
+                    *(f32x4*)(a.dx + (size_t)gr * a.lddx + col) = r;
+                  }
+                }
+              });
+      if (st > 0) {
+        csum = wave_sum(csum);
+        if (lane == 0) cred[w][st == 4 ? 3 : 3 - st] = csum;
+      }
+    } else {
+      if (st == 0) {
+        wave_colsum(buf0, LD, Dout, prow + P.bt, lane);
+      } else if (st == 1) {
+        wave_copy_out(buf2, LD, a.dY + G.d4, GW, Din, r0, M, lane);
+        wave_colsum(buf0, LD, Din, prow + P.dg, lane);
+        wave_colsum(buf1, LD, Din, prow + P.dbe, lane);
+        wave_colsum(buf2, LD, Din, prow + P.b4, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *flag = 1;
+      } else {
+        // dy of the previous step sits in this step's input
+        const int pN = st == 4 ? Din : mid;
+        const int off_d = st == 2 ? G.d3 : st == 3 ? G.d2 : G.d1, off_pb = st == 2 ? P.b3 : st == 3 ? P.b2 : P.b1;
+        wave_copy_out(in, LD, a.dY + off_d, GW, pN, r0, M, lane);
+        wave_colsum(in, LD, pN, prow + off_pb, lane);
+      }
+    }
+    lds_barrier();
+    if (st == 0) {
+      if (compute) {
+        // LayerNorm backward: ds = rstd (g - mean(g) - xhat mean(g xhat)), g = do * gamma.  buf0 <- do * xhat (for
+        // dgamma), buf1 keeps do (for dbeta), buf2 <- ds = dy4 (also the residual branch of dx)
+        const int row = w * 4 + q4;
+        const float mu = rowstat[row], rs = rowstat[RB + row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 sv = *(const f32x4*)(sbuf + row * LD + c), dv = *(const f32x4*)(buf1 + row * LD + c),
+                      gm = *(const f32x4*)(par + P.dg + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = dv[e] * gm[e];
+            s1 += g;
+            s2 += g * ((sv[e] - mu) * rs);
+          }
+        }
+        s1 = group16_sum(s1) / Din;
+        s2 = group16_sum(s2) / Din;
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 sv = *(const f32x4*)(sbuf + row * LD + c), dv = *(const f32x4*)(buf1 + row * LD + c),
+                      gm = *(const f32x4*)(par + P.dg + c);
+          f32x4 dsv, dxh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (sv[e] - mu) * rs;
+            dsv[e] = rs * (dv[e] * gm[e] - s1 - xh * s2);       // rows past M: do = 0 -> ds = 0
+            dxh[e] = dv[e] * xh;
+          }
+          *(f32x4*)(buf0 + row * LD + c) = dxh;
+          *(f32x4*)(buf2 + row * LD + c) = dsv;
+        }
+      }
+      lds_barrier();
+    }
+  }
+  if (tid < 5) a.cpart[tid * nwg + blockIdx.x] = cred[0][tid] + cred[1][tid] + cred[2][tid] + cred[3][tid];
+}
+
+struct ParamReduceArgs {
+  const float* ppart;    // [nwg][width]
+  int nwg, width;
+  int seg_end[7];        // exclusive ends of db1, db2, db3, db4, dbt, dgamma, dbeta inside a partial row
+  float* dst[7];
+  int accumulate;
+};
+
+__global__ __launch_bounds__(256) void block_param_reduce_kernel(ParamReduceArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.width) return;
+  float s = 0.f;
+  for (int g = 0; g < a.nwg; ++g) s += a.ppart[(size_t)g * a.width + c];     // fixed order
+  int seg = 0;
+  while (c >= a.seg_end[seg]) ++seg;
+  float* d = a.dst[seg] + (c - (seg ? a.seg_end[seg - 1] : 0));
+  *d = a.accumulate ? *d + s : s;
+}
+
+int check_dims(int M, int Din, int mid, int Dout, const char* who) {
+  PV_REQUIRE(M > 0 && Din > 0 && mid > 0 && Dout > 0, "%s: empty shape", who);
+  PV_REQUIRE(Din % 16 == 0 && mid % 16 == 0 && Dout % 16 == 0, "%s: widths %d/%d/%d must be multiples of 16", who, Din, mid, Dout);
+  PV_REQUIRE(Din <= 512 && mid <= 512 && Dout <= 512, "%s: widths %d/%d/%d exceed 512 (16-row LDS images)", who, Din, mid, Dout);
+  return PV_OK;
+}
+
+int fill_desc(BlockDesc& d, const float* const* W, const float* const* bias, const float* const* inv_sigma,
+              const float* gamma, const float* beta, int Din, int mid, int Dout, float eps, const char* who) {
+  PV_REQUIRE(W && bias && inv_sigma && gamma && beta, "%s: null parameter table", who);
+  for (int i = 0; i < 5; ++i) {
+    PV_REQUIRE(W[i] && bias[i] && inv_sigma[i], "%s: null parameter of linear %d", who, i);
+    PV_REQUIRE(((uintptr_t)W[i] & 15) == 0 && ((uintptr_t)bias[i] & 15) == 0, "%s: parameters must be 16-byte aligned", who);
+    d.W[i] = W[i];
+    d.bias[i] = bias[i];
+    d.inv_sigma[i] = inv_sigma[i];
+  }
+  d.gamma = gamma;
+  d.beta = beta;
+  d.Din = Din;
+  d.mid = mid;
+  d.Dout = Dout;
+  d.eps = eps;
+  return PV_OK;
+}
+
+template <class K>
+int set_lds(K kernel, size_t bytes, size_t* seen) {
+  if (bytes > *seen) {
+    PV_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    *seen = bytes;
+  }
+  return PV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+#ifdef PV_BLOCK_STAMPS
+int pv_block_stamps_read(unsigned long long* host64) {
+  PV_HIP(hipDeviceSynchronize());
+  PV_HIP(hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_block_stamps), sizeof(unsigned long long) * 64));
+  return PV_OK;
+}
+#endif
+
+int pv_block_layout(int Din, int mid, int Dout, int* save_width, int* grad_width, int* part_width) {
+  int rc = check_dims(1, Din, mid, Dout, "pv_block_layout");
+  if (rc) return rc;
+  if (save_width) *save_width = SaveLayout(Din, mid).width;
+  if (grad_width) *grad_width = GradLayout(Din, mid).width;
+  if (part_width) *part_width = PartLayout(Din, mid, Dout).width;
+  return PV_OK;
+}
+
+int pv_block_fwd(const float* x, long ldx, int M, int Din, int mid, int Dout, const float* const* Wt,
+                 const float* const* bias, const float* const* inv_sigma, const float* gamma, const float* beta, float eps,
+                 float* save, float* mean, float* rstd, float* out, long ldo, void* stream) {
+  int rc = check_dims(M, Din, mid, Dout, "pv_block_fwd");
+  if (rc) return rc;
+  PV_REQUIRE(x && save && mean && rstd && out && ldx >= Din && ldo >= Dout && ldx % 4 == 0 && ldo % 4 == 0,
+             "pv_block_fwd: bad argument");
+  PV_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)save & 15) == 0 && ((uintptr_t)out & 15) == 0,
+             "pv_block_fwd: buffers must be 16-byte aligned");
+  BlockFwdArgs a;
+  if ((rc = fill_desc(a.d, Wt, bias, inv_sigma, gamma, beta, Din, mid, Dout, eps, "pv_block_fwd"))) return rc;
+  a.x = x; a.ldx = ldx; a.M = M; a.save = save; a.mean = mean; a.rstd = rstd; a.out = out; a.ldo = ldo;
+  const int mx = Din > mid ? (Din > Dout ? Din : Dout) : (mid > Dout ? mid : Dout);
+  a.LD = mx + 4;
+  const size_t smem = ((size_t)4 * RB * a.LD + PartLayout(Din, mid, Dout).width + 8 + 2 * RB + 32) * sizeof(float);
+  static size_t seen = 0;
+  if ((rc = set_lds(block_fwd_kernel, smem, &seen))) return rc;
+  hipLaunchKernelGGL(block_fwd_kernel, dim3(cdiv(M, RB)), dim3(NT), smem, (hipStream_t)stream, a);
+  PV_LAUNCH_CHECK("block_fwd_kernel");
+  return PV_OK;
+}
+
+int pv_block_bwd(const float* dout, long lddo, const float* x, long ldx, const float* out, long ldo, int M, int Din,
+                 int mid, int Dout, const float* const* W, const float* const* bias, const float* const* inv_sigma,
+                 const float* gamma, const float* save, const float* mean, const float* rstd, float* dx, long lddx,
+                 float* dY, float* cpart, float* ppart, const float* const* u, const float* const* v, float* const* dW,
+                 float* const* db, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  int rc = check_dims(M, Din, mid, Dout, "pv_block_bwd");
+  if (rc) return rc;
+  PV_REQUIRE(dout && x && out && save && mean && rstd && dx && dY && cpart && ppart && u && v && dW && db && dgamma && dbeta,
+             "pv_block_bwd: null argument");
+  PV_REQUIRE(lddo >= Dout && ldx >= Din && ldo >= Dout && lddx >= Din && lddo % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 &&
+                 lddx % 4 == 0, "pv_block_bwd: bad leading dimension");
+  PV_REQUIRE(((uintptr_t)dout & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
+                 ((uintptr_t)save & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dY & 15) == 0,
+             "pv_block_bwd: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  BlockBwdArgs a;
+  if ((rc = fill_desc(a.d, W, bias, inv_sigma, gamma, gamma, Din, mid, Dout, 0.f, "pv_block_bwd"))) return rc;
+  a.dout = dout; a.lddo = lddo; a.x = x; a.ldx = ldx; a.out = out; a.ldo = ldo; a.M = M; a.save = save; a.mean = mean;
+  a.rstd = rstd; a.dx = dx; a.lddx = lddx; a.dY = dY; a.cpart = cpart; a.ppart = ppart;
+  const int mx = Din > mid ? (Din > Dout ? Din : Dout) : (mid > Dout ? mid : Dout);
+  a.LD = mx + 4;
+  const int nwg = cdiv(M, RB);
+  const size_t smem = ((size_t)4 * RB * a.LD + PartLayout(Din, mid, Dout).width + 8 + 2 * RB + 24 + 8) * sizeof(float);
+  static size_t seen = 0;
+  if ((rc = set_lds(block_bwd_dx_kernel, smem, &seen))) return rc;
+  hipLaunchKernelGGL(block_bwd_dx_kernel, dim3(nwg), dim3(NT), smem, st, a);
+  PV_LAUNCH_CHECK("block_bwd_dx_kernel");
+
+  const PartLayout P(Din, mid, Dout);
+  ParamReduceArgs r;
+  r.ppart = ppart; r.nwg = nwg; r.width = P.width; r.accumulate = accumulate;
+  const int ends[7] = {P.b2, P.b3, P.b4, P.bt, P.dg, P.dbe, P.width};
+  float* dsts[7] = {db[0], db[1], db[2], db[3], db[4], dgamma, dbeta};
+  for (int i = 0; i < 7; ++i) {
+    PV_REQUIRE(dsts[i], "pv_block_bwd: null parameter-gradient destination %d", i);
+    r.seg_end[i] = ends[i];
+    r.dst[i] = dsts[i];
+  }
+  hipLaunchKernelGGL(block_param_reduce_kernel, dim3(cdiv(P.width, 256)), dim3(256), 0, st, r);
+  PV_LAUNCH_CHECK("block_param_reduce_kernel");
+
+  // weight gradients: dW_i (+)= (dy_i^T a_{i-1} - <dy_i, y_i - b_i> u_i v_i^T) / sigma_i, five GEMMs in one launch
+  const SaveLayout L(Din, mid);
+  const GradLayout G(Din, mid);
+  const long SW = L.width, GW = G.width;
+  const int outs[5] = {Din, mid, mid, Din, Dout}, ins[5] = {Din, Din, mid, mid, Din};
+  const float* dys[5] = {dY + G.d1, dY + G.d2, dY + G.d3, dY + G.d4, dout};
+  const long dyld[5] = {GW, GW, GW, GW, lddo};
+  const float* acts[5] = {save + L.a0, save + L.a1, save + L.a2, save + L.a3, save + L.o};
+  LinGroupItem it[5];
+  for (int i = 0; i < 5; ++i) {
+    PV_REQUIRE(dW[i] && u[i] && v[i], "pv_block_bwd: null weight-gradient argument %d", i);
+    it[i] = LinGroupItem{dys[i], 1, dyld[i], acts[i], SW, 1, dW[i], ins[i], outs[i], ins[i], M,
+                         inv_sigma[i], accumulate, cpart + (size_t)i * nwg, nwg, u[i], v[i]};
+  }
+  return pv_linear_f32_group(it, 5, st);
+}
+
+}  // extern "C"

@@ -8,6 +8,7 @@
 // Arbitrary element strides make forward (x W^T), data-grad (dy W) and weight-grad (dy^T x) the same kernel;
 // `batch` + batch strides give the bmm forms of the attention block (decoders.py:85-107).
 #include "common.h"
+#include "linear_group.h"
 #include "../../include/pevae_hip.h"
 
 namespace {
@@ -129,15 +130,14 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const
 // so these batch-256 GEMMs are bound by how many CUs they occupy: T = 32 quadruples the workgroup count and is used
 // whenever 64x64 tiles would leave most of the chip idle.
 template <int MA, int MB, int T>
-__global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
+__device__ __forceinline__ void linear_tile(const LinArgs& g, const int m0, const int n0, const int z,
+                                            float (&lds)[2][2][TK * (T + 16)]) {
   constexpr int LS = T + 16, NR = T / 8, NF = T / 32;       // NF x NF 16x16 tiles per wave
-  __shared__ __attribute__((aligned(16))) float lds[2][2][TK * LS];      // [buffer][A|B][k][x]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
   const int i16 = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
-  const float* A = g.A + (long)blockIdx.z * g.bsa;
-  const float* B = g.B + (long)blockIdx.z * g.bsb;
-  float* C = g.C + (long)blockIdx.z * g.bsc;
+  const float* A = g.A + (long)z * g.bsa;
+  const float* B = g.B + (long)z * g.bsb;
+  float* C = g.C + (long)z * g.bsc;
   f32x4 acc[NF][NF];
 #pragma unroll
   for (int t = 0; t < NF; ++t)
@@ -233,6 +233,30 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
   }
 }
 
+template <int MA, int MB, int T>
+__global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][TK * (T + 16)];      // [buffer][A|B][k][x]
+  linear_tile<MA, MB, T>(g, blockIdx.y * T, blockIdx.x * T, blockIdx.z, lds);
+}
+
+// Several independent GEMMs of the x-fast / x-fast operand form (the weight gradients dy^T a of one Block) in ONE
+// launch: blockIdx.x walks the 32x32 tiles of item 0, then item 1, ...
+constexpr int GROUP_MAX = 5;
+struct LinGroup {
+  LinArgs g[GROUP_MAX];
+  int tile_end[GROUP_MAX];     // exclusive prefix of tile counts
+  int ntn[GROUP_MAX];          // tiles along N
+  int n;
+};
+
+__global__ __launch_bounds__(256) void linear_f32_group_kernel(LinGroup G) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][TK * 48];
+  int i = 0;
+  while (i + 1 < G.n && (int)blockIdx.x >= G.tile_end[i]) ++i;
+  const int local = blockIdx.x - (i ? G.tile_end[i - 1] : 0);
+  linear_tile<MODE_XFAST, MODE_XFAST, 32>(G.g[i], (local / G.ntn[i]) * 32, (local % G.ntn[i]) * 32, 0, lds);
+}
+
 void launch_linear(const LinArgs& g, int batch, hipStream_t st) {
   // 32x32 tiles when 64x64 tiles would occupy fewer than ~half of the CUs
   const bool small = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * batch < 128;
@@ -259,6 +283,28 @@ int pick_mode(const float* P, long sx, long sk, long bs, int batch) {
 }
 
 }  // namespace
+
+int pv_linear_f32_group(const LinGroupItem* it, int n, hipStream_t st) {
+  PV_REQUIRE(it && n > 0 && n <= GROUP_MAX, "pv_linear_f32_group: bad item count %d", n);
+  LinGroup G;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const LinGroupItem& t = it[i];
+    PV_REQUIRE(t.A && t.B && t.C && t.M > 0 && t.N > 0 && t.K > 0 && t.ldc >= t.N, "pv_linear_f32_group: bad item %d", i);
+    PV_REQUIRE(pick_mode(t.A, t.sam, t.sak, 0, 1) == MODE_XFAST && pick_mode(t.B, t.sbn, t.sbk, 0, 1) == MODE_XFAST,
+               "pv_linear_f32_group: item %d operands must be 16-byte aligned with unit stride along M / N", i);
+    G.g[i] = LinArgs{t.A, t.B, nullptr, t.C, t.M, t.N, t.K, t.sam, t.sak, t.sbk, t.sbn, t.ldc, 0, 0, 0, 1.f, t.alpha_dev,
+                     t.accumulate, MODE_XFAST, MODE_XFAST, nullptr, nullptr, t.r1_c, t.r1_u, t.r1_v, t.r1_nc};
+    G.ntn[i] = cdiv(t.N, 32);
+    tiles += cdiv(t.M, 32) * G.ntn[i];
+    G.tile_end[i] = tiles;
+  }
+  for (int i = n; i < GROUP_MAX; ++i) { G.g[i] = G.g[0]; G.tile_end[i] = tiles; G.ntn[i] = 1; }
+  G.n = n;
+  hipLaunchKernelGGL(linear_f32_group_kernel, dim3(tiles), dim3(256), 0, st, G);
+  PV_LAUNCH_CHECK("linear_f32_group_kernel");
+  return PV_OK;
+}
 
 extern "C" {
 

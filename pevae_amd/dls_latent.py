@@ -54,6 +54,9 @@ class Block(nn.Module):
         """x_act: gelu(x) if the producer of x already wrote it (else one standalone GELU launch); emit_gelu: also
         return gelu(output) for a following Block.  Each GELU is computed once, in the epilogue of the linear that
         produces its argument."""
+        if ops.block_fusable(self.c1.weight_orig.shape[1], self.c2.weight_orig.shape[0], self.translate.weight_orig.shape[0]):
+            out = ops.block_forward(self, x)                 # one launch; gelu(x) is formed inside the kernel
+            return (out, None) if emit_gelu else out
         if x_act is None:
             x_act = ops.gelu(x).detach()          # data for the GEMM; the gradient reaches x through c1's gelu' epilogue
         y, g = self.c1(x, x_act, emit_gelu=True)

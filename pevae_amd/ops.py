@@ -1035,18 +1035,114 @@ def spectral_prepass(modules, training, eps=1e-12, cache=None):
     if cache.get("ptrs") != ptrs:
         dev = modules[0].weight_orig.device
         inv = torch.empty(len(modules), dtype=torch.float32, device=dev)
-        rec = np.zeros((len(modules), 6), dtype=np.int64)
+        rec = np.zeros((len(modules), 7), dtype=np.int64)
+        sizes = [m.weight_orig.numel() for m in modules]
+        wt = torch.empty(int(np.sum(sizes)), dtype=torch.float32, device=dev)      # W^T of every weight (pv_block_fwd operands)
+        wts, off = [], 0
         for i, m in enumerate(modules):
             assert m.weight_orig.is_contiguous()
             n_out, n_in = m.weight_orig.shape
-            rec[i] = (ptrs[i][0], ptrs[i][1], ptrs[i][2], inv.data_ptr() + 4 * i, n_out, n_in)
-        cache.update(ptrs=ptrs, inv=inv, desc=torch.from_numpy(rec).to(dev), max_out=int(rec[:, 4].max()),
+            wts.append(wt[off:off + sizes[i]].view(n_in, n_out))
+            rec[i] = (ptrs[i][0], ptrs[i][1], ptrs[i][2], inv.data_ptr() + 4 * i, n_out, n_in, wts[i].data_ptr())
+            off += sizes[i]
+        cache.update(ptrs=ptrs, inv=inv, wts=wts, desc=torch.from_numpy(rec).to(dev), max_out=int(rec[:, 4].max()),
                      max_in=int(rec[:, 5].max()))
     _lib.call("pv_spectral_norm_multi", _p(cache["desc"]), len(modules), cache["max_out"], cache["max_in"], eps,
-              1 if training else 0, _stream())
+              1 if training else 0, 1 if FUSED_BLOCK else 0, _stream())
     for i, m in enumerate(modules):
         m._inv_sigma_pre = cache["inv"][i:i + 1]
+        m._wt_pre = cache["wts"][i]
     return cache
+
+
+FUSED_BLOCK = True      # Block.forward uses the one-launch kernels below whenever its widths allow it
+
+
+def block_fusable(din, mid, dout):
+    return FUSED_BLOCK and all(d % 16 == 0 and 0 < d <= 512 for d in (din, mid, dout))
+
+
+def _ptr_table(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class BlockFn(torch.autograd.Function):
+    """A whole Block (dialog_models.py:253-271) as ONE forward launch and three backward launches
+    (pv_block_fwd / pv_block_bwd): 16 batch rows per workgroup, activations in LDS, exact fp32 MFMA.
+    Arguments: x [M, Din]; inv_sigma, weight, bias, u, v of c1, c2, c3, c4, translate (5 each, in that order);
+    LayerNorm gamma / beta.  inv_sigma / u / v come from the spectral-norm power iteration of this step."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ln_eps, *rest):
+        inv, Ws, bs, us, vs, wts = rest[0:5], rest[5:10], rest[10:15], rest[15:20], rest[20:25], rest[25:30]
+        _need_cuda(x, gamma, beta, *Ws, *bs)
+        din, mid, dout = Ws[0].shape[1], Ws[1].shape[0], Ws[4].shape[0]
+        x2 = x.reshape(-1, din).contiguous()
+        M = x2.shape[0]
+        dev = x.device
+        sw, gw, pw = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.call("pv_block_layout", din, mid, dout, C.byref(sw), C.byref(gw), C.byref(pw))
+        Wc = [w.contiguous() for w in Ws]
+        bc = [b.contiguous() for b in bs]
+        save = torch.empty((M, sw.value), dtype=torch.float32, device=dev)
+        mean = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        out = torch.empty((M, dout), dtype=torch.float32, device=dev)
+        g, b = gamma.contiguous(), beta.contiguous()
+        _lib.call("pv_block_fwd", _p(x2), din, M, din, mid, dout, _ptr_table(list(wts)), _ptr_table(bc), _ptr_table(list(inv)),
+                  _p(g), _p(b), ln_eps, _p(save), _p(mean), _p(rstd), _p(out), dout, _stream())
+        ctx.save_for_backward(x2, out, save, mean, rstd, g, *inv, *Wc, *bc, *us, *vs)
+        ctx.dims = (M, din, mid, dout, gw.value, pw.value)
+        ctx.params = (gamma, beta, tuple(Ws), tuple(bs))
+        ctx.xshape = x.shape
+        return out.view(tuple(x.shape[:-1]) + (dout,))
+
+    @staticmethod
+    def backward(ctx, dout):
+        t = ctx.saved_tensors
+        x2, out, save, mean, rstd, g = t[:6]
+        inv, Wc, bc, us, vs = t[6:11], t[11:16], t[16:21], t[21:26], t[26:31]
+        M, din, mid, do, gw, pw = ctx.dims
+        dev = x2.device
+        p_g, p_b, p_W, p_bias = ctx.params
+        d2 = dout.reshape(M, do).contiguous()
+        nwg = (M + 15) // 16
+        dx = torch.empty((M, din), dtype=torch.float32, device=dev)
+        dY = torch.empty((M, gw), dtype=torch.float32, device=dev)
+        cpart = torch.empty(5 * nwg, dtype=torch.float32, device=dev)
+        ppart = torch.empty((nwg, pw), dtype=torch.float32, device=dev)
+        params = list(p_W) + list(p_bias) + [p_g, p_b]
+        sinks = [grad_sink(p, tuple(p.shape)) for p in params]
+        fused = all(s is not None for s in sinks)          # all-or-nothing: one accumulate flag for the launch group
+        grads = sinks if fused else [torch.empty(tuple(p.shape), dtype=torch.float32, device=dev) for p in params]
+        _lib.call("pv_block_bwd", _p(d2), do, _p(x2), din, _p(out), do, M, din, mid, do, _ptr_table(list(Wc)),
+                  _ptr_table(list(bc)), _ptr_table(list(inv)), _p(g), _p(save), _p(mean), _p(rstd), _p(dx), din, _p(dY),
+                  _p(cpart), _p(ppart), _ptr_table(list(us)), _ptr_table(list(vs)), _ptr_table(grads[0:5]),
+                  _ptr_table(grads[5:10]), _p(grads[10]), _p(grads[11]), 1 if fused else 0, _stream())
+        ret = [None] * 12 if fused else grads
+        dW, db, dg, dbe = ret[0:5], ret[5:10], ret[10], ret[11]
+        return (dx.view(ctx.xshape), dg, dbe, None) + (None,) * 5 + tuple(dW) + tuple(db) + (None,) * 15
+
+
+def block_forward(blk, x):
+    """Run a dls_latent.Block through BlockFn (the caller checked block_fusable)."""
+    lins = (blk.c1, blk.c2, blk.c3, blk.c4, blk.translate)
+    if any(m._inv_sigma_pre is None or getattr(m, "_wt_pre", None) is None for m in lins):
+        spectral_prepass(list(lins), blk.training, lins[0].eps)
+        us = [m.weight_u.clone() for m in lins]       # a later forward may advance the buffers before this backward runs
+        vs = [m.weight_v.clone() for m in lins]
+    else:
+        us = [m.weight_u for m in lins]
+        vs = [m.weight_v for m in lins]
+    inv, wts = [], []
+    for m in lins:
+        inv.append(m._inv_sigma_pre)
+        wts.append(m._wt_pre)
+        m._inv_sigma_pre = None
+        m._wt_pre = None
+    ln = blk.layer_norm
+    return BlockFn.apply(x, ln.weight, ln.bias, ln.eps, *inv, *[m.weight_orig for m in lins], *[m.bias for m in lins],
+                         *us, *vs, *wts)
 
 
 class L2NormRows(torch.autograd.Function):

@@ -46,6 +46,41 @@ def test_block_golden(dev):
     close(blk(T(g["x"], dev)), g["y_eval"])
 
 
+@pytest.mark.parametrize("M,din,dout,mid,sinks", [(37, 48, 32, 96, False), (256, 128, 64, 64, True), (16, 16, 16, 16, False),
+                                                  (70, 512, 256, 256, True)])
+def test_block_fused_matches_unfused(dev, M, din, dout, mid, sinks):
+    """The one-launch Block kernels (pv_block_fwd / pv_block_bwd) against the per-linear path that the reference goldens
+    pin (test_block_golden), on ragged row counts, with gradients returned and accumulated into existing .grad."""
+    import copy
+    from pevae_amd import dls_latent as L, ops
+    torch.manual_seed(3)
+    blk_a = L.Block(din, dout, mid).to(dev).train()
+    blk_b = copy.deepcopy(blk_a)
+    assert ops.block_fusable(din, mid, dout)
+    x = torch.randn(M, din, device=dev)
+    w = torch.randn(M, dout, device=dev)
+    res = []
+    for blk, fused in ((blk_a, True), (blk_b, False)):
+        ops.FUSED_BLOCK = fused
+        try:
+            if sinks:
+                for p in blk.parameters():
+                    p.grad = torch.full_like(p, 0.25)
+            xi = x.clone().requires_grad_()
+            y = blk(xi)
+            (y * w).sum().backward()
+        finally:
+            ops.FUSED_BLOCK = True
+        res.append((y, xi.grad, blk))
+    (ya, dxa, _), (yb, dxb, _) = res
+    close(ya, yb, rtol=1e-4, atol=2e-5)
+    close(dxa, dxb, rtol=1e-4, atol=1e-4 * float(dxb.abs().max()))
+    for (k, p), (_, q) in zip(blk_a.named_parameters(), blk_b.named_parameters()):
+        close(p.grad, q.grad, rtol=1e-4, atol=1e-4 * float(q.grad.abs().max()) + 1e-6)
+    for (k, u), (_, v) in zip(blk_a.named_buffers(), blk_b.named_buffers()):
+        close(u, v, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["dlsrec", "dlspri"])
 def test_pyramid_golden(dev, name):
     from pevae_amd import dls_latent as L
