@@ -189,21 +189,48 @@ int pv_spectral_norm_bwd(const float* dy, const float* y, const float* bias, lon
                          const float* v, const float* inv_sigma, float* scratch1, float* dW, void* stream);
 /* A whole Block (:253-271) per launch: a workgroup owns 16 batch rows and walks gelu -> c1 -> gelu -> c2 -> gelu ->
  * c3 -> gelu -> c4 -> +x -> LayerNorm -> translate with the activations in LDS (every step is row-independent once
- * 1/sigma is known).  W / bias / inv_sigma / u / v / dW / db: HOST arrays of five device pointers in the order c1, c2,
- * c3, c4, translate (weight_orig [out][in]; pv_block_fwd takes the TRANSPOSED copies Wt [in][out] written by
- * pv_spectral_norm_multi, so that every weight access of both passes is a contiguous 256-byte run).  Widths must be multiples of 16 and <= 512.  pv_block_layout gives the
- * per-row float counts of `save` (activations kept for the backward pass), `dY` (gradients of the four inner linears)
- * and of one workgroup's row in `ppart` (cdiv(M,16) rows); `cpart` holds 5 * cdiv(M,16) floats.  pv_block_bwd writes dx
- * and (accumulate != 0: adds to) every parameter gradient, including the spectral-norm rank-1 term of the weights. */
+ * 1/sigma is known).  The forward pass streams the TRANSPOSED weights Wt [in][out] written by pv_spectral_norm_multi, the
+ * backward pass weight_orig [out][in]: every weight access of both passes is a contiguous 256-byte run.  Widths must be
+ * multiples of 16 and <= 512.  pv_block_layout gives the per-row float counts of `save` (activations kept for the
+ * backward pass), `dY` (gradients of the four inner linears) and of one workgroup's row in `ppart`.  pv_block_bwd writes
+ * dx and (accumulate != 0: adds to) every parameter gradient, including the spectral-norm rank-1 term of the weights. */
 int pv_block_layout(int Din, int mid, int Dout, int* save_width, int* grad_width, int* part_width);
-int pv_block_fwd(const float* x, long ldx, int M, int Din, int mid, int Dout, const float* const* Wt,
-                 const float* const* bias, const float* const* inv_sigma, const float* gamma, const float* beta, float eps,
-                 float* save, float* mean, float* rstd, float* out, long ldo, void* stream);
-int pv_block_bwd(const float* dout, long lddo, const float* x, long ldx, const float* out, long ldo, int M, int Din,
-                 int mid, int Dout, const float* const* W, const float* const* bias, const float* const* inv_sigma,
-                 const float* gamma, const float* save, const float* mean, const float* rstd, float* dx, long lddx,
-                 float* dY, float* cpart, float* ppart, const float* const* u, const float* const* v, float* const* dW,
-                 float* const* db, float* dgamma, float* dbeta, int accumulate, void* stream);
+#define PV_BLOCK_GROUP_MAX 3
+typedef struct pv_block_call {      /* one Block of a launch; arrays are in the order c1, c2, c3, c4, translate */
+  int M, Din, mid, Dout;
+  float ln_eps;
+  int accumulate;                   /* backward: add to the parameter gradients instead of overwriting them */
+  const float* W[5];                /* weight_orig [out][in]           (backward) */
+  const float* Wt[5];               /* W^T [in][out] of this step      (forward)  */
+  const float* bias[5];
+  const float* inv_sigma[5];        /* device scalars */
+  const float* u[5];                /* power-iteration vectors of this step (backward) */
+  const float* v[5];
+  const float* gamma;
+  const float* beta;
+  const float* x;                   /* [M][ldx] */
+  long ldx;
+  float* save;                      /* [M][save_width]; written by forward, read by backward */
+  float* mean;                      /* [M] */
+  float* rstd;                      /* [M] */
+  float* out;                       /* [M][ldo] */
+  long ldo;
+  const float* dout;                /* backward: [M][lddo] */
+  long lddo;
+  float* dx;                        /* [M][lddx] */
+  long lddx;
+  float* dY;                        /* scratch [M][grad_width] */
+  float* cpart;                     /* scratch 5 * cdiv(M,16) floats */
+  float* ppart;                     /* scratch cdiv(M,16) * part_width floats */
+  float* dW[5];
+  float* db[5];
+  float* dgamma;
+  float* dbeta;
+} pv_block_call;
+/* Up to PV_BLOCK_GROUP_MAX INDEPENDENT Blocks per launch (each alone fills 16 CUs at batch 256: the two pyramids' Blocks
+ * of a level, or the three Blocks of a DLS_Auto level, run side by side). */
+int pv_block_fwd(const pv_block_call* calls, int n, void* stream);
+int pv_block_bwd(const pv_block_call* calls, int n, void* stream);
 /* DLS_Auto.cons_loss (:3266-3272): row L2 normalisation and the symmetric InfoNCE over a [B][B] score matrix with
  * the diagonal as targets: loss = (CE(log_softmax rows) + CE(log_softmax columns)) / 2. */
 int pv_l2norm_rows_fwd(const float* x, int rows, int D, float* a, float* nrm, void* stream);

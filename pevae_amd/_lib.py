@@ -13,6 +13,20 @@ LIB_PATH = os.environ.get("PEVAE_HIP_LIB") or os.path.join(_HERE, "lib", "libpev
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 lng = C.c_long
 
+
+class BlockCall(C.Structure):
+    """struct pv_block_call of include/pevae_hip.h (one Block of a pv_block_fwd / pv_block_bwd launch)."""
+    _P5 = vp * 5
+    _fields_ = [("M", i32), ("Din", i32), ("mid", i32), ("Dout", i32), ("ln_eps", f32), ("accumulate", i32),
+                ("W", vp * 5), ("Wt", vp * 5), ("bias", vp * 5), ("inv_sigma", vp * 5), ("u", vp * 5), ("v", vp * 5),
+                ("gamma", vp), ("beta", vp),
+                ("x", vp), ("ldx", lng), ("save", vp), ("mean", vp), ("rstd", vp), ("out", vp), ("ldo", lng),
+                ("dout", vp), ("lddo", lng), ("dx", vp), ("lddx", lng), ("dY", vp), ("cpart", vp), ("ppart", vp),
+                ("dW", vp * 5), ("db", vp * 5), ("dgamma", vp), ("dbeta", vp)]
+
+
+BLOCK_GROUP_MAX = 3
+
 # name -> (restype, argtypes); mirrors include/pevae_hip.h one-to-one (tests/test_abi.py checks that)
 SIGNATURES = {
     "pv_last_error": (C.c_char_p, []),
@@ -32,9 +46,8 @@ SIGNATURES = {
     "pv_gru_fwd": (i32, [vp, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     "pv_gru_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pv_block_layout": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
-    "pv_block_fwd": (i32, [vp, lng, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, lng, vp]),
-    "pv_block_bwd": (i32, [vp, lng, vp, lng, vp, lng, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, lng, vp, vp, vp,
-                           vp, vp, vp, vp, vp, vp, i32, vp]),
+    "pv_block_fwd": (i32, [vp, i32, vp]),
+    "pv_block_bwd": (i32, [vp, i32, vp]),
     "pv_lstm_geometry": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "pv_lstm_fwd": (i32, [vp, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pv_lstm_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

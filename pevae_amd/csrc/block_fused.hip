@@ -281,8 +281,17 @@ struct BlockFwdArgs {
   int LD;           // LDS row stride (floats) = max width + 4
 };
 
-__global__ __launch_bounds__(NT) void block_fwd_kernel(BlockFwdArgs a) {
+// Independent Blocks (the two pyramids' Blocks of one level, the three Blocks of a DLS_Auto level) share a launch:
+// blockIdx.y picks the Block, blockIdx.x its 16-row slab.  Each Block alone occupies 16 of the 256 CUs.
+struct BlockFwdGroup {
+  BlockFwdArgs a[PV_BLOCK_GROUP_MAX];
+};
+struct BlockBwdGroup;
+
+__global__ __launch_bounds__(NT) void block_fwd_kernel(BlockFwdGroup grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const BlockFwdArgs& a = grp.a[blockIdx.y];
+  if ((int)blockIdx.x * RB >= a.M) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, q4 = lane >> 4;
   const bool compute = w < 4;
   const int Din = a.d.Din, mid = a.d.mid, Dout = a.d.Dout, LD = a.LD, M = a.M;
@@ -454,12 +463,18 @@ struct BlockBwdArgs {
   int LD;
 };
 
-__global__ __launch_bounds__(NT) void block_bwd_dx_kernel(BlockBwdArgs a) {
+struct BlockBwdGroup {
+  BlockBwdArgs a[PV_BLOCK_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(NT) void block_bwd_dx_kernel(BlockBwdGroup grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const BlockBwdArgs& a = grp.a[blockIdx.y];
+  if ((int)blockIdx.x * RB >= a.M) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, q4 = lane >> 4;
   const bool compute = w < 4;
   const int Din = a.d.Din, mid = a.d.mid, Dout = a.d.Dout, LD = a.LD, M = a.M;
-  const int r0 = blockIdx.x * RB, nwg = gridDim.x;
+  const int r0 = blockIdx.x * RB, nwg = (a.M + RB - 1) / RB;
   float* buf0 = lds;
   float* buf1 = lds + RB * LD;
   float* buf2 = lds + 2 * RB * LD;
@@ -655,7 +670,12 @@ struct ParamReduceArgs {
   int accumulate;
 };
 
-__global__ __launch_bounds__(256) void block_param_reduce_kernel(ParamReduceArgs a) {
+struct ParamReduceGroup {
+  ParamReduceArgs r[PV_BLOCK_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256) void block_param_reduce_kernel(ParamReduceGroup grp) {
+  const ParamReduceArgs& a = grp.r[blockIdx.y];
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= a.width) return;
   float s = 0.f;
@@ -673,24 +693,27 @@ int check_dims(int M, int Din, int mid, int Dout, const char* who) {
   return PV_OK;
 }
 
-int fill_desc(BlockDesc& d, const float* const* W, const float* const* bias, const float* const* inv_sigma,
-              const float* gamma, const float* beta, int Din, int mid, int Dout, float eps, const char* who) {
-  PV_REQUIRE(W && bias && inv_sigma && gamma && beta, "%s: null parameter table", who);
+int fill_desc(BlockDesc& d, const pv_block_call& c, bool transposed, const char* who) {
   for (int i = 0; i < 5; ++i) {
-    PV_REQUIRE(W[i] && bias[i] && inv_sigma[i], "%s: null parameter of linear %d", who, i);
-    PV_REQUIRE(((uintptr_t)W[i] & 15) == 0 && ((uintptr_t)bias[i] & 15) == 0, "%s: parameters must be 16-byte aligned", who);
-    d.W[i] = W[i];
-    d.bias[i] = bias[i];
-    d.inv_sigma[i] = inv_sigma[i];
+    const float* W = transposed ? c.Wt[i] : c.W[i];
+    PV_REQUIRE(W && c.bias[i] && c.inv_sigma[i], "%s: null parameter of linear %d", who, i);
+    PV_REQUIRE(((uintptr_t)W & 15) == 0 && ((uintptr_t)c.bias[i] & 15) == 0, "%s: parameters must be 16-byte aligned", who);
+    d.W[i] = W;
+    d.bias[i] = c.bias[i];
+    d.inv_sigma[i] = c.inv_sigma[i];
   }
-  d.gamma = gamma;
-  d.beta = beta;
-  d.Din = Din;
-  d.mid = mid;
-  d.Dout = Dout;
-  d.eps = eps;
+  PV_REQUIRE(c.gamma && (c.beta || !transposed), "%s: null LayerNorm parameter", who);
+  PV_REQUIRE(((uintptr_t)c.gamma & 15) == 0 && ((uintptr_t)c.beta & 15) == 0, "%s: parameters must be 16-byte aligned", who);
+  d.gamma = c.gamma;
+  d.beta = c.beta ? c.beta : c.gamma;
+  d.Din = c.Din;
+  d.mid = c.mid;
+  d.Dout = c.Dout;
+  d.eps = c.ln_eps;
   return PV_OK;
 }
+
+int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
 template <class K>
 int set_lds(K kernel, size_t bytes, size_t* seen) {
@@ -722,84 +745,102 @@ int pv_block_layout(int Din, int mid, int Dout, int* save_width, int* grad_width
   return PV_OK;
 }
 
-int pv_block_fwd(const float* x, long ldx, int M, int Din, int mid, int Dout, const float* const* Wt,
-                 const float* const* bias, const float* const* inv_sigma, const float* gamma, const float* beta, float eps,
-                 float* save, float* mean, float* rstd, float* out, long ldo, void* stream) {
-  int rc = check_dims(M, Din, mid, Dout, "pv_block_fwd");
-  if (rc) return rc;
-  PV_REQUIRE(x && save && mean && rstd && out && ldx >= Din && ldo >= Dout && ldx % 4 == 0 && ldo % 4 == 0,
-             "pv_block_fwd: bad argument");
-  PV_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)save & 15) == 0 && ((uintptr_t)out & 15) == 0,
-             "pv_block_fwd: buffers must be 16-byte aligned");
-  BlockFwdArgs a;
-  if ((rc = fill_desc(a.d, Wt, bias, inv_sigma, gamma, beta, Din, mid, Dout, eps, "pv_block_fwd"))) return rc;
-  a.x = x; a.ldx = ldx; a.M = M; a.save = save; a.mean = mean; a.rstd = rstd; a.out = out; a.ldo = ldo;
-  const int mx = Din > mid ? (Din > Dout ? Din : Dout) : (mid > Dout ? mid : Dout);
-  a.LD = mx + 4;
-  const size_t smem = ((size_t)4 * RB * a.LD + PartLayout(Din, mid, Dout).width + 8 + 2 * RB + 32) * sizeof(float);
+int pv_block_fwd(const pv_block_call* calls, int n, void* stream) {
+  PV_REQUIRE(calls && n >= 1 && n <= PV_BLOCK_GROUP_MAX, "pv_block_fwd: 1..%d blocks per launch", PV_BLOCK_GROUP_MAX);
+  BlockFwdGroup g;
+  size_t smem = 0;
+  int nwg = 0;
+  for (int b = 0; b < n; ++b) {
+    const pv_block_call& c = calls[b];
+    int rc = check_dims(c.M, c.Din, c.mid, c.Dout, "pv_block_fwd");
+    if (rc) return rc;
+    PV_REQUIRE(c.x && c.save && c.mean && c.rstd && c.out && c.ldx >= c.Din && c.ldo >= c.Dout && c.ldx % 4 == 0 &&
+                   c.ldo % 4 == 0, "pv_block_fwd: bad argument (block %d)", b);
+    PV_REQUIRE(((uintptr_t)c.x & 15) == 0 && ((uintptr_t)c.save & 15) == 0 && ((uintptr_t)c.out & 15) == 0,
+               "pv_block_fwd: buffers must be 16-byte aligned");
+    BlockFwdArgs& a = g.a[b];
+    if ((rc = fill_desc(a.d, c, true, "pv_block_fwd"))) return rc;
+    a.x = c.x; a.ldx = c.ldx; a.M = c.M; a.save = c.save; a.mean = c.mean; a.rstd = c.rstd; a.out = c.out; a.ldo = c.ldo;
+    a.LD = max3(c.Din, c.mid, c.Dout) + 4;
+    const size_t need = ((size_t)4 * RB * a.LD + PartLayout(c.Din, c.mid, c.Dout).width + 8 + 2 * RB + 32) * sizeof(float);
+    if (need > smem) smem = need;
+    if (cdiv(c.M, RB) > nwg) nwg = cdiv(c.M, RB);
+  }
+  for (int b = n; b < PV_BLOCK_GROUP_MAX; ++b) g.a[b] = g.a[0];
   static size_t seen = 0;
-  if ((rc = set_lds(block_fwd_kernel, smem, &seen))) return rc;
-  hipLaunchKernelGGL(block_fwd_kernel, dim3(cdiv(M, RB)), dim3(NT), smem, (hipStream_t)stream, a);
+  int rc = set_lds(block_fwd_kernel, smem, &seen);
+  if (rc) return rc;
+  hipLaunchKernelGGL(block_fwd_kernel, dim3(nwg, n), dim3(NT), smem, (hipStream_t)stream, g);
   PV_LAUNCH_CHECK("block_fwd_kernel");
   return PV_OK;
 }
 
-int pv_block_bwd(const float* dout, long lddo, const float* x, long ldx, const float* out, long ldo, int M, int Din,
-                 int mid, int Dout, const float* const* W, const float* const* bias, const float* const* inv_sigma,
-                 const float* gamma, const float* save, const float* mean, const float* rstd, float* dx, long lddx,
-                 float* dY, float* cpart, float* ppart, const float* const* u, const float* const* v, float* const* dW,
-                 float* const* db, float* dgamma, float* dbeta, int accumulate, void* stream) {
-  int rc = check_dims(M, Din, mid, Dout, "pv_block_bwd");
-  if (rc) return rc;
-  PV_REQUIRE(dout && x && out && save && mean && rstd && dx && dY && cpart && ppart && u && v && dW && db && dgamma && dbeta,
-             "pv_block_bwd: null argument");
-  PV_REQUIRE(lddo >= Dout && ldx >= Din && ldo >= Dout && lddx >= Din && lddo % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 &&
-                 lddx % 4 == 0, "pv_block_bwd: bad leading dimension");
-  PV_REQUIRE(((uintptr_t)dout & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
-                 ((uintptr_t)save & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dY & 15) == 0,
-             "pv_block_bwd: buffers must be 16-byte aligned");
+int pv_block_bwd(const pv_block_call* calls, int n, void* stream) {
+  PV_REQUIRE(calls && n >= 1 && n <= PV_BLOCK_GROUP_MAX, "pv_block_bwd: 1..%d blocks per launch", PV_BLOCK_GROUP_MAX);
   hipStream_t st = (hipStream_t)stream;
-  BlockBwdArgs a;
-  if ((rc = fill_desc(a.d, W, bias, inv_sigma, gamma, gamma, Din, mid, Dout, 0.f, "pv_block_bwd"))) return rc;
-  a.dout = dout; a.lddo = lddo; a.x = x; a.ldx = ldx; a.out = out; a.ldo = ldo; a.M = M; a.save = save; a.mean = mean;
-  a.rstd = rstd; a.dx = dx; a.lddx = lddx; a.dY = dY; a.cpart = cpart; a.ppart = ppart;
-  const int mx = Din > mid ? (Din > Dout ? Din : Dout) : (mid > Dout ? mid : Dout);
-  a.LD = mx + 4;
-  const int nwg = cdiv(M, RB);
-  const size_t smem = ((size_t)4 * RB * a.LD + PartLayout(Din, mid, Dout).width + 8 + 2 * RB + 24 + 8) * sizeof(float);
+  BlockBwdGroup g;
+  ParamReduceGroup pr;
+  LinGroupItem it[5 * PV_BLOCK_GROUP_MAX];
+  size_t smem = 0;
+  int nwg_max = 0, width_max = 0;
+  for (int b = 0; b < n; ++b) {
+    const pv_block_call& c = calls[b];
+    int rc = check_dims(c.M, c.Din, c.mid, c.Dout, "pv_block_bwd");
+    if (rc) return rc;
+    PV_REQUIRE(c.dout && c.x && c.out && c.save && c.mean && c.rstd && c.dx && c.dY && c.cpart && c.ppart && c.dgamma && c.dbeta,
+               "pv_block_bwd: null argument (block %d)", b);
+    PV_REQUIRE(c.lddo >= c.Dout && c.ldx >= c.Din && c.ldo >= c.Dout && c.lddx >= c.Din && c.lddo % 4 == 0 && c.ldx % 4 == 0 &&
+                   c.ldo % 4 == 0 && c.lddx % 4 == 0, "pv_block_bwd: bad leading dimension");
+    PV_REQUIRE(((uintptr_t)c.dout & 15) == 0 && ((uintptr_t)c.x & 15) == 0 && ((uintptr_t)c.out & 15) == 0 &&
+                   ((uintptr_t)c.save & 15) == 0 && ((uintptr_t)c.dx & 15) == 0 && ((uintptr_t)c.dY & 15) == 0 &&
+                   ((uintptr_t)c.ppart & 15) == 0, "pv_block_bwd: buffers must be 16-byte aligned");
+    BlockBwdArgs& a = g.a[b];
+    if ((rc = fill_desc(a.d, c, false, "pv_block_bwd"))) return rc;
+    a.dout = c.dout; a.lddo = c.lddo; a.x = c.x; a.ldx = c.ldx; a.out = c.out; a.ldo = c.ldo; a.M = c.M; a.save = c.save;
+    a.mean = c.mean; a.rstd = c.rstd; a.dx = c.dx; a.lddx = c.lddx; a.dY = c.dY; a.cpart = c.cpart; a.ppart = c.ppart;
+    a.LD = max3(c.Din, c.mid, c.Dout) + 4;
+    const int nwg = cdiv(c.M, RB);
+    const PartLayout P(c.Din, c.mid, c.Dout);
+    const size_t need = ((size_t)4 * RB * a.LD + P.width + 8 + 2 * RB + 24 + 8) * sizeof(float);
+    if (need > smem) smem = need;
+    if (nwg > nwg_max) nwg_max = nwg;
+    if (P.width > width_max) width_max = P.width;
+
+    ParamReduceArgs& r = pr.r[b];
+    r.ppart = c.ppart; r.nwg = nwg; r.width = P.width; r.accumulate = c.accumulate;
+    const int ends[7] = {P.b2, P.b3, P.b4, P.bt, P.dg, P.dbe, P.width};
+    float* dsts[7] = {c.db[0], c.db[1], c.db[2], c.db[3], c.db[4], c.dgamma, c.dbeta};
+    for (int i = 0; i < 7; ++i) {
+      PV_REQUIRE(dsts[i], "pv_block_bwd: null parameter-gradient destination %d", i);
+      r.seg_end[i] = ends[i];
+      r.dst[i] = dsts[i];
+    }
+    // weight gradients: dW_i (+)= (dy_i^T a_{i-1} - <dy_i, y_i - b_i> u_i v_i^T) / sigma_i
+    const SaveLayout L(c.Din, c.mid);
+    const GradLayout G(c.Din, c.mid);
+    const long SW = L.width, GW = G.width;
+    const int outs[5] = {c.Din, c.mid, c.mid, c.Din, c.Dout}, ins[5] = {c.Din, c.Din, c.mid, c.mid, c.Din};
+    const float* dys[5] = {c.dY + G.d1, c.dY + G.d2, c.dY + G.d3, c.dY + G.d4, c.dout};
+    const long dyld[5] = {GW, GW, GW, GW, c.lddo};
+    const float* acts[5] = {c.save + L.a0, c.save + L.a1, c.save + L.a2, c.save + L.a3, c.save + L.o};
+    for (int i = 0; i < 5; ++i) {
+      PV_REQUIRE(c.dW[i] && c.u[i] && c.v[i], "pv_block_bwd: null weight-gradient argument %d", i);
+      it[5 * b + i] = LinGroupItem{dys[i], 1, dyld[i], acts[i], SW, 1, c.dW[i], ins[i], outs[i], ins[i], c.M,
+                                   c.inv_sigma[i], c.accumulate, c.cpart + (size_t)i * nwg, nwg, c.u[i], c.v[i]};
+    }
+  }
+  for (int b = n; b < PV_BLOCK_GROUP_MAX; ++b) {
+    g.a[b] = g.a[0];
+    pr.r[b] = pr.r[0];
+  }
   static size_t seen = 0;
-  if ((rc = set_lds(block_bwd_dx_kernel, smem, &seen))) return rc;
-  hipLaunchKernelGGL(block_bwd_dx_kernel, dim3(nwg), dim3(NT), smem, st, a);
+  int rc = set_lds(block_bwd_dx_kernel, smem, &seen);
+  if (rc) return rc;
+  hipLaunchKernelGGL(block_bwd_dx_kernel, dim3(nwg_max, n), dim3(NT), smem, st, g);
   PV_LAUNCH_CHECK("block_bwd_dx_kernel");
-
-  const PartLayout P(Din, mid, Dout);
-  ParamReduceArgs r;
-  r.ppart = ppart; r.nwg = nwg; r.width = P.width; r.accumulate = accumulate;
-  const int ends[7] = {P.b2, P.b3, P.b4, P.bt, P.dg, P.dbe, P.width};
-  float* dsts[7] = {db[0], db[1], db[2], db[3], db[4], dgamma, dbeta};
-  for (int i = 0; i < 7; ++i) {
-    PV_REQUIRE(dsts[i], "pv_block_bwd: null parameter-gradient destination %d", i);
-    r.seg_end[i] = ends[i];
-    r.dst[i] = dsts[i];
-  }
-  hipLaunchKernelGGL(block_param_reduce_kernel, dim3(cdiv(P.width, 256)), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(block_param_reduce_kernel, dim3(cdiv(width_max, 256), n), dim3(256), 0, st, pr);
   PV_LAUNCH_CHECK("block_param_reduce_kernel");
-
-  // weight gradients: dW_i (+)= (dy_i^T a_{i-1} - <dy_i, y_i - b_i> u_i v_i^T) / sigma_i, five GEMMs in one launch
-  const SaveLayout L(Din, mid);
-  const GradLayout G(Din, mid);
-  const long SW = L.width, GW = G.width;
-  const int outs[5] = {Din, mid, mid, Din, Dout}, ins[5] = {Din, Din, mid, mid, Din};
-  const float* dys[5] = {dY + G.d1, dY + G.d2, dY + G.d3, dY + G.d4, dout};
-  const long dyld[5] = {GW, GW, GW, GW, lddo};
-  const float* acts[5] = {save + L.a0, save + L.a1, save + L.a2, save + L.a3, save + L.o};
-  LinGroupItem it[5];
-  for (int i = 0; i < 5; ++i) {
-    PV_REQUIRE(dW[i] && u[i] && v[i], "pv_block_bwd: null weight-gradient argument %d", i);
-    it[i] = LinGroupItem{dys[i], 1, dyld[i], acts[i], SW, 1, dW[i], ins[i], outs[i], ins[i], M,
-                         inv_sigma[i], accumulate, cpart + (size_t)i * nwg, nwg, u[i], v[i]};
-  }
-  return pv_linear_f32_group(it, 5, st);
+  return pv_linear_f32_group(it, 5 * n, st);       // the 5 n weight-gradient GEMMs in one launch
 }
 
 }  // extern "C"

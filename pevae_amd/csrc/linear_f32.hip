@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
 
 // Several independent GEMMs of the x-fast / x-fast operand form (the weight gradients dy^T a of one Block) in ONE
 // launch: blockIdx.x walks the 32x32 tiles of item 0, then item 1, ...
-constexpr int GROUP_MAX = 5;
+constexpr int GROUP_MAX = 15;
 struct LinGroup {
   LinArgs g[GROUP_MAX];
   int tile_end[GROUP_MAX];     // exclusive prefix of tile counts

@@ -67,6 +67,37 @@ class Block(nn.Module):
         return self.translate(out, emit_gelu=emit_gelu)
 
 
+def block_dims(blk):
+    return blk.c1.weight_orig.shape[1], blk.c2.weight_orig.shape[0], blk.translate.weight_orig.shape[0]
+
+
+def run_blocks(blks, xs):
+    """Independent Blocks: one fused launch per group when every one of them has a fused kernel, else parallel stream
+    branches of the per-Block path."""
+    if all(ops.block_fusable(*block_dims(b)) for b in blks):
+        return ops.blocks_forward(list(blks), list(xs))
+    return ops.parallel(*[(lambda b=b, x=x: b(x)) for b, x in zip(blks, xs)])
+
+
+def pyramid_pair(pyr_a, x_a, pyr_b, x_b):
+    """Two pyramids of equal depth walked level by level, the two Blocks of a level sharing a launch
+    (DlsPri / DlsRec on prior_h / h, dialog_models.py:3529-3530).  -> ((out_a, acts_a), (out_b, acts_b))"""
+    la = [l[0] if isinstance(l, nn.Sequential) else l for l in pyr_a.layers]
+    lb = [l[0] if isinstance(l, nn.Sequential) else l for l in pyr_b.layers]
+    if len(la) != len(lb):
+        return ops.parallel(lambda: pyr_a(x_a), lambda: pyr_b(x_b))
+    if x_a.dim() == 3:
+        x_a = x_a[:, 0]
+    if x_b.dim() == 3:
+        x_b = x_b[:, 0]
+    acts_a, acts_b = [], []
+    for ba, bb in zip(la, lb):
+        acts_a.append(x_a)
+        acts_b.append(x_b)
+        x_a, x_b = run_blocks([ba, bb], [x_a, x_b])
+    return (x_a, acts_a), (x_b, acts_b)
+
+
 class _Pyramid(nn.Module):
     def __init__(self, input_dim, output_dim, wrap):
         super().__init__()
@@ -132,9 +163,8 @@ class DLSAuto(nn.Module):
                 q_in = torch.cat([a1 + a2, last_sample], -1)
                 p_in = torch.cat([a2, last_t if train_branch else last_sample], -1)
             need_q = train_branch or self.training
-            # the three Blocks of a level are independent: run them as parallel branches
-            branches = [lambda: dis2(p_in), lambda: layer(output)] + ([lambda: dis(q_in)] if need_q else [])
-            res = ops.parallel(*branches)
+            # the three Blocks of a level are independent: they share one launch (or run as parallel stream branches)
+            res = run_blocks([dis2, layer] + ([dis] if need_q else []), [p_in, output] + ([q_in] if need_q else []))
             t_mean, t_lv = res[0].chunk(2, -1)
             lay_out = res[1]
             if need_q:

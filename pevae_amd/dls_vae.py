@@ -101,8 +101,8 @@ class DLSVAE(nn.Module):
             if getattr(self, "_sn_modules", None) is None:
                 self._sn_modules, self._sn_cache = L.spectral_modules(self), {}
             ops.spectral_prepass(self._sn_modules, self.training, cache=self._sn_cache)    # all 105 power iterations, one launch
-            (z_pri, pri_state), (z_rec, rec_state) = ops.parallel(lambda: self.pri_encoder(prior_h),   # :3529
-                                                                  lambda: self.rec_encoder(h))         # :3530
+            (z_pri, pri_state), (z_rec, rec_state) = L.pyramid_pair(self.pri_encoder, prior_h,         # :3529
+                                                                    self.rec_encoder, h)               # :3530
             z, rkl = self.sup_decoder(z_pri, z_rec, rec_state, pri_state,
                                       getattr(self, "restarted", False), noise=eps)        # :3535
             if not self.training:

@@ -1066,66 +1066,112 @@ def _ptr_table(tensors):
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-class BlockFn(torch.autograd.Function):
-    """A whole Block (dialog_models.py:253-271) as ONE forward launch and three backward launches
-    (pv_block_fwd / pv_block_bwd): 16 batch rows per workgroup, activations in LDS, exact fp32 MFMA.
-    Arguments: x [M, Din]; inv_sigma, weight, bias, u, v of c1, c2, c3, c4, translate (5 each, in that order);
-    LayerNorm gamma / beta.  inv_sigma / u / v come from the spectral-norm power iteration of this step."""
+NPB = 33      # tensors per Block in BlockGroupFn's flat argument list
+
+
+def _ptrs5(tensors):
+    return (C.c_void_p * 5)(*[t.data_ptr() for t in tensors])
+
+
+class BlockGroupFn(torch.autograd.Function):
+    """Up to three INDEPENDENT Blocks (dialog_models.py:253-271) as ONE forward launch and three backward launches
+    (pv_block_fwd / pv_block_bwd): 16 batch rows per workgroup, activations in LDS, exact fp32 MFMA.  A Block alone
+    occupies 16 of the 256 CUs, so the two pyramids' Blocks of one level and the three Blocks of a DLS_Auto level share
+    launches.  Flat arguments, per Block: x [M, Din], gamma, beta, then inv_sigma, weight, bias, u, v, W^T of c1, c2, c3,
+    c4, translate (5 each).  inv_sigma / u / v / W^T come from this step's spectral-norm pre-pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, ln_eps, *rest):
-        inv, Ws, bs, us, vs, wts = rest[0:5], rest[5:10], rest[10:15], rest[15:20], rest[20:25], rest[25:30]
-        _need_cuda(x, gamma, beta, *Ws, *bs)
-        din, mid, dout = Ws[0].shape[1], Ws[1].shape[0], Ws[4].shape[0]
-        x2 = x.reshape(-1, din).contiguous()
-        M = x2.shape[0]
-        dev = x.device
-        sw, gw, pw = C.c_int(0), C.c_int(0), C.c_int(0)
-        _lib.call("pv_block_layout", din, mid, dout, C.byref(sw), C.byref(gw), C.byref(pw))
-        Wc = [w.contiguous() for w in Ws]
-        bc = [b.contiguous() for b in bs]
-        save = torch.empty((M, sw.value), dtype=torch.float32, device=dev)
-        mean = torch.empty(M, dtype=torch.float32, device=dev)
-        rstd = torch.empty(M, dtype=torch.float32, device=dev)
-        out = torch.empty((M, dout), dtype=torch.float32, device=dev)
-        g, b = gamma.contiguous(), beta.contiguous()
-        _lib.call("pv_block_fwd", _p(x2), din, M, din, mid, dout, _ptr_table(list(wts)), _ptr_table(bc), _ptr_table(list(inv)),
-                  _p(g), _p(b), ln_eps, _p(save), _p(mean), _p(rstd), _p(out), dout, _stream())
-        ctx.save_for_backward(x2, out, save, mean, rstd, g, *inv, *Wc, *bc, *us, *vs)
-        ctx.dims = (M, din, mid, dout, gw.value, pw.value)
-        ctx.params = (gamma, beta, tuple(Ws), tuple(bs))
-        ctx.xshape = x.shape
-        return out.view(tuple(x.shape[:-1]) + (dout,))
+    def forward(ctx, eps_list, *flat):
+        n = len(flat) // NPB
+        _need_cuda(*flat)
+        dev = flat[0].device
+        calls = (_lib.BlockCall * n)()
+        saved, meta, outs = [], [], []
+        for b in range(n):
+            t = flat[b * NPB:(b + 1) * NPB]
+            x, gamma, beta = t[0:3]
+            inv, Ws, bs, us, vs, wts = t[3:8], t[8:13], t[13:18], t[18:23], t[23:28], t[28:33]
+            din, mid, dout = Ws[0].shape[1], Ws[1].shape[0], Ws[4].shape[0]
+            x2 = x.reshape(-1, din).contiguous()
+            M = x2.shape[0]
+            sw, gw, pw = C.c_int(0), C.c_int(0), C.c_int(0)
+            _lib.call("pv_block_layout", din, mid, dout, C.byref(sw), C.byref(gw), C.byref(pw))
+            Wc = [w.contiguous() for w in Ws]
+            bc = [q.contiguous() for q in bs]
+            g, be = gamma.contiguous(), beta.contiguous()
+            save = torch.empty((M, sw.value), dtype=torch.float32, device=dev)
+            mean = torch.empty(M, dtype=torch.float32, device=dev)
+            rstd = torch.empty(M, dtype=torch.float32, device=dev)
+            out = torch.empty((M, dout), dtype=torch.float32, device=dev)
+            c = calls[b]
+            c.M, c.Din, c.mid, c.Dout, c.ln_eps, c.accumulate = M, din, mid, dout, eps_list[b], 0
+            c.W, c.Wt, c.bias, c.inv_sigma = _ptrs5(Wc), _ptrs5(wts), _ptrs5(bc), _ptrs5(inv)
+            c.gamma, c.beta = g.data_ptr(), be.data_ptr()
+            c.x, c.ldx, c.save, c.mean, c.rstd, c.out, c.ldo = (x2.data_ptr(), din, save.data_ptr(), mean.data_ptr(),
+                                                                rstd.data_ptr(), out.data_ptr(), dout)
+            saved += [x2, out, save, mean, rstd, g, *inv, *Wc, *bc, *us, *vs]
+            meta.append((M, din, mid, dout, gw.value, pw.value, x.shape, (gamma, beta, tuple(Ws), tuple(bs))))
+            outs.append(out.view(tuple(x.shape[:-1]) + (dout,)))
+        _lib.call("pv_block_fwd", C.byref(calls), n, _stream())
+        ctx.save_for_backward(*saved)
+        ctx.meta = meta
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dout):
-        t = ctx.saved_tensors
-        x2, out, save, mean, rstd, g = t[:6]
-        inv, Wc, bc, us, vs = t[6:11], t[11:16], t[16:21], t[21:26], t[26:31]
-        M, din, mid, do, gw, pw = ctx.dims
-        dev = x2.device
-        p_g, p_b, p_W, p_bias = ctx.params
-        d2 = dout.reshape(M, do).contiguous()
-        nwg = (M + 15) // 16
-        dx = torch.empty((M, din), dtype=torch.float32, device=dev)
-        dY = torch.empty((M, gw), dtype=torch.float32, device=dev)
-        cpart = torch.empty(5 * nwg, dtype=torch.float32, device=dev)
-        ppart = torch.empty((nwg, pw), dtype=torch.float32, device=dev)
-        params = list(p_W) + list(p_bias) + [p_g, p_b]
-        sinks = [grad_sink(p, tuple(p.shape)) for p in params]
-        fused = all(s is not None for s in sinks)          # all-or-nothing: one accumulate flag for the launch group
-        grads = sinks if fused else [torch.empty(tuple(p.shape), dtype=torch.float32, device=dev) for p in params]
-        _lib.call("pv_block_bwd", _p(d2), do, _p(x2), din, _p(out), do, M, din, mid, do, _ptr_table(list(Wc)),
-                  _ptr_table(list(bc)), _ptr_table(list(inv)), _p(g), _p(save), _p(mean), _p(rstd), _p(dx), din, _p(dY),
-                  _p(cpart), _p(ppart), _ptr_table(list(us)), _ptr_table(list(vs)), _ptr_table(grads[0:5]),
-                  _ptr_table(grads[5:10]), _p(grads[10]), _p(grads[11]), 1 if fused else 0, _stream())
-        ret = [None] * 12 if fused else grads
-        dW, db, dg, dbe = ret[0:5], ret[5:10], ret[10], ret[11]
-        return (dx.view(ctx.xshape), dg, dbe, None) + (None,) * 5 + tuple(dW) + tuple(db) + (None,) * 15
+    def backward(ctx, *douts):
+        meta = ctx.meta
+        n = len(meta)
+        st = ctx.saved_tensors
+        per = len(st) // n
+        dev = st[0].device
+        live = [b for b in range(n) if douts[b] is not None]
+        calls = (_lib.BlockCall * max(len(live), 1))()
+        keep, results = [], {}
+        for k, b in enumerate(live):
+            t = st[b * per:(b + 1) * per]
+            x2, out, save, mean, rstd, g = t[:6]
+            inv, Wc, bc, us, vs = t[6:11], t[11:16], t[16:21], t[21:26], t[26:31]
+            M, din, mid, do, gw, pw, xshape, (p_g, p_b, p_W, p_bias) = meta[b]
+            d2 = douts[b].reshape(M, do).contiguous()
+            nwg = (M + 15) // 16
+            dx = torch.empty((M, din), dtype=torch.float32, device=dev)
+            dY = torch.empty((M, gw), dtype=torch.float32, device=dev)
+            cpart = torch.empty(5 * nwg, dtype=torch.float32, device=dev)
+            ppart = torch.empty((nwg, pw), dtype=torch.float32, device=dev)
+            params = list(p_W) + list(p_bias) + [p_g, p_b]
+            sinks = [grad_sink(p, tuple(p.shape)) for p in params]
+            fused = all(s is not None for s in sinks)      # all-or-nothing: one accumulate flag per Block
+            grads = sinks if fused else [torch.empty(tuple(p.shape), dtype=torch.float32, device=dev) for p in params]
+            c = calls[k]
+            c.M, c.Din, c.mid, c.Dout, c.ln_eps, c.accumulate = M, din, mid, do, 0.0, 1 if fused else 0
+            c.W, c.bias, c.inv_sigma, c.u, c.v = _ptrs5(Wc), _ptrs5(bc), _ptrs5(inv), _ptrs5(us), _ptrs5(vs)
+            c.gamma, c.beta = g.data_ptr(), None
+            c.x, c.ldx, c.save, c.mean, c.rstd, c.out, c.ldo = (x2.data_ptr(), din, save.data_ptr(), mean.data_ptr(),
+                                                                rstd.data_ptr(), out.data_ptr(), do)
+            c.dout, c.lddo, c.dx, c.lddx = d2.data_ptr(), do, dx.data_ptr(), din
+            c.dY, c.cpart, c.ppart = dY.data_ptr(), cpart.data_ptr(), ppart.data_ptr()
+            c.dW, c.db = _ptrs5(grads[0:5]), _ptrs5(grads[5:10])
+            c.dgamma, c.dbeta = grads[10].data_ptr(), grads[11].data_ptr()
+            keep += [d2, dY, cpart, ppart]
+            results[b] = (dx.view(xshape), None if fused else grads)
+        if live:
+            _lib.call("pv_block_bwd", C.byref(calls), len(live), _stream())
+        ret = [None]
+        for b in range(n):
+            if b not in results:
+                ret += [None] * NPB
+                continue
+            dx, grads = results[b]
+            dW = [None] * 5 if grads is None else grads[0:5]
+            db = [None] * 5 if grads is None else grads[5:10]
+            dg, dbe = (None, None) if grads is None else (grads[10], grads[11])
+            ret += [dx, dg, dbe] + [None] * 5 + list(dW) + list(db) + [None] * 15
+        return tuple(ret)
 
 
-def block_forward(blk, x):
-    """Run a dls_latent.Block through BlockFn (the caller checked block_fusable)."""
+def _block_args(blk):
+    """BlockGroupFn's per-Block arguments after x (consumes the pre-pass results of the five linears)."""
     lins = (blk.c1, blk.c2, blk.c3, blk.c4, blk.translate)
     if any(m._inv_sigma_pre is None or getattr(m, "_wt_pre", None) is None for m in lins):
         spectral_prepass(list(lins), blk.training, lins[0].eps)
@@ -1141,8 +1187,24 @@ def block_forward(blk, x):
         m._inv_sigma_pre = None
         m._wt_pre = None
     ln = blk.layer_norm
-    return BlockFn.apply(x, ln.weight, ln.bias, ln.eps, *inv, *[m.weight_orig for m in lins], *[m.bias for m in lins],
-                         *us, *vs, *wts)
+    return [ln.weight, ln.bias, *inv, *[m.weight_orig for m in lins], *[m.bias for m in lins], *us, *vs, *wts]
+
+
+def block_forward(blk, x):
+    """Run a dls_latent.Block through the fused kernels (the caller checked block_fusable)."""
+    return BlockGroupFn.apply([blk.layer_norm.eps], x, *_block_args(blk))[0]
+
+
+def blocks_forward(blks, xs):
+    """Independent fusable Blocks side by side: one launch per pv_block_fwd group of up to three."""
+    outs = []
+    for i in range(0, len(blks), _lib.BLOCK_GROUP_MAX):
+        grp, gx = blks[i:i + _lib.BLOCK_GROUP_MAX], xs[i:i + _lib.BLOCK_GROUP_MAX]
+        flat = []
+        for blk, x in zip(grp, gx):
+            flat += [x] + _block_args(blk)
+        outs += list(BlockGroupFn.apply([b.layer_norm.eps for b in grp], *flat))
+    return outs
 
 
 class L2NormRows(torch.autograd.Function):
