@@ -174,9 +174,13 @@ int pv_spectral_norm(const float* W, float* u, float* v, int n_out, int n_in, fl
                      void* stream);
 /* Multi-tensor form: `descs` is a device array of `count` records {const float* W; float* u; float* v;
  * float* inv_sigma; int64 n_out; int64 n_in; float* Wt} (56 bytes each); one workgroup per weight, one launch per step.
- * transpose != 0: records with Wt != NULL also get Wt [n_in][n_out] = W^T (the weight layout pv_block_fwd streams). */
+ * transpose != 0: records with Wt != NULL also get Wt [n_in][n_out] = W^T (the weight layout pv_block_fwd streams).
+ * workspace (pv_spectral_norm_multi_ws_bytes, or NULL): with it the iteration is split at its two norms into three
+ * launches whose workgroups own 64-column / 64-row slabs (the whole chip reads the weights); without it one workgroup
+ * walks each weight. */
+size_t pv_spectral_norm_multi_ws_bytes(int count, int max_out);
 int pv_spectral_norm_multi(const void* descs, int count, int max_out, int max_in, float eps, int do_iter, int transpose,
-                           void* stream);
+                           void* workspace, void* stream);
 /* One pass over dy: db[n] (+)= sum_m dy (db may be NULL) and cpart[j] = sum over the j-th 64-column block of
  * dy * (y - bias); sum_j cpart[j] = <dL/dW_eff, W_eff>, consumed by pv_linear_f32_fused's rank-1 epilogue. */
 int pv_spectral_norm_reduce(const float* dy, const float* y, const float* bias, int M, int N, float* db,

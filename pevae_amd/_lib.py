@@ -70,7 +70,8 @@ SIGNATURES = {
     "pv_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     "pv_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp]),
     "pv_spectral_norm": (i32, [vp, vp, vp, i32, i32, f32, i32, vp, vp]),
-    "pv_spectral_norm_multi": (i32, [vp, i32, i32, i32, f32, i32, i32, vp]),
+    "pv_spectral_norm_multi": (i32, [vp, i32, i32, i32, f32, i32, i32, vp, vp]),
+    "pv_spectral_norm_multi_ws_bytes": (sz, [i32, i32]),
     "pv_spectral_norm_reduce": (i32, [vp, vp, vp, i32, i32, vp, i32, vp, vp]),
     "pv_linear_f32_fused": (i32, [vp, lng, lng, vp, lng, lng, vp, vp, lng, i32, i32, i32, f32, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
     "pv_spectral_norm_bwd": (i32, [vp, vp, vp, lng, i32, i32, vp, vp, vp, vp, vp, vp]),

@@ -208,6 +208,112 @@ __global__ __launch_bounds__(256) void spectral_iter_multi_kernel(const SnDesc* 
   spectral_iter_body(d.W, d.u, d.v, (int)d.n_out, (int)d.n_in, eps, do_iter, d.inv_sigma);
 }
 
+// ---- the multi-tensor pre-pass, spread over the chip ------------------------------------------------------------
+// One workgroup per weight reads a 512x512 matrix twice on a single CU (~220 us on the critical path of every step).
+// The power iteration is two mat-vecs with a norm in between, so it is split at the norms into three launches whose
+// workgroups each own a 64-column / 64-row slab of one weight:
+//   phase 1 (training): v <- W^T u (unnormalised, in place), pn1[weight][slab] = partial |v|^2
+//   phase 2           : wv = W (v / |v|) -> workspace, pn2[weight][slab] = partial |wv|^2
+//   phase 3           : training: u <- wv / |wv|, v <- v / |v|;   1/sigma = 1 / (u . wv)
+// workspace per weight: SN_WS_HDR floats of partials + max_out floats of wv.  Partials are summed in slab order.
+constexpr int SN_SLABS = 16;               // up to 1024 rows / columns
+constexpr int SN_WS_HDR = 2 * SN_SLABS;
+
+__device__ __forceinline__ float sn_inv_norm(const float* part, int nslab, float eps) {
+  float nn = 0.f;
+  for (int i = 0; i < nslab; ++i) nn += part[i];
+  return 1.f / fmaxf(sqrtf(nn), eps);
+}
+
+__global__ __launch_bounds__(256) void sn_phase1_kernel(const SnDesc* __restrict__ desc, float* __restrict__ ws, int ws_stride) {
+  __shared__ float part[4][64];
+  __shared__ float red[4];
+  const SnDesc d = desc[blockIdx.y];
+  const int n_out = (int)d.n_out, n_in = (int)d.n_in, j0 = blockIdx.x * 64;
+  if (j0 >= n_in) return;
+  const int c = threadIdx.x & 63, rq = threadIdx.x >> 6, j = min(j0 + c, n_in - 1);
+  float sacc = 0.f;
+  int i = rq;
+  for (; i + 28 < n_out; i += 32) {                  // 8 independent loads in flight
+    float wv8[8], u8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      wv8[k] = d.W[(size_t)(i + 4 * k) * n_in + j];
+      u8[k] = d.u[i + 4 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sacc += wv8[k] * u8[k];
+  }
+  for (; i < n_out; i += 4) sacc += d.W[(size_t)i * n_in + j] * d.u[i];
+  part[rq][c] = sacc;
+  __syncthreads();
+  float t = 0.f;
+  if (rq == 0) {
+    t = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+    if (j0 + c < n_in) d.v[j0 + c] = t; else t = 0.f;
+  }
+  const float nn = block_sum(t * t, red);
+  if (threadIdx.x == 0) ws[(size_t)blockIdx.y * ws_stride + blockIdx.x] = nn;
+}
+
+__global__ __launch_bounds__(256) void sn_phase2_kernel(const SnDesc* __restrict__ desc, float* __restrict__ ws, int ws_stride,
+                                                         float eps, int do_iter) {
+  extern __shared__ float sv[];                      // v / |v|  [n_in]
+  __shared__ float red[4];
+  const SnDesc d = desc[blockIdx.y];
+  const int n_out = (int)d.n_out, n_in = (int)d.n_in, i0 = blockIdx.x * 64;
+  if (i0 >= n_out) return;
+  float* wsw = ws + (size_t)blockIdx.y * ws_stride;
+  const float inv = do_iter ? sn_inv_norm(wsw, (n_in + 63) / 64, eps) : 1.f;
+  for (int j = threadIdx.x; j < n_in; j += 256) sv[j] = d.v[j] * inv;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float nn = 0.f;
+  for (int r = 0; r < 16; r += 4) {                  // wave w: rows i0 + 16 w + r .. + 3, four row sums side by side
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = lane; j < n_in; j += 64) {
+      const float vj = sv[j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s4[k] += d.W[(size_t)min(i0 + 16 * w + r + k, n_out - 1) * n_in + j] * vj;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float t = wave_sum(s4[k]);
+      const int i = i0 + 16 * w + r + k;
+      if (i < n_out) {
+        if (lane == 0) wsw[SN_WS_HDR + i] = t;
+        nn += t * t;                                  // identical in every lane
+      }
+    }
+  }
+  __syncthreads();
+  if (lane == 0) red[w] = nn;
+  __syncthreads();
+  if (threadIdx.x == 0) wsw[SN_SLABS + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ __launch_bounds__(256) void sn_phase3_kernel(const SnDesc* __restrict__ desc, const float* __restrict__ ws,
+                                                         int ws_stride, float eps, int do_iter) {
+  __shared__ float red[4];
+  const SnDesc d = desc[blockIdx.x];
+  const int n_out = (int)d.n_out, n_in = (int)d.n_in;
+  const float* wsw = ws + (size_t)blockIdx.x * ws_stride;
+  float dot = 0.f;
+  if (do_iter) {
+    const float inv_v = sn_inv_norm(wsw, (n_in + 63) / 64, eps), inv_u = sn_inv_norm(wsw + SN_SLABS, (n_out + 63) / 64, eps);
+    for (int j = threadIdx.x; j < n_in; j += 256) d.v[j] *= inv_v;
+    for (int i = threadIdx.x; i < n_out; i += 256) {
+      const float wv = wsw[SN_WS_HDR + i], un = wv * inv_u;
+      d.u[i] = un;
+      dot += un * wv;
+    }
+  } else {
+    for (int i = threadIdx.x; i < n_out; i += 256) dot += d.u[i] * wsw[SN_WS_HDR + i];
+  }
+  dot = block_sum(dot, red);
+  if (threadIdx.x == 0) d.inv_sigma[0] = 1.f / dot;
+}
+
 // W^T of every described weight (32x32 tiles through LDS; blockIdx.y = weight, blockIdx.x walks its tiles)
 __global__ __launch_bounds__(256) void sn_transpose_multi_kernel(const SnDesc* __restrict__ desc) {
   __shared__ float tile[32][33];
@@ -387,8 +493,36 @@ int pv_spectral_norm(const float* W, float* u, float* v, int n_out, int n_in, fl
 }
 
 /* descs: device array of {W, u, v, inv_sigma (pointers), n_out, n_in (int64), Wt (pointer or 0)} records, 56 bytes each */
+size_t pv_spectral_norm_multi_ws_bytes(int count, int max_out) {
+  return (size_t)count * (SN_WS_HDR + (size_t)round_up(max_out > 0 ? max_out : 1, 4)) * sizeof(float);
+}
+
 int pv_spectral_norm_multi(const void* descs, int count, int max_out, int max_in, float eps, int do_iter, int transpose,
-                           void* stream) {
+                           void* workspace, void* stream) {
+  if (workspace) {
+    PV_REQUIRE(descs && count > 0 && max_out > 0 && max_in > 0, "pv_spectral_norm_multi: bad argument");
+    PV_REQUIRE(max_out <= 64 * SN_SLABS && max_in <= 64 * SN_SLABS, "pv_spectral_norm_multi: %d x %d exceeds %d rows / columns",
+               max_out, max_in, 64 * SN_SLABS);
+    hipStream_t st = (hipStream_t)stream;
+    const SnDesc* dd = (const SnDesc*)descs;
+    float* ws = (float*)workspace;
+    const int stride = SN_WS_HDR + round_up(max_out, 4);
+    if (do_iter) {
+      hipLaunchKernelGGL(sn_phase1_kernel, dim3(cdiv(max_in, 64), count), dim3(256), 0, st, dd, ws, stride);
+      PV_LAUNCH_CHECK("sn_phase1_kernel");
+    }
+    hipLaunchKernelGGL(sn_phase2_kernel, dim3(cdiv(max_out, 64), count), dim3(256), (size_t)max_in * sizeof(float), st, dd, ws,
+                       stride, eps, do_iter);
+    PV_LAUNCH_CHECK("sn_phase2_kernel");
+    hipLaunchKernelGGL(sn_phase3_kernel, dim3(count), dim3(256), 0, st, dd, (const float*)ws, stride, eps, do_iter);
+    PV_LAUNCH_CHECK("sn_phase3_kernel");
+    if (transpose) {
+      const int tiles = cdiv(max_out, 32) * cdiv(max_in, 32);
+      hipLaunchKernelGGL(sn_transpose_multi_kernel, dim3(tiles < 64 ? tiles : 64, count), dim3(256), 0, st, dd);
+      PV_LAUNCH_CHECK("sn_transpose_multi_kernel");
+    }
+    return PV_OK;
+  }
   PV_REQUIRE(descs && count > 0 && max_out > 0 && max_in > 0, "pv_spectral_norm_multi: bad argument");
   const size_t smem = (size_t)(2 * max_out + max_in + 4) * sizeof(float);
   PV_REQUIRE(smem <= 64 * 1024, "pv_spectral_norm_multi: %d x %d exceeds the 64 KiB LDS staging", max_out, max_in);

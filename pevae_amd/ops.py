@@ -1045,10 +1045,13 @@ def spectral_prepass(modules, training, eps=1e-12, cache=None):
             wts.append(wt[off:off + sizes[i]].view(n_in, n_out))
             rec[i] = (ptrs[i][0], ptrs[i][1], ptrs[i][2], inv.data_ptr() + 4 * i, n_out, n_in, wts[i].data_ptr())
             off += sizes[i]
-        cache.update(ptrs=ptrs, inv=inv, wts=wts, desc=torch.from_numpy(rec).to(dev), max_out=int(rec[:, 4].max()),
-                     max_in=int(rec[:, 5].max()))
+        max_out, max_in = int(rec[:, 4].max()), int(rec[:, 5].max())
+        ws = None
+        if max(max_out, max_in) <= 1024:
+            ws = torch.empty(_lib.load().pv_spectral_norm_multi_ws_bytes(len(modules), max_out), dtype=torch.uint8, device=dev)
+        cache.update(ptrs=ptrs, inv=inv, wts=wts, desc=torch.from_numpy(rec).to(dev), max_out=max_out, max_in=max_in, ws=ws)
     _lib.call("pv_spectral_norm_multi", _p(cache["desc"]), len(modules), cache["max_out"], cache["max_in"], eps,
-              1 if training else 0, 1 if FUSED_BLOCK else 0, _stream())
+              1 if training else 0, 1 if FUSED_BLOCK else 0, _p(cache["ws"]), _stream())
     for i, m in enumerate(modules):
         m._inv_sigma_pre = cache["inv"][i:i + 1]
         m._wt_pre = cache["wts"][i]
