@@ -100,6 +100,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi ep
     swz[i] = (c16 >> 1) & 7;   // (row>>1)&7 : rows are 16-aligned + c16, so only c16 matters
   }
 
+  // what the epilogue reads from global memory (bias, targets, row statistics) is requested now, a whole main loop
+  // ahead of its use: at K = 512 a tile's main loop is ~4 us and an exposed load round trip in the epilogue ~1-2 us
+  const typename Epi::Pre pre = epi.prefetch(m0 + wm * 64, n0 + wn * 64, lane);
   const int nk_all = g.K / BK;
   const int kt0 = g.kt_per_split ? blockIdx.y * g.kt_per_split : 0;
   const int nk = g.kt_per_split ? min(nk_all, kt0 + g.kt_per_split) : nk_all;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi ep
     }
   }
   __syncthreads();   // all waves done with the ring: epilogues may reuse smem
-  epi(acc, m0 + wm * 64, n0 + wn * 64, w, lane, smem);
+  epi(acc, pre, m0 + wm * 64, n0 + wn * 64, w, lane, smem);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -140,7 +143,9 @@ struct EpiStore {
   const float* bias;
   int M, N, ldc, ldcb, accumulate, bias_per_row;
   long split_stride;   // split-K: slab blockIdx.y of the fp32 output starts at C + y * split_stride
-  __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
+  struct Pre {};
+  __device__ Pre prefetch(int, int, int) const { return Pre{}; }
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem) const {
     const int c16 = lane & 15, q4 = lane >> 4;
     float* C = this->C ? this->C + (long)blockIdx.y * split_stride : nullptr;
 #pragma unroll
@@ -166,6 +171,25 @@ struct EpiStore {
   }
 };
 
+// reductions over the 16 lanes that share lane >> 4, on the DPP cross-lane path (full-rate VALU; a ds_bpermute shuffle
+// is a ~100-cycle LDS round trip, and 128 of them in a dependent chain made this epilogue 40 % of the kernel)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_mov<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_mov<0x141>(v));     // row_half_mirror
+  return fmaxf(v, dpp_mov<0x140>(v));  // row_mirror
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  return v + dpp_mov<0x140>(v);
+}
+
 struct EpiSoftmax {
   const float* bias;        // [V]
   const int64_t* target;    // [T]
@@ -173,7 +197,20 @@ struct EpiSoftmax {
   float* tgt_logit;         // [T]
   int T, V, Tpad;
   float inv_temp;
-  __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
+  struct Pre {
+    float bv[4];
+    int tgt[16];
+  };
+  __device__ Pre prefetch(int row0, int col0, int lane) const {
+    Pre p;
+    const int c16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) p.bv[ni] = bias[min(col0 + ni * 16 + c16, V - 1)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p.tgt[r] = (int)target[min(row0 + (r >> 2) * 16 + q4 * 4 + (r & 3), T - 1)];
+    return p;
+  }
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem) const {
     if (col0 >= V) return;
     const int c16 = lane & 15, q4 = lane >> 4;
     float bv[4];
@@ -182,41 +219,56 @@ struct EpiSoftmax {
     for (int ni = 0; ni < 4; ++ni) {
       const int col = col0 + ni * 16 + c16;
       live[ni] = col < V;
-      bv[ni] = live[ni] ? bias[col] : 0.f;
+      bv[ni] = live[ni] ? pre.bv[ni] : 0.f;
     }
+    // the 16 rows of this lane in two halves of 8: 8 independent reduction chains each
     float my_m = 0.f, my_s = 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int h = 0; h < 2; ++h) {
+      int tc[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = row0 + mi * 16 + q4 * 4 + j;
+      for (int r = 0; r < 8; ++r) {
+        const int row = row0 + (2 * h + (r >> 2)) * 16 + q4 * 4 + (r & 3);
+        tc[r] = row < T ? pre.tgt[8 * h + r] - col0 : -1;
+      }
+      float m[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int mi = 2 * h + (r >> 2), j = r & 3;
         float x[4];
-        float m = -INFINITY;
+        float mx = -INFINITY;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           x[ni] = live[ni] ? (acc[mi][ni][j] + bv[ni]) * inv_temp : -INFINITY;
-          m = fmaxf(m, x[ni]);
+          mx = fmaxf(mx, x[ni]);
         }
-        if (row < T) {
-          const int tc = (int)target[row] - col0;      // target column relative to this slab
-          if (tc >= 0 && tc < 64 && (tc & 15) == c16) {
-            const int tn = tc >> 4;
-            const float xv = tn == 0 ? x[0] : tn == 1 ? x[1] : tn == 2 ? x[2] : x[3];
-            tgt_logit[row] = xv;
-          }
+        if (tc[r] >= 0 && tc[r] < 64 && (tc[r] & 15) == c16) {
+          const int tn = tc[r] >> 4;
+          tgt_logit[row0 + mi * 16 + q4 * 4 + j] = tn == 0 ? x[0] : tn == 1 ? x[1] : tn == 2 ? x[2] : x[3];
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float s = 0.f;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) s += __expf(x[ni] - m);     // exp(-inf) = 0 for masked columns
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
-        if (c16 == mi * 4 + j) {
-          my_m = m;
-          my_s = s;
-        }
+        m[r] = mx;
       }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) m[r] = row16_max(m[r]);
+      float sm[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int mi = 2 * h + (r >> 2), j = r & 3;
+        float t = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          t += live[ni] ? __expf((acc[mi][ni][j] + bv[ni]) * inv_temp - m[r]) : 0.f;
+        sm[r] = t;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sm[r] = row16_sum(sm[r]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (c16 == 8 * h + r) {
+          my_m = m[r];
+          my_s = sm[r];
+        }
+    }
     // lane (q4, c16) publishes row  (c16>>2)*16 + q4*4 + (c16&3)
     const int row = row0 + (c16 >> 2) * 16 + q4 * 4 + (c16 & 3);
     if (row < Tpad) part[(size_t)(col0 >> 6) * Tpad + row] = make_float2(my_m, my_s);
@@ -236,7 +288,26 @@ struct EpiProb {
   float* dbias_part;        // [Tpad/64][ldp]
   int T, V, Tpad, Vpad, ldp, ldpt;
   float inv_temp;
-  __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
+  struct Pre {
+    float bv[4];
+    int tgt[16];
+    float lse[16], gs[16];
+  };
+  __device__ Pre prefetch(int row0, int col0, int lane) const {
+    Pre p;
+    const int c16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) p.bv[ni] = bias[min(col0 + ni * 16 + c16, V - 1)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(row0 + (r >> 2) * 16 + q4 * 4 + (r & 3), T - 1);
+      p.tgt[r] = (int)target[row];
+      p.lse[r] = lse[row];
+      p.gs[r] = gscale[row];
+    }
+    return p;
+  }
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem) const {
     const int c16 = lane & 15, q4 = lane >> 4;
     const bool slab_live = (col0 < Vpad) && (row0 < Tpad);
     char* my = smem + w * EPI_WAVE_BYTES;
@@ -246,7 +317,7 @@ struct EpiProb {
     for (int ni = 0; ni < 4; ++ni) {
       const int col = col0 + ni * 16 + c16;
       live[ni] = col < V;
-      bv[ni] = live[ni] ? bias[col] : 0.f;
+      bv[ni] = live[ni] ? pre.bv[ni] : 0.f;
     }
     float colsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -255,9 +326,9 @@ struct EpiProb {
       for (int j = 0; j < 4; ++j) {
         const int row = row0 + mi * 16 + q4 * 4 + j;
         const bool rl = row < T;
-        const float l = rl ? lse[row] : 0.f;
-        const float gs = rl ? gscale[row] * inv_temp : 0.f;
-        const int tc = rl ? (int)target[row] - col0 : -1;
+        const float l = rl ? pre.lse[mi * 4 + j] : 0.f;
+        const float gs = rl ? pre.gs[mi * 4 + j] * inv_temp : 0.f;
+        const int tc = rl ? pre.tgt[mi * 4 + j] - col0 : -1;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           float p = 0.f;
@@ -326,7 +397,9 @@ struct EpiLogProb {
   float* out;         // [T][V] dense log-probs
   int T, V;
   float inv_temp;
-  __device__ void operator()(f32x4 (&acc)[4][4], int row0, int col0, int w, int lane, char* smem) const {
+  struct Pre {};
+  __device__ Pre prefetch(int, int, int) const { return Pre{}; }
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem) const {
     const int c16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -431,6 +504,30 @@ int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N
   EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb, accumulate, bias_per_row, 0};
   return launch(g, e, (hipStream_t)stream, "pv_gemm_bf16_nt");
 }
+
+#ifdef PV_GEMM_DEBUG
+// diagnostic build only: the GEMM main loop with a (nearly) empty epilogue, to time epilogues by difference
+struct EpiNone {
+  float* sink;
+  struct Pre {};
+  __device__ Pre prefetch(int, int, int) const { return Pre{}; }
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem) const {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 1234.5678f) sink[0] = s;
+  }
+};
+}
+extern "C" int pv_gemm_bf16_nt_noepi(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* sink, void* stream) {
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, 0};
+  EpiNone e{sink};
+  return launch(g, e, (hipStream_t)stream, "noepi");
+}
+extern "C" {
+#endif
 
 int pv_gemm_splitk_plan(int M, int N, int K, int target_wgs, int* splits) {
   PV_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && splits, "pv_gemm_splitk_plan: bad argument");
