@@ -356,6 +356,46 @@ def gen_dialog_pieces(utils):
          anneal_linear=anneal_lin)
 
 
+def gen_den_auto():
+    """DeN_Auto (dialog_models.py:2611-2764), training branch, from the reference class itself (it constructs on CPU).
+    Its random draws (torch.rand_like at :2658, exponential_ at :2682) come from the seeded CPU generator; the same
+    stream is re-drawn here in the same order and stored, so the HIP path and the oracle take the draws as inputs."""
+    from models import dialog_models as dm
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_modules as R
+    cfg = types.SimpleNamespace(expand_weight=0.5, converge_weight=0.1, ost=False, no_mutual_information=False)
+    torch.manual_seed(71)
+    B, d0, dmax, nlev = 8, 16, 32, 2
+    m = dm.DeN_Auto(d0, dmax, cfg)
+    m.train()
+    pre = {k: npy(v).copy() for k, v in m.state_dict().items()}
+    widths = [2 * d0 * 2 ** i for i in range(nlev)]              # act[-1], act[-2]
+    output = torch.randn(B, d0, requires_grad=True)
+    act1 = [torch.randn(B, w, requires_grad=True) for w in reversed(widths)]
+    act2 = [torch.randn(B, w, requires_grad=True) for w in reversed(widths)]
+    torch.manual_seed(72)
+    z, rkl = m(output, act1, act2, None, False)
+    (z.sum() * 0.01 + rkl).backward()
+    torch.manual_seed(72)
+    noise, gumbels = [], []
+    for w in widths:
+        noise.append(torch.rand(B, w))
+        gumbels.append(-torch.empty(B, B).exponential_().log())
+    # the re-drawn stream reproduces the reference: the oracle restatement fed with it must agree
+    o = R.DeNAuto(d0, dmax, cfg)
+    o.load_state_dict({k: torch.from_numpy(v) for k, v in pre.items()})
+    o.train()
+    z2, rkl2 = o(output.detach(), [a.detach() for a in act1], [a.detach() for a in act2], False, noise, gumbels)
+    assert torch.allclose(z2, z, rtol=1e-5, atol=1e-6) and abs(float(rkl2) - float(rkl)) < 1e-5 * abs(float(rkl)), \
+        (float((z2 - z).abs().max()), float(rkl2), float(rkl))
+    arrs = dict(output=output, z=z, rkl=rkl, d_output=output.grad)
+    for i in range(nlev):
+        arrs.update({"act1_%d" % i: act1[i], "act2_%d" % i: act2[i], "d_act1_%d" % i: act1[i].grad,
+                     "d_act2_%d" % i: act2[i].grad, "noise_%d" % i: noise[i], "gumbel_%d" % i: gumbels[i]})
+    post = {k: v for k, v in sd(m, "post.").items() if k.endswith("weight_u") or k.endswith("weight_v")}
+    save("den_auto", **arrs, **{"p." + k: v for k, v in pre.items()}, **post, **grads(m))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -366,7 +406,7 @@ def main():
     todo = dict(encoder=lambda: gen_encoder(encoders), decoder=lambda: gen_decoder(decoders),
                 attention=lambda: gen_attention(decoders), connectors=lambda: gen_connectors(nn_lib),
                 criterions=lambda: gen_criterions(criterions),
-                dialog=lambda: gen_dialog_pieces(utils))
+                dialog=lambda: gen_dialog_pieces(utils), den=gen_den_auto)
     for k, fn in todo.items():
         if not args.only or k in args.only.split(","):
             fn()

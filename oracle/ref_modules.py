@@ -771,3 +771,89 @@ class DLSAuto(nn.Module):
                     last_sample = t_mean + a2
                 output = torch.nan_to_num(layer(output) + last_sample)
         return output, rkl
+
+
+def gumbel_sampling(samples, gumbels):
+    """DeN_Auto.gumbel_sampling, dialog_models.py:2674-2685: hard-negative indices.  Row-normalise, cosine scores
+    with the diagonal pushed down by the matrix maximum, log(1 + 1e-6 + score), Gumbel-max over each row.  The reference
+    draws `gumbels = -log(Exp(1))` inside (:2682); here the draw is an argument."""
+    ratio = torch.sqrt(torch.sum(samples * samples, -1))
+    samples = samples / ratio.unsqueeze(-1)
+    sc = samples @ samples.transpose(0, 1)
+    dig = torch.diag(torch.ones_like(ratio) * torch.max(sc))
+    scores = torch.log(1 + 1e-6 + sc - dig)
+    return (scores + gumbels).max(-1)[1]
+
+
+class DeNAuto(nn.Module):
+    """DeN_Auto, dialog_models.py:2611-2764: the DEM / Self-Adaption-Fusion sibling of DLS_Auto.  Per level: posterior
+    and prior Blocks, gaussian_merge of the two (:2687-2693), two detached-direction KLs against the merged Gaussian
+    (:2716-2717), uniform reparameterisation of the MERGED Gaussian (:2719) and the discriminator term
+    -mean(log(pos + 1e-6) + log(1 - neg + 1e-6)) with Gumbel hard negatives (:2721-2727).  `noise`: per level the
+    uniform draw of :2658 ([B, 2d]); `gumbels`: per level the -log(Exp(1)) draw of :2682 ([B, B]).
+    The restarted / ost branch (:2730-2762) is restated with `mean, logvar` computed whenever they are used (the
+    reference reads them unbound when ost is set without restarted)."""
+
+    def __init__(self, input_dim, output_dim, config):
+        super().__init__()
+        self.config = config
+        self.layers, self.dis_layers, self.dis_layers2 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.y_z_info = nn.ModuleList()
+        cnt = 0
+        while input_dim <= output_dim:
+            self.layers.append(Block(input_dim, input_dim * 2, input_dim * 2))
+            k = 2 if cnt == 0 else 3
+            self.dis_layers.append(Block(input_dim * k, input_dim * 4, input_dim * 4))
+            self.dis_layers2.append(Block(input_dim * k, input_dim * 4, input_dim * 4))
+            self.y_z_info.append(nn.Sequential(Block(input_dim * 4, input_dim * 4), Block(input_dim * 4, 1, input_dim),
+                                               nn.Sigmoid()))
+            input_dim *= 2
+            cnt += 1
+
+    def forward(self, output, act1, act2, restarted=False, noise=None, gumbels=None):
+        cfg = self.config
+        ew, cw = cfg.expand_weight, cfg.converge_weight
+        rkl = 0
+        last_sample = last_t = None
+        train_branch = not restarted and not getattr(cfg, "ost", False)
+        for i, (layer, dis, dis2, m_layer) in enumerate(zip(self.layers, self.dis_layers, self.dis_layers2, self.y_z_info)):
+            a1, a2 = act1[-i - 1], act2[-i - 1]
+            if train_branch:
+                if last_sample is None:
+                    q_in, p_in = a1 + a2, a2
+                else:
+                    q_in, p_in = torch.cat([a1 + a2, last_sample], -1), torch.cat([a2, last_t], -1)
+                mean, lv = dis(q_in).chunk(2, -1)
+                t_mean, t_lv = dis2(p_in).chunk(2, -1)
+                last_t = t_mean
+                m_mean, m_lv = gaussian_merge(t_mean, mean, t_lv, lv)
+                rkl = rkl + ew * gaussian_analytical_kl(t_mean, m_mean.detach(), t_lv, m_lv.detach())
+                rkl = rkl + cw * gaussian_analytical_kl(m_mean.detach(), mean, m_lv.detach(), lv)
+                eps = noise[i] if noise is not None else torch.rand_like(m_lv)
+                last_sample = reparameterization(m_mean, m_lv, eps) + a2
+                if not getattr(cfg, "no_mutual_information", False):
+                    g = gumbels[i] if gumbels is not None else -torch.empty(a2.size(0), a2.size(0)).exponential_().log()
+                    perm = gumbel_sampling(last_sample.detach().clone(), g)
+                    pos = m_layer(torch.cat([last_t, last_sample], -1))
+                    neg = m_layer(torch.cat([last_t, last_sample[perm]], -1))
+                    rkl = rkl - torch.mean(torch.log(pos + 1e-6) + torch.log(1 - neg + 1e-6))
+                output = layer(output) + last_sample
+            else:
+                need_q = restarted or self.training
+                if last_sample is None:
+                    q_in, p_in = a1, a2
+                else:
+                    q_in, p_in = torch.cat([a1, last_sample], -1), torch.cat([a2, last_sample], -1)
+                t_mean, t_lv = dis2(p_in).chunk(2, -1)
+                if need_q:
+                    mean, lv = dis(q_in).chunk(2, -1)
+                if self.training:
+                    eps = noise[i] if noise is not None else torch.rand_like(t_lv)
+                    last_sample = reparameterization(t_mean, t_lv, eps) + a2
+                    m_mean, m_lv = gaussian_merge(t_mean, mean, t_lv, lv)
+                    rkl = rkl + ew * gaussian_analytical_kl(t_mean, m_mean.detach(), t_lv, m_lv.detach())
+                    rkl = rkl + cw * gaussian_analytical_kl(m_mean.detach(), mean, m_lv.detach(), lv)
+                else:
+                    last_sample = t_mean + a2
+                output = torch.nan_to_num(layer(output) + last_sample)
+        return output, rkl

@@ -189,3 +189,108 @@ class DLSAuto(nn.Module):
                     last_sample = t_mean + a2                                                      # :3350
                 output = torch.nan_to_num(lay_out + last_sample)                                   # :3351
         return output, rkl
+
+
+def gaussian_merge(mean1, mean2, logvar1, logvar2):
+    """DeN_Auto.gaussian_merge (dialog_models.py:2687-2693): product-style fusion of two Gaussians given as
+    (mean, logvar); the merged variance is doubled ("Var Non decrease")."""
+    var1, var2 = logvar1.exp(), logvar2.exp()
+    mean = (var1 * mean2 + var2 * mean1) / (var1 + var2)
+    return mean, (2 * (var1 * var2) / (var1 + var2)).log()
+
+
+def gumbel_sampling(samples, gumbels=None):
+    """DeN_Auto.gumbel_sampling (dialog_models.py:2674-2685): one hard-negative row index per row by Gumbel-max over
+    log(1 + 1e-6 + cosine score), the diagonal pushed down by the matrix maximum.  `gumbels`: the -log(Exp(1)) draw
+    of :2682 (drawn on the device when None).  No gradient (the reference passes a detached clone)."""
+    with torch.no_grad():
+        a = ops.L2NormRows.apply(samples.contiguous())
+        sc = ops.ScaledMatmulNT.apply(a, a, 1.0)
+        n = sc.size(0)
+        sc = sc - torch.eye(n, device=sc.device, dtype=sc.dtype) * sc.max()
+        if gumbels is None:
+            gumbels = -torch.empty_like(sc).exponential_().log()
+        return (torch.log(1 + 1e-6 + sc) + gumbels).max(-1)[1]
+
+
+class DeNAuto(nn.Module):
+    """DeN_Auto.forward(output, act1, act2, pos_embeddings, restarted) -> (z, rkl)  (dialog_models.py:2611-2764): the
+    DEM / Self-Adaption-Fusion sibling of DLS_Auto, same parameter names (`layers`, `dis_layers`, `dis_layers2`,
+    `y_z_info.i.{0,1}`).  Per level the posterior and prior Blocks are merged (gaussian_merge), two detached-direction KLs
+    pull each towards the merged Gaussian, the sample comes from the MERGED Gaussian, and a discriminator (two Blocks +
+    sigmoid) scores (prior mean, sample) pairs against Gumbel hard negatives.  `noise` / `gumbels`: the per-level random
+    draws (:2658, :2682) for deterministic parity tests; drawn on the device when None.  `pos_embeddings` is unused by
+    the reference and is not a parameter here."""
+
+    def __init__(self, input_dim, output_dim, config):
+        super().__init__()
+        self.config = config
+        self.layers, self.dis_layers, self.dis_layers2 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.y_z_info = nn.ModuleList()
+        cnt = 0
+        while input_dim <= output_dim:
+            self.layers.append(Block(input_dim, input_dim * 2, input_dim * 2))
+            k = 2 if cnt == 0 else 3
+            self.dis_layers.append(Block(input_dim * k, input_dim * 4, input_dim * 4))
+            self.dis_layers2.append(Block(input_dim * k, input_dim * 4, input_dim * 4))
+            self.y_z_info.append(nn.Sequential(Block(input_dim * 4, input_dim * 4), Block(input_dim * 4, 1, input_dim),
+                                               nn.Sigmoid()))
+            input_dim *= 2
+            cnt += 1
+
+    @staticmethod
+    def _kl(mu1, mu2, ls1, ls2):
+        """gaussian_analytical_kl (:2664-2668), batch mean of the row sums (log-sigma inputs)."""
+        _, k = ops.reparam_kl(mu1, ls1, mu2, ls2, None, mode=1, want_z=False)
+        return ops.mean(k)
+
+    def forward(self, output, act1, act2, restarted=False, noise=None, gumbels=None):
+        cfg = self.config
+        ew, cw = cfg.expand_weight, cfg.converge_weight
+        rkl = 0
+        last_sample = last_t = None
+        train_branch = not restarted and not getattr(cfg, "ost", False)
+        for i, (layer, dis, dis2, m_layer) in enumerate(zip(self.layers, self.dis_layers, self.dis_layers2, self.y_z_info)):
+            a1, a2 = act1[-i - 1], act2[-i - 1]
+            if train_branch:
+                if last_sample is None:
+                    q_in, p_in = a1 + a2, a2
+                else:
+                    q_in, p_in = torch.cat([a1 + a2, last_sample], -1), torch.cat([a2, last_t], -1)
+                res = run_blocks([dis, dis2, layer], [q_in, p_in, output])
+                mean, lv = res[0].chunk(2, -1)
+                t_mean, t_lv = res[1].chunk(2, -1)
+                last_t = t_mean
+                m_mean, m_lv = gaussian_merge(t_mean, mean, t_lv, lv)
+                rkl = rkl + ew * self._kl(t_mean, m_mean.detach(), t_lv, m_lv.detach())         # :2716
+                rkl = rkl + cw * self._kl(m_mean.detach(), mean, m_lv.detach(), lv)             # :2717
+                eps = noise[i] if noise is not None else torch.rand_like(m_lv)
+                z, _ = ops.reparam_kl(m_mean, m_lv, None, None, eps, mode=1, want_kl=False)     # :2719
+                last_sample = z + a2
+                if not getattr(cfg, "no_mutual_information", False):                             # :2721-2727
+                    perm = gumbel_sampling(last_sample.detach(), None if gumbels is None else gumbels[i])
+                    pos = m_layer(torch.cat([last_t, last_sample], -1))
+                    neg = m_layer(torch.cat([last_t, last_sample[perm]], -1))
+                    rkl = rkl - torch.mean(torch.log(pos + 1e-6) + torch.log(1 - neg + 1e-6))
+                output = res[2] + last_sample                                                    # :2729
+            else:
+                need_q = restarted or self.training
+                if last_sample is None:
+                    q_in, p_in = a1, a2
+                else:
+                    q_in, p_in = torch.cat([a1, last_sample], -1), torch.cat([a2, last_sample], -1)
+                res = run_blocks([dis2, layer] + ([dis] if need_q else []), [p_in, output] + ([q_in] if need_q else []))
+                t_mean, t_lv = res[0].chunk(2, -1)
+                if need_q:
+                    mean, lv = res[2].chunk(2, -1)
+                if self.training:
+                    eps = noise[i] if noise is not None else torch.rand_like(t_lv)
+                    z, _ = ops.reparam_kl(t_mean, t_lv, None, None, eps, mode=1, want_kl=False)   # :2756
+                    last_sample = z + a2
+                    m_mean, m_lv = gaussian_merge(t_mean, mean, t_lv, lv)
+                    rkl = rkl + ew * self._kl(t_mean, m_mean.detach(), t_lv, m_lv.detach())       # :2758
+                    rkl = rkl + cw * self._kl(m_mean.detach(), mean, m_lv.detach(), lv)           # :2759
+                else:
+                    last_sample = t_mean + a2                                                    # :2761
+                output = torch.nan_to_num(res[1] + last_sample)                                  # :2762
+        return output, rkl

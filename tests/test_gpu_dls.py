@@ -145,3 +145,40 @@ def test_dls_auto_matches_oracle(dev, restarted, training):
     for n, p in gpu.named_parameters():
         if ref_p[n].grad is not None:
             close(p.grad, ref_p[n].grad, rtol=1e-3, atol=5e-5 + 1e-4 * float(ref_p[n].grad.abs().max()))
+
+
+def test_den_auto_golden(dev):
+    """DeNAuto (DEM discriminator + Self-Adaption Fusion, row a17) against the golden made from the reference's own
+    DeN_Auto class: z, rkl, every input / parameter gradient, the advanced power-iteration buffers."""
+    import types
+    from pevae_amd import dls_latent as L
+    g = load_golden("den_auto")
+    cfg = types.SimpleNamespace(expand_weight=0.5, converge_weight=0.1, ost=False, no_mutual_information=False)
+    m = load_params(L.DeNAuto(16, 32, cfg), g).to(dev)
+    m.train()
+    output = T(g["output"], dev).requires_grad_()
+    act1 = [T(g["act1_%d" % i], dev).requires_grad_() for i in range(2)]
+    act2 = [T(g["act2_%d" % i], dev).requires_grad_() for i in range(2)]
+    z, rkl = m(output, act1, act2, False, [T(g["noise_%d" % i], dev) for i in range(2)],
+               [T(g["gumbel_%d" % i], dev) for i in range(2)])
+    (z.sum() * 0.01 + rkl).backward()
+    close(z, g["z"], rtol=1e-4, atol=1e-5)
+    close(rkl, g["rkl"], rtol=1e-4, atol=1e-5)
+    close(output.grad, g["d_output"], rtol=1e-4, atol=1e-4 * float(np.abs(g["d_output"]).max()))
+    for i in range(2):
+        close(act1[i].grad, g["d_act1_%d" % i], rtol=1e-4, atol=1e-4 * float(np.abs(g["d_act1_%d" % i]).max()))
+        close(act2[i].grad, g["d_act2_%d" % i], rtol=1e-4, atol=1e-4 * float(np.abs(g["d_act2_%d" % i]).max()))
+    for k, p in m.named_parameters():
+        close(p.grad, g["g." + k], rtol=3e-4, atol=1e-4 * float(np.abs(g["g." + k]).max()) + 1e-6)
+    for k, v in m.state_dict().items():
+        if "post." + k in g:
+            close(v, g["post." + k], rtol=1e-4, atol=1e-6)
+    m.eval()                                     # inference branch (:2761): prior means only, no random draw
+    z2, rkl2 = m(T(g["output"], dev), [T(g["act1_%d" % i], dev) for i in range(2)],
+                 [T(g["act2_%d" % i], dev) for i in range(2)], True)
+    ref = load_params(R.DeNAuto(16, 32, cfg), {k: v for k, v in g.items()})
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    ref.eval()
+    z3, _ = ref(T(g["output"], "cpu"), [T(g["act1_%d" % i], "cpu") for i in range(2)],
+                [T(g["act2_%d" % i], "cpu") for i in range(2)], True)
+    close(z2, z3, rtol=1e-4, atol=1e-5)

@@ -281,3 +281,32 @@ def test_dls_helpers():
     steps = (0, 1, 100, 2500, 9000)
     close(np.array([R.kl_anneal_function("logistic", s, 0.0025, 2500) for s in steps]), g["anneal_logistic"])
     close(np.array([R.kl_anneal_function("linear", s, 0.0025, 2500) for s in steps]), g["anneal_linear"])
+
+
+def test_den_auto_oracle_matches_reference():
+    """oracle DeNAuto vs the golden made from the reference's own DeN_Auto (oracle/make_golden.py gen_den_auto): outputs,
+    every gradient and the advanced power-iteration buffers, with the reference's random draws as inputs."""
+    import types
+    g = load_golden("den_auto")
+    cfg = types.SimpleNamespace(expand_weight=0.5, converge_weight=0.1, ost=False, no_mutual_information=False)
+    m = load_params(R.DeNAuto(16, 32, cfg), g)
+    m.train()
+    output = T(g["output"]).requires_grad_()
+    act1 = [T(g["act1_%d" % i]).requires_grad_() for i in range(2)]
+    act2 = [T(g["act2_%d" % i]).requires_grad_() for i in range(2)]
+    z, rkl = m(output, act1, act2, False, [T(g["noise_%d" % i]) for i in range(2)], [T(g["gumbel_%d" % i]) for i in range(2)])
+    (z.sum() * 0.01 + rkl).backward()
+    close(z, g["z"], rtol=1e-5, atol=1e-6)
+    close(rkl, g["rkl"], rtol=1e-5, atol=1e-6)
+    close(output.grad, g["d_output"], rtol=1e-4, atol=1e-6)
+    for i in range(2):
+        close(act1[i].grad, g["d_act1_%d" % i], rtol=1e-4, atol=1e-6)
+        close(act2[i].grad, g["d_act2_%d" % i], rtol=1e-4, atol=1e-6)
+    n = 0
+    for k, p in m.named_parameters():
+        close(p.grad, g["g." + k], rtol=2e-4, atol=2e-6)
+        n += 1
+    assert n > 50
+    for k, v in m.state_dict().items():
+        if "post." + k in g:
+            close(v, g["post." + k], rtol=1e-5, atol=1e-6)
