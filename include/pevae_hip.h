@@ -65,6 +65,12 @@ int pv_vocab_nll_bwd_prob(const void* h, int ldh, const void* W, int ldw, const 
  * (decoders.py:193,292); needs lse from pv_vocab_nll_fwd. */
 int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const float* bias, const float* lse,
                            int T, int V, int H, float inv_temp, float* out, void* stream);
+/* Greedy decoding without a [T][V] tensor (decoders.py:252-254, scores.topk(1); :144-147,247-248 mask_unk): ids[t] =
+ * arg-max over columns != mask_col (mask_col < 0: none; lowest column on ties) of the scaled logits of row t, logp[t] =
+ * its log-softmax value.  workspace: pv_vocab_argmax_ws_bytes(T, V). */
+size_t pv_vocab_argmax_ws_bytes(int T, int V);
+int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H, float inv_temp,
+                    int mask_col, void* workspace, int64_t* ids, float* logp, void* stream);
 /* Backward of the dense path: P = (dlogp - exp(logp) * rowsum(dlogp)) * inv_temp as bf16 [T][ldp] (+ dbias). */
 int pv_logsoftmax_bwd_bf16(const float* logp, const float* dlogp, int T, int V, float inv_temp, void* P, int ldp,
                            float* dbias, void* stream);

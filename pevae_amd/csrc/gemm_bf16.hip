@@ -275,6 +275,91 @@ struct EpiSoftmax {
   }
 };
 
+// Greedy decoding (decoders.py:252-254: scores.topk(1)): per row and 64-column slab the maximum scaled logit, its column
+// and sum exp(x - max): arg-max and the log-probability of the chosen symbol without a [B, V] tensor.  `mask_col`
+// (decoders.py:144-147,247-248: mask_unk) is excluded from the arg-max but stays in the softmax denominator, as adding
+// a -inf one-hot to LOG-PROBABILITIES does in the reference.
+struct ArgPart {
+  float m, s, best;     // slab max over ALL columns, sum exp(x - m), best value over the allowed columns
+  int idx;              // its column (lowest on ties), -1 if none
+};
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_movi(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+struct EpiArgmax {
+  const float* bias;
+  ArgPart* part;            // [nslab][Tpad]
+  int T, V, Tpad, mask_col;
+  float inv_temp;
+  struct Pre {
+    float bv[4];
+  };
+  __device__ Pre prefetch(int row0, int col0, int lane) const {
+    Pre p;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) p.bv[ni] = bias[min(col0 + ni * 16 + (lane & 15), V - 1)];
+    return p;
+  }
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem) const {
+    if (col0 >= V) return;
+    const int c16 = lane & 15, q4 = lane >> 4;
+    ArgPart mine{0.f, 0.f, 0.f, -1};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mi = r >> 2, j = r & 3;
+      float x[4], mx = -INFINITY, bst = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int col = col0 + ni * 16 + c16;
+        x[ni] = col < V ? (acc[mi][ni][j] + pre.bv[ni]) * inv_temp : -INFINITY;
+        mx = fmaxf(mx, x[ni]);
+        if (col < V && col != mask_col && x[ni] > bst) {      // ascending columns: the first maximum wins
+          bst = x[ni];
+          bi = col;
+        }
+      }
+      const float m = row16_max(mx), b = row16_max(bst);
+      float sacc = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) sacc += __expf(x[ni] - m);
+      sacc = row16_sum(sacc);
+      int cand = (bst == b && b > -INFINITY) ? bi : 0x7fffffff;   // lowest column among the lanes that hold the maximum
+      cand = min(cand, dpp_movi<0xB1>(cand));
+      cand = min(cand, dpp_movi<0x4E>(cand));
+      cand = min(cand, dpp_movi<0x141>(cand));
+      cand = min(cand, dpp_movi<0x140>(cand));
+      if (c16 == r) mine = ArgPart{m, sacc, b, cand == 0x7fffffff ? -1 : cand};
+    }
+    const int row = row0 + (c16 >> 2) * 16 + q4 * 4 + (c16 & 3);
+    if (row < Tpad) part[(size_t)(col0 >> 6) * Tpad + row] = mine;
+  }
+};
+
+// one thread per row: slabs in ascending order (fixed order; the first maximum wins)
+__global__ __launch_bounds__(256) void vocab_argmax_reduce_kernel(const ArgPart* __restrict__ part, int T, int Tpad, int nslab,
+                                                                   int64_t* __restrict__ ids, float* __restrict__ logp) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= T) return;
+  float m = -INFINITY, s = 0.f, best = -INFINITY;
+  int idx = -1;
+  for (int k = 0; k < nslab; ++k) {
+    const ArgPart p = part[(size_t)k * Tpad + row];
+    const float mn = fmaxf(m, p.m);
+    s = s * __expf(m - mn) + p.s * __expf(p.m - mn);
+    m = mn;
+    if (p.idx >= 0 && p.best > best) {
+      best = p.best;
+      idx = p.idx;
+    }
+  }
+  ids[row] = idx;
+  logp[row] = best - (m + logf(s));
+}
+
 constexpr int EPI_LD = 144;            // bytes per staged 64-element bf16 row (128 + 16 pad)
 constexpr int EPI_WAVE_BYTES = 64 * EPI_LD;
 
@@ -605,6 +690,25 @@ int pv_vocab_nll_bwd_prob(const void* h, int ldh, const void* W, int ldw, const 
   if (rc) return rc;
   // dbias[v] = sum over row-slabs of dbias_part[slab][v]   (fixed order: bitwise reproducible)
   return pv_colsum_f32(dbias_part, Tpad / 64, ldp, V, dbias, 0, stream);
+}
+
+size_t pv_vocab_argmax_ws_bytes(int T, int V) { return (size_t)cdiv(V, 64) * round_up(T, 64) * sizeof(ArgPart); }
+
+int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H, float inv_temp,
+                    int mask_col, void* workspace, int64_t* ids, float* logp, void* stream) {
+  int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_argmax");
+  if (rc) return rc;
+  PV_REQUIRE(bias && workspace && ids && logp, "pv_vocab_argmax: null argument");
+  const int Tpad = round_up(T, 64), nslab = cdiv(V, 64);
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 0};
+  EpiArgmax e{bias, (ArgPart*)workspace, T, V, Tpad, mask_col, inv_temp};
+  rc = launch(g, e, st, "pv_vocab_argmax");
+  if (rc) return rc;
+  hipLaunchKernelGGL(vocab_argmax_reduce_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, (const ArgPart*)workspace, T, Tpad,
+                     nslab, ids, logp);
+  PV_LAUNCH_CHECK("vocab_argmax_reduce_kernel");
+  return PV_OK;
 }
 
 int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const float* bias,

@@ -239,7 +239,27 @@ class DecoderRNN(BaseRNN):
             decoder_outputs = DeferredLogProbs(output, w, b, 1.0 / self.softmax_temperature, hid_bf16, layout)
         else:
             step_outputs, cum_sum = [], None
+            fused = getattr(self, "fused_greedy", False) and gen_type == 'greedy'
             for di in range(self.max_length):
+                if fused:
+                    # opt-in (self.fused_greedy = True): arg-max fused into the projection GEMM, no [B,V] log-probs; the
+                    # returned decoder_outputs is then [B, L] = log-probability of each emitted symbol (a deviation from
+                    # the reference's [B, L, V] return value, for callers that only consume ret_dict['sequence'])
+                    output, decoder_hidden, step_attn, _ = self._hidden_states(decoder_input, decoder_hidden,
+                                                                               attn_context, latent_variable)
+                    w, b = self._out_weights()
+                    symbols, lp = ops.vocab_argmax(output.reshape(-1, output.shape[-1]), w, b,
+                                                   1.0 / self.softmax_temperature, self.unk_id if self.mask_unk else -1)
+                    symbols = symbols.view(-1, 1)
+                    step_outputs.append(lp.view(-1, 1))
+                    if self.use_attention:
+                        ret_dict[DecoderRNN.KEY_ATTN_SCORE].append(step_attn)
+                    sequence_symbols.append(symbols)
+                    eos_batches = symbols.data.eq(self.eos_id).cpu().view(-1).numpy()
+                    update_idx = ((lengths > di) & eos_batches) != 0
+                    lengths[update_idx] = len(sequence_symbols)
+                    decoder_input = symbols
+                    continue
                 step_output, decoder_hidden, step_attn = self.forward_step(decoder_input, decoder_hidden,
                                                                            attn_context, latent_variable)
                 step_outputs.append(step_output)

@@ -275,6 +275,21 @@ def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, dw_sink=None):
     return dH, dW
 
 
+def vocab_argmax(hid, weight, bias, inv_temp=1.0, mask_col=-1):
+    """Greedy symbol and its log-probability per row of hid [T,H] (decoders.py:252-254 topk(1) on the log-softmax of the
+    projection, :247-248 mask_unk) without a [T,V] tensor.  -> (ids int64 [T], logp fp32 [T]); no gradient."""
+    with torch.no_grad():
+        _need_cuda(hid, weight, bias)
+        T, H, V, Hp, h_bf, ldh, w_bf = _vocab_operands(hid, weight)
+        dev = weight.device
+        ws = workspace("vocab_argmax", _lib.load().pv_vocab_argmax_ws_bytes(T, V), torch.uint8, dev)
+        ids = torch.empty(T, dtype=torch.int64, device=dev)
+        logp = torch.empty(T, dtype=torch.float32, device=dev)
+        _lib.call("pv_vocab_argmax", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias.contiguous()), T, V, Hp, inv_temp, int(mask_col),
+                  _p(ws), _p(ids), _p(logp), _stream())
+        return ids, logp
+
+
 class VocabLogProbDense(torch.autograd.Function):
     """Dense [T,V] log-softmax rows: the reference's DecoderRNN return value (decoders.py:193) for callers
     that want it as a tensor.  Costs the 4 B x T x V write the fused path avoids."""

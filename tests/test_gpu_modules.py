@@ -255,6 +255,49 @@ def test_decoder_gen_greedy(dev, tag, mask_unk):
         dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="bogus")
 
 
+@pytest.mark.parametrize("mask_unk", [False, True])
+def test_decoder_gen_fused_greedy(dev, mask_unk):
+    """Opt-in fused arg-max decode (pv_vocab_argmax): the same symbols, lengths and per-symbol log-probabilities as the
+    dense path (the reference's own return value, golden-tested above), with no [B,V] tensor."""
+    from pevae_amd.enc2dec import decoders as D
+    g = load_golden("decoder_gen_greedy_maskunk" if mask_unk else "decoder_gen_greedy")
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb, mask_unk=mask_unk), g).to(dev)
+    dec.eval()
+    with torch.no_grad():
+        logp, _, ret = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="greedy")
+        dec.fused_greedy = True
+        lp_f, _, ret_f = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="greedy")
+    seq, seq_f = torch.cat(ret["sequence"], 1), torch.cat(ret_f["sequence"], 1)
+    assert torch.equal(seq, seq_f) and ret["length"] == ret_f["length"]          # bit-exact indices
+    assert tuple(lp_f.shape) == (B, L)
+    close(lp_f, logp.gather(2, seq.unsqueeze(-1)).squeeze(-1).cpu(), rtol=0, atol=1e-4)
+
+
+def test_vocab_argmax_large(dev):
+    """pv_vocab_argmax at the step's vocabulary (V = 20004, ragged last slab) against torch on the same bf16 operands."""
+    from pevae_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    Tn, H, V = 200, 512, 20004
+    hid = (torch.randn(Tn, H, generator=gen) * 0.5).to(torch.bfloat16).float()
+    W = (torch.randn(V, H, generator=gen) * 0.05).to(torch.bfloat16).float()
+    b = torch.randn(V, generator=gen) * 0.1
+    ref = torch.log_softmax((hid.double() @ W.double().t() + b.double()) / 0.7, -1)
+    for mask in (-1, 3):
+        r = ref.clone()
+        if mask >= 0:
+            r[:, mask] = -float("inf")
+        want_lp, want_id = r.max(-1)
+        ids, lp = ops.vocab_argmax(hid.to(dev), W.to(dev), b.to(dev), 1.0 / 0.7, mask)
+        ids, lp = ids.cpu(), lp.cpu()
+        for t in range(Tn):                      # a flip is legitimate only between near-equal candidates
+            if ids[t] != want_id[t]:
+                assert float(want_lp[t] - r[t, ids[t]]) < 1e-3, t
+        close(lp, want_lp.float(), rtol=0, atol=2e-3)
+        assert int(ids.min()) >= 0 and (mask < 0 or int((ids == mask).sum()) == 0)
+
+
 @pytest.mark.parametrize("mode", ["dot", "general", "cat"])
 def test_attention(dev, mode):
     from pevae_amd.enc2dec.decoders import Attention
