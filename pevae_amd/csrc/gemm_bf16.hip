@@ -618,7 +618,20 @@ int pv_gemm_splitk_plan(int M, int N, int K, int target_wgs, int* splits) {
   PV_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && splits, "pv_gemm_splitk_plan: bad argument");
   const int tiles = cdiv(M, BM) * cdiv(N, BN), nk = K / BK;
   int s = target_wgs / tiles;
-  if (s < 1) s = 1;
+  if (s < 1) {
+    // More tiles than resident workgroups: the launch runs in rounds and the last one may be nearly empty (628 tiles on
+    // 512 slots = 2 rounds at 61 %).  A small split evens the rounds out; it pays only when the gain clearly exceeds the
+    // slab traffic (measured at M=20004, N=512, K=12800: 523 -> 410 us with 3 splits; M=12800: no split is best).
+    s = 1;
+    const double e1 = (double)tiles / target_wgs / cdiv(tiles, target_wgs);
+    for (int c = 2; c <= 4; ++c) {
+      const double ec = (double)tiles * c / target_wgs / cdiv(tiles * c, target_wgs);
+      if (ec >= 0.9 && ec >= 1.3 * e1) {
+        s = c;
+        break;
+      }
+    }
+  }
   if (s > nk / 4) s = nk / 4 > 0 ? nk / 4 : 1;         // keep >= 4 k-tiles per split
   const int per = cdiv(nk, s);
   *splits = cdiv(nk, per);                             // no empty split

@@ -267,11 +267,7 @@ def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, dw_sink=None):
         dH = gemm_nt(P, Vp, wT, Vp, T, H, Vp)
     hT = transpose_to_bf16(h_bf, T, H, ldh, Tp, out=workspace("vocab_hT", H * Tp, BF16, dev).view(H, Tp))
     with timed("vocab_dW"):
-        if dw_sink is not None:
-            gemm_nt(PT, Tp, hT, Tp, V, H, Tp, out=dw_sink, accumulate=True)
-            dW = None
-        else:
-            dW = gemm_nt(PT, Tp, hT, Tp, V, H, Tp)
+        dW = gemm_nt_wgrad(PT, Tp, hT, Tp, V, H, Tp, dw_sink)      # split-K when the tile count leaves a ragged last round
     return dH, dW
 
 
