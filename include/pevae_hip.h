@@ -241,6 +241,20 @@ typedef struct pv_block_call {      /* one Block of a launch; arrays are in the 
  * of a level, or the three Blocks of a DLS_Auto level, run side by side). */
 int pv_block_fwd(const pv_block_call* calls, int n, void* stream);
 int pv_block_bwd(const pv_block_call* calls, int n, void* stream);
+/* One level of DLS_Auto's train branch (:3285-3311) as two elementwise launches.  Q / Pr [B][2n]: outputs of dis_layer /
+ * dis_layer2 (mean | log sigma halves).  ls = mean + exp(logsigma) * eps + a2 (:3299-3300), out = lay + ls (:3310),
+ * kl[0] = (ew + cw) * mean_b sum_d KL(prior || posterior) (:3305-3306; the backward gives the prior's gradient the
+ * weight ew and the posterior's cw, as the two detached-direction terms do).  pv_dls_inputs_*: q_in = [a1 + a2 | ls],
+ * p_in = [a2 | lt] (:3289-3297) and the split of their gradients. */
+int pv_dls_level_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
+                     float ew, float cw, float* ls, float* out, float* kl, void* stream);
+int pv_dls_level_bwd(const float* Q, const float* Pr, const float* eps, const float* d_ls, const float* d_out,
+                     const float* g_kl, int B, int n, float ew, float cw, float* dQ, float* dPr, float* da2, float* dlay,
+                     void* stream);
+int pv_dls_inputs_fwd(const float* a1, const float* a2, const float* ls, const float* lt, int B, int w, int e, float* q_in,
+                      float* p_in, void* stream);
+int pv_dls_inputs_bwd(const float* dq, const float* dp, int B, int w, int e, float* da1, float* da2, float* dls, float* dlt,
+                      void* stream);
 /* DLS_Auto.cons_loss (:3266-3272): row L2 normalisation and the symmetric InfoNCE over a [B][B] score matrix with
  * the diagonal as targets: loss = (CE(log_softmax rows) + CE(log_softmax columns)) / 2. */
 int pv_l2norm_rows_fwd(const float* x, int rows, int D, float* a, float* nrm, void* stream);

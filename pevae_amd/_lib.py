@@ -50,6 +50,10 @@ SIGNATURES = {
     "pv_block_layout": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "pv_block_fwd": (i32, [vp, i32, vp]),
     "pv_block_bwd": (i32, [vp, i32, vp]),
+    "pv_dls_level_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp]),
+    "pv_dls_level_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
+    "pv_dls_inputs_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "pv_dls_inputs_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "pv_lstm_geometry": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "pv_lstm_fwd": (i32, [vp, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pv_lstm_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

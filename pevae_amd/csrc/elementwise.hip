@@ -352,6 +352,143 @@ int pv_reparam_kl_bwd(const float* mu_q, const float* lv_q, const float* mu_p, c
   return PV_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// ---- one level of DLS_Auto's train branch (dialog_models.py:3285-3311) as two elementwise launches -----------------
+// The level's glue -- chunk(2), reparameterise, + act2, + layer(output), two detached-direction KLs, their batch means
+// and weights -- was ~15 four-microsecond launches forward and as many backward.
+//   Q = dis_layer output  [B][2n] = (mean | logsigma) of the posterior;  Pr = dis_layer2 output [B][2n] = prior
+//   ls  = mean + exp(logsigma) * eps + a2                      (last_sample, :3299-3300)
+//   out = lay + ls                                             (:3310)
+//   kl  = (ew + cw) * mean_b sum_d KL(prior || posterior)      (:3305-3306; as a VALUE both detached-direction terms are
+//         this number, their gradients differ: ew scales the prior's, cw the posterior's)
+// One workgroup (B * n <= a few 10^4 elements), fixed-order reduction.
+__global__ __launch_bounds__(256) void dls_level_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Pr,
+                                                             const float* __restrict__ a2, const float* __restrict__ eps,
+                                                             const float* __restrict__ lay, int B, int n, float ew, float cw,
+                                                             float* __restrict__ ls, float* __restrict__ out,
+                                                             float* __restrict__ kl) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < B * n; i += 256) {
+    const int b = i / n, d = i % n;
+    const float m = Q[(size_t)b * 2 * n + d], l = Q[(size_t)b * 2 * n + n + d];
+    const float tm = Pr[(size_t)b * 2 * n + d], tl = Pr[(size_t)b * 2 * n + n + d];
+    const float s = m + expf(l) * eps[i] + a2[i];
+    ls[i] = s;
+    out[i] = lay[i] + s;
+    const float diff = tm - m;
+    acc += -0.5f + l - tl + 0.5f * (expf(2.f * tl) + diff * diff) * expf(-2.f * l);     // KL(t || q), log-sigma inputs
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) kl[0] = (ew + cw) * red[0] / B;
+}
+
+// d_ls / d_out / g_kl: gradients of the three outputs (d_ls, d_out may be NULL).  dQ, dPr [B][2n]; da2, dlay [B][n].
+__global__ void dls_level_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Pr, const float* __restrict__ eps,
+                                     const float* __restrict__ d_ls, const float* __restrict__ d_out,
+                                     const float* __restrict__ g_kl, int B, int n, float ew, float cw,
+                                     float* __restrict__ dQ, float* __restrict__ dPr, float* __restrict__ da2,
+                                     float* __restrict__ dlay) {
+  const float g = g_kl ? g_kl[0] / B : 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * n; i += gridDim.x * blockDim.x) {
+    const int b = i / n, d = i % n;
+    const size_t im = (size_t)b * 2 * n + d, il = im + n;
+    const float m = Q[im], l = Q[il], tm = Pr[im], tl = Pr[il];
+    const float go = d_out ? d_out[i] : 0.f, gs = (d_ls ? d_ls[i] : 0.f) + go;
+    const float diff = tm - m, ip2 = expf(-2.f * l), e2t = expf(2.f * tl);
+    // posterior (m, l) is "2" of KL(1 || 2), weight cw; prior (tm, tl) is "1", weight ew
+    dQ[im] = gs + g * cw * (-diff * ip2);
+    dQ[il] = gs * expf(l) * eps[i] + g * cw * (1.f - (e2t + diff * diff) * ip2);
+    dPr[im] = g * ew * (diff * ip2);
+    dPr[il] = g * ew * (-1.f + e2t * ip2);
+    da2[i] = gs;
+    dlay[i] = go;
+  }
+}
+
+// q_in = [a1 + a2 | ls], p_in = [a2 | lt]   (:3289-3291, :3295-3297): one launch instead of an add and two cats
+__global__ void dls_inputs_fwd_kernel(const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ ls,
+                                      const float* __restrict__ lt, int B, int w, int e, float* __restrict__ q_in,
+                                      float* __restrict__ p_in) {
+  const int W = w + e;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * W; i += gridDim.x * blockDim.x) {
+    const int b = i / W, c = i % W;
+    if (c < w) {
+      const float x2 = a2[(size_t)b * w + c];
+      q_in[i] = a1[(size_t)b * w + c] + x2;
+      p_in[i] = x2;
+    } else {
+      q_in[i] = ls[(size_t)b * e + c - w];
+      p_in[i] = lt[(size_t)b * e + c - w];
+    }
+  }
+}
+__global__ void dls_inputs_bwd_kernel(const float* __restrict__ dq, const float* __restrict__ dp, int B, int w, int e,
+                                      float* __restrict__ da1, float* __restrict__ da2, float* __restrict__ dls,
+                                      float* __restrict__ dlt) {
+  const int W = w + e;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * W; i += gridDim.x * blockDim.x) {
+    const int b = i / W, c = i % W;
+    const float gq = dq ? dq[i] : 0.f, gp = dp ? dp[i] : 0.f;
+    if (c < w) {
+      da1[(size_t)b * w + c] = gq;
+      da2[(size_t)b * w + c] = gq + gp;
+    } else {
+      dls[(size_t)b * e + c - w] = gq;
+      dlt[(size_t)b * e + c - w] = gp;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pv_dls_level_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
+                     float ew, float cw, float* ls, float* out, float* kl, void* stream) {
+  PV_REQUIRE(Q && Pr && a2 && eps && lay && ls && out && kl && B > 0 && n > 0, "pv_dls_level_fwd: bad argument");
+  hipLaunchKernelGGL(dls_level_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Q, Pr, a2, eps, lay, B, n, ew, cw, ls,
+                     out, kl);
+  PV_LAUNCH_CHECK("dls_level_fwd_kernel");
+  return PV_OK;
+}
+
+int pv_dls_level_bwd(const float* Q, const float* Pr, const float* eps, const float* d_ls, const float* d_out,
+                     const float* g_kl, int B, int n, float ew, float cw, float* dQ, float* dPr, float* da2, float* dlay,
+                     void* stream) {
+  PV_REQUIRE(Q && Pr && eps && dQ && dPr && da2 && dlay && B > 0 && n > 0, "pv_dls_level_bwd: bad argument");
+  hipLaunchKernelGGL(dls_level_bwd_kernel, dim3(grid_for((long)B * n, 256)), dim3(256), 0, (hipStream_t)stream, Q, Pr, eps,
+                     d_ls, d_out, g_kl, B, n, ew, cw, dQ, dPr, da2, dlay);
+  PV_LAUNCH_CHECK("dls_level_bwd_kernel");
+  return PV_OK;
+}
+
+int pv_dls_inputs_fwd(const float* a1, const float* a2, const float* ls, const float* lt, int B, int w, int e, float* q_in,
+                      float* p_in, void* stream) {
+  PV_REQUIRE(a1 && a2 && ls && lt && q_in && p_in && B > 0 && w > 0 && e > 0, "pv_dls_inputs_fwd: bad argument");
+  hipLaunchKernelGGL(dls_inputs_fwd_kernel, dim3(grid_for((long)B * (w + e), 256)), dim3(256), 0, (hipStream_t)stream, a1, a2,
+                     ls, lt, B, w, e, q_in, p_in);
+  PV_LAUNCH_CHECK("dls_inputs_fwd_kernel");
+  return PV_OK;
+}
+
+int pv_dls_inputs_bwd(const float* dq, const float* dp, int B, int w, int e, float* da1, float* da2, float* dls, float* dlt,
+                      void* stream) {
+  PV_REQUIRE(da1 && da2 && dls && dlt && B > 0 && w > 0 && e > 0, "pv_dls_inputs_bwd: bad argument");
+  hipLaunchKernelGGL(dls_inputs_bwd_kernel, dim3(grid_for((long)B * (w + e), 256)), dim3(256), 0, (hipStream_t)stream, dq, dp,
+                     B, w, e, da1, da2, dls, dlt);
+  PV_LAUNCH_CHECK("dls_inputs_bwd_kernel");
+  return PV_OK;
+}
+
 int pv_gumbel_softmax_fwd(const float* logits, const float* u, int rows, int k, float tau, int hard, float* y_soft,
                           float* y, int64_t* ids, void* stream) {
   PV_REQUIRE(logits && u && y_soft && y && rows > 0 && k > 0 && tau > 0.f, "pv_gumbel_softmax_fwd: bad argument");

@@ -159,9 +159,11 @@ class DLSAuto(nn.Module):
             train_branch = not restarted and not getattr(cfg, "ost", False)
             if last_sample is None:
                 q_in, p_in = a1 + a2, a2
+            elif train_branch:
+                q_in, p_in = ops.DlsInputs.apply(a1, a2, last_sample, last_t)
             else:
                 q_in = torch.cat([a1 + a2, last_sample], -1)
-                p_in = torch.cat([a2, last_t if train_branch else last_sample], -1)
+                p_in = torch.cat([a2, last_sample], -1)
             need_q = train_branch or self.training
             # the three Blocks of a level are independent: they share one launch (or run as parallel stream branches)
             res = run_blocks([dis2, layer] + ([dis] if need_q else []), [p_in, output] + ([q_in] if need_q else []))
@@ -170,14 +172,11 @@ class DLSAuto(nn.Module):
             if need_q:
                 mean, lv = res[2].chunk(2, -1)
             if train_branch:
-                eps = noise[i] if noise is not None else torch.rand_like(lv)
-                z, _ = ops.reparam_kl(mean, lv, None, None, eps, mode=1, want_kl=False)         # :3292 / :3299
-                last_sample = z + a2
+                eps = noise[i] if noise is not None else torch.rand(a2.shape, device=a2.device, dtype=a2.dtype)
+                # sample (:3292/:3299-3300), output (:3310) and ew * KL(t || q.detach) + cw * KL(t.detach || q) (:3305-3306)
+                last_sample, output, klw = ops.DlsLevel.apply(res[2], res[0], a2, eps, lay_out, float(ew), float(cw))
                 last_t = t_mean
-                _, k1 = ops.reparam_kl(t_mean, t_lv, mean.detach(), lv.detach(), None, mode=1, want_z=False)
-                _, k2 = ops.reparam_kl(t_mean.detach(), t_lv.detach(), mean, lv, None, mode=1, want_z=False)
-                rkl = rkl + ew * ops.mean(k1) + cw * ops.mean(k2) + ops.cons_loss(a1, a2) * cip     # :3305-3307
-                output = lay_out + last_sample                                                     # :3310
+                rkl = rkl + klw + ops.cons_loss(a1, a2) * cip                                      # :3307
             else:
                 if self.training:
                     eps = noise[i] if noise is not None else torch.rand_like(t_lv)

@@ -1221,6 +1221,68 @@ def blocks_forward(blks, xs):
     return outs
 
 
+class DlsLevel(torch.autograd.Function):
+    """One level of DLS_Auto's train branch after its three Blocks (dialog_models.py:3299-3310): posterior sample,
+    residual adds and the two weighted detached-direction KLs in one launch each way.
+    (Q, Pr [B,2n], a2, eps, lay [B,n]) -> (last_sample, output, ew * KL(t || q.detach) + cw * KL(t.detach || q))."""
+
+    @staticmethod
+    def forward(ctx, Q, Pr, a2, eps, lay, ew, cw):
+        _need_cuda(Q, Pr, a2, eps, lay)
+        Q, Pr, a2, eps, lay = [t.contiguous() for t in (Q, Pr, a2, eps, lay)]
+        B, n = a2.shape
+        dev = Q.device
+        ls = torch.empty((B, n), dtype=torch.float32, device=dev)
+        out = torch.empty((B, n), dtype=torch.float32, device=dev)
+        kl = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.call("pv_dls_level_fwd", _p(Q), _p(Pr), _p(a2), _p(eps), _p(lay), B, n, ew, cw, _p(ls), _p(out), _p(kl), _stream())
+        ctx.save_for_backward(Q, Pr, eps)
+        ctx.w = (ew, cw)
+        ctx.set_materialize_grads(False)
+        return ls, out, kl.view(())
+
+    @staticmethod
+    def backward(ctx, d_ls, d_out, g_kl):
+        Q, Pr, eps = ctx.saved_tensors
+        B, n = eps.shape
+        ew, cw = ctx.w
+        dQ, dPr = torch.empty_like(Q), torch.empty_like(Pr)
+        da2, dlay = torch.empty_like(eps), torch.empty_like(eps)
+        c = lambda t: None if t is None else t.contiguous()
+        _lib.call("pv_dls_level_bwd", _p(Q), _p(Pr), _p(eps), _p(c(d_ls)), _p(c(d_out)), _p(c(g_kl)), B, n, ew, cw, _p(dQ),
+                  _p(dPr), _p(da2), _p(dlay), _stream())
+        return dQ, dPr, da2, None, dlay, None, None
+
+
+class DlsInputs(torch.autograd.Function):
+    """q_in = [a1 + a2 | last_sample], p_in = [a2 | last_t] (dialog_models.py:3289-3297) in one launch."""
+
+    @staticmethod
+    def forward(ctx, a1, a2, ls, lt):
+        _need_cuda(a1, a2, ls, lt)
+        a1, a2, ls, lt = [t.contiguous() for t in (a1, a2, ls, lt)]
+        B, w = a1.shape
+        e = ls.shape[1]
+        q_in = torch.empty((B, w + e), dtype=torch.float32, device=a1.device)
+        p_in = torch.empty((B, w + e), dtype=torch.float32, device=a1.device)
+        _lib.call("pv_dls_inputs_fwd", _p(a1), _p(a2), _p(ls), _p(lt), B, w, e, _p(q_in), _p(p_in), _stream())
+        ctx.dims = (B, w, e)
+        ctx.set_materialize_grads(False)
+        return q_in, p_in
+
+    @staticmethod
+    def backward(ctx, dq, dp):
+        B, w, e = ctx.dims
+        dev = (dq if dq is not None else dp).device
+        da1 = torch.empty((B, w), dtype=torch.float32, device=dev)
+        da2 = torch.empty((B, w), dtype=torch.float32, device=dev)
+        dls = torch.empty((B, e), dtype=torch.float32, device=dev)
+        dlt = torch.empty((B, e), dtype=torch.float32, device=dev)
+        c = lambda t: None if t is None else t.contiguous()
+        _lib.call("pv_dls_inputs_bwd", _p(c(dq)), _p(c(dp)), B, w, e, _p(da1), _p(da2), _p(dls), _p(dlt), _stream())
+        return da1, da2, dls, dlt
+
+
 class L2NormRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
