@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--latent", default="dls", choices=["gauss", "dls"],
                     help="latent stack: 'dls' = the reference's DLS pyramid (DlsRec/DlsPri/DLS_Auto), 'gauss' = flat")
     ap.add_argument("--attention", type=int, default=0, help="decoder attention over encoder states (configs[2])")
+    ap.add_argument("--vocab-dense", type=int, default=0,
+                    help="1 = run the vocabulary GEMMs over the padding rows too (no ignored-token compaction)")
     ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for per-kernel times")
     return ap.parse_args()
 
@@ -74,6 +76,8 @@ def main():
     from pevae_amd import dp, ops
     from pevae_amd.dls_vae import DLSVAE, default_config, synthetic_batch
     from pevae_amd.optim import FlatAdam
+    if args.vocab_dense:
+        ops.SKIP_IGNORED_TOKENS = False
     rank, world, local = dp.init_from_env()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device("cuda", local)
@@ -172,7 +176,10 @@ def main():
             kern_ms[tag] = dict(ms_per_step=round(tot, 4), launches_per_step=per_step)
         ops.TIMERS = None
         T, H, V = args.batch * cfg.max_seq_len, cfg.dec_cell_size, cfg.vocab_size
-        alg_flop = 6.0 * T * H * V                       # fwd + dH + dW; the backward's logit recompute is NOT credited
+        # Only target rows that are not padding reach the vocabulary GEMMs (their NLL and gradients are exactly zero in
+        # the reference too: NLLEntropy ignore_index, criterions.py), so only those rows are credited as work.
+        T_live = int((feed["ans_ids"] != 0).sum()) if ops.SKIP_IGNORED_TOKENS else T
+        alg_flop = 6.0 * T_live * H * V                  # fwd + dH + dW; the backward's logit recompute is NOT credited
         vocab_ms = sum(kern_ms[k]["ms_per_step"] for k in ("vocab_fwd", "vocab_bwd_prob", "vocab_dH", "vocab_dW"))
         ach = alg_flop / (vocab_ms * 1e-3) / 1e12
         traffic = None          # HBM bytes per step of the group, from the committed rocprofv3 --pmc passes (this script
@@ -185,7 +192,8 @@ def main():
                     traffic_source="profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per step)",
                     kernel="gemm_nt_kernel<EpiSoftmax|EpiProb|EpiStore> (vocab projection+softmax+NLL fwd+bwd group)",
                     algorithmic_gflop_per_step=round(alg_flop / 1e9, 1), group_ms_per_step=round(vocab_ms, 4),
-                    fwd_kernel_tflops=round(2.0 * T * H * V / (kern_ms["vocab_fwd"]["ms_per_step"] * 1e-3) / 1e12, 2))
+                    token_rows=T, token_rows_computed=T_live,
+                    fwd_kernel_tflops=round(2.0 * T_live * H * V / (kern_ms["vocab_fwd"]["ms_per_step"] * 1e-3) / 1e12, 2))
 
     if rank == 0:
         cpu = cpu_baseline(cfg, args.batch, args.cpu_steps) if (args.cpu_baseline and world == 1) else None
@@ -198,7 +206,9 @@ def main():
                                    "V=20004 NU=30000 NI=20000 Z=64, dropout=%.1f, Adam lr=1e-4 clip=5, latent stack '%s'%s"
                                    % (args.dropout, args.latent, ", decoder attention" if args.attention else ""),
                        "global_batch": args.batch * world, "seq_len": cfg.max_seq_len, "params": n_params,
-                       "parallelism": "dp%d" % world, "hip_graph": bool(args.graph)},
+                       "parallelism": "dp%d" % world, "hip_graph": bool(args.graph),
+                       "padding_rows_skipped": bool(ops.SKIP_IGNORED_TOKENS),
+                       "live_target_fraction": round(float((feed["ans_ids"] != 0).float().mean()), 4)},
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kern_ms, "final_vae_nll": round(final_nll, 4),
         }
         print(json.dumps(out))

@@ -31,17 +31,25 @@ int pv_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
  * 16-byte aligned.  Writes fp32 C (C += when accumulate != 0) and/or bf16 Cb.  Replaces the cuBLAS GEMMs inside nn.GRU's input
  * projection (models/enc2dec/base_modules.py:42) and the weight/data-gradient GEMMs of nn.Linear backward
  * for `project` (models/enc2dec/decoders.py:162). */
+/* m_live / k_live (device scalars, NULL = none): run-time bounds for a launch whose geometry must stay static (HIP
+ * graphs): 128-row tiles starting at or past *m_live exit at once, the K loop stops at round_up(*k_live, 64). */
 int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
-                    int bias_per_row, float* C, int ldc, void* Cb, int ldcb, int accumulate, void* stream);
+                    int bias_per_row, float* C, int ldc, void* Cb, int ldcb, int accumulate, const int* m_live,
+                    const int* k_live, void* stream);
 
 /* Split-K form for weight-gradient GEMMs with few output tiles and a long K (dW_ih / dW_hh of the GRU: K = all
  * L*B tokens): `splits` slices of K are computed by separate workgroups into fp32 slabs of `workspace`
  * (pv_gemm_splitk_ws_bytes) and summed in slice order by a second kernel (bitwise reproducible, no atomics);
- * C (+)= the sum.  pv_gemm_splitk_plan picks `splits` so that tiles * splits ~ target_wgs. */
+ * C (+)= the sum.  pv_gemm_splitk_plan picks `splits` so that tiles * splits ~ target_wgs.
+ * With m_live (device scalar, rows past it are neither computed nor written) `splits` is an upper limit: the kernel
+ * lowers it on the device until live tiles * splits fits the resident workgroups once, so a launch whose row count
+ * is only known on the device (the compacted vocabulary dH) still fills the chip; the workspace is sized for the
+ * limit. */
 int pv_gemm_splitk_plan(int M, int N, int K, int target_wgs, int* splits);   /* host out-param */
 size_t pv_gemm_splitk_ws_bytes(int M, int N, int splits);
 int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits,
-                           void* workspace, float* C, int ldc, int accumulate, void* stream);
+                           void* workspace, float* C, int ldc, int accumulate, const int* m_live, const int* k_live,
+                           void* stream);
 
 /* ---- fused vocabulary projection + log-softmax + NLL -----------------------------------------------------
  * Forward: logits = (h W^T + bias) * inv_temp are produced tile-wise by the MFMA GEMM and reduced on the fly
@@ -52,7 +60,7 @@ int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M
 size_t pv_vocab_nll_fwd_ws_bytes(int T, int V);
 int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float* bias, const int64_t* target,
                      int T, int V, int H, float inv_temp, int64_t ignore_index, void* workspace, float* lse,
-                     float* nll, void* stream);
+                     float* nll, const int* live_rows, void* stream);
 /* Backward, stage 1: recompute the logits tile-wise and emit P = (softmax - onehot(target)) * gscale[t] *
  * inv_temp as bf16, both as P [round_up(T,64)][ldp] and P^T [round_up(V,64)][ldpt], plus
  * dbias[v] = sum_t P[t,v].  Stage 2 is two pv_gemm_bf16_nt calls: dH = P (W^T)^T and dW = P^T (h^T)^T.
@@ -60,7 +68,17 @@ int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float
 int pv_vocab_nll_bwd_prob(const void* h, int ldh, const void* W, int ldw, const float* bias,
                           const int64_t* target, const float* lse, const float* gscale, int T, int V, int H,
                           float inv_temp, void* P, int ldp, void* PT, int ldpt, float* dbias_part, float* dbias,
-                          void* stream);
+                          const int* live_rows, void* stream);
+/* Ignored-token compaction.  Rows whose target is ignore_index add exactly zero to the loss (NLLLoss(ignore_index),
+ * criterions.py:38-41) and to every gradient.  pv_vocab_compact: stable partition, perm[new] = old row (live rows first,
+ * original order), count[0] = live rows.  pv_vocab_gather: h_c / target_c = rows in perm order.  The vocabulary kernels
+ * then run on the compact rows with live_rows = count (tiles past the live rows exit; lse / nll of those rows are 0)
+ * and pv_scatter_rows_f32 puts per-row results back: dst[perm[new]] = new < count ? src[new] : 0. */
+int pv_vocab_compact(const int64_t* target, int T, int64_t ignore_index, int64_t* perm, int* count, void* stream);
+int pv_vocab_gather(const void* h, int ldh, const int64_t* target, const int64_t* perm, int T, int H, void* h_c, int ldc,
+                    int64_t* target_c, void* stream);
+int pv_scatter_rows_f32(const float* src, long lds, const int64_t* perm, const int* count, int T, int cols, float* dst,
+                        long ldd, void* stream);
 /* Dense [T][V] fp32 log-probs for callers that need the reference's DecoderRNN return value as a tensor
  * (decoders.py:193,292); needs lse from pv_vocab_nll_fwd. */
 int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const float* bias, const float* lse,

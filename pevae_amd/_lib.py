@@ -32,13 +32,16 @@ SIGNATURES = {
     "pv_last_error": (C.c_char_p, []),
     "pv_abi_version": (i32, []),
     "pv_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
-    "pv_gemm_bf16_nt": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp]),
+    "pv_gemm_bf16_nt": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp]),
     "pv_gemm_splitk_plan": (i32, [i32, i32, i32, i32, C.POINTER(i32)]),
     "pv_gemm_splitk_ws_bytes": (sz, [i32, i32, i32]),
-    "pv_gemm_bf16_nt_splitk": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
+    "pv_gemm_bf16_nt_splitk": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
     "pv_vocab_nll_fwd_ws_bytes": (sz, [i32, i32]),
-    "pv_vocab_nll_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i64, vp, vp, vp, vp]),
-    "pv_vocab_nll_bwd_prob": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, i32, vp, i32, vp, vp, vp]),
+    "pv_vocab_nll_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i64, vp, vp, vp, vp, vp]),
+    "pv_vocab_nll_bwd_prob": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, i32, vp, i32, vp, vp, vp, vp]),
+    "pv_vocab_compact": (i32, [vp, i32, i64, vp, vp, vp]),
+    "pv_vocab_gather": (i32, [vp, i32, vp, vp, i32, i32, vp, i32, vp, vp]),
+    "pv_scatter_rows_f32": (i32, [vp, lng, vp, vp, i32, i32, vp, lng, vp]),
     "pv_vocab_argmax_ws_bytes": (sz, [i32, i32]),
     "pv_vocab_argmax": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp]),
     "pv_vocab_logprob_dense": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, vp, vp]),

@@ -30,19 +30,29 @@ struct GemmArgs {
   const bf16_t* A;
   const bf16_t* B;
   int M, N, K, lda, ldb;
-  int kt_per_split;   // split-K: blockIdx.y handles k-tiles [y*kt_per_split, (y+1)*kt_per_split); 0 = all of K
+  int splits;         // split-K: every tile is computed `splits` times over disjoint k-tile ranges (1 = no split)
+  int adaptive_slots; // > 0 with m_live: the kernel itself lowers `splits` to max(1, adaptive_slots / live tiles), so
+                      // that a launch whose row count is only known on the device still fills the chip once
+  // Device-side bounds (NULL = none), read at run time so that a captured graph follows the batch:
+  const int* m_live;  // tiles whose first row is >= *m_live exit at once (their rows are ignored tokens)
+  const int* k_live;  // the K loop stops at round_up(*k_live, 64) (<= K); with split-K the live k-tiles are divided
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ void tile_coords(int M, int N, int& pm, int& pn) {
-  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN, nwg = nbm * nbn;
-  const int bid = blockIdx.x;
-  // XCD-aware remap (bijective for any nwg): blocks b and b+8 share an XCD / L2.
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  // grouped ordering: walk 8 tile-rows at a time so concurrently running tiles share A/B panels
+// Tile walk.  The grid is a multiple of 8 workgroups; workgroups b and b+8 share an XCD (one L2), so XCD x owns the
+// contiguous range [xbeg, xbeg+xcnt) of tile ids and its gridDim.x/8 workgroups stride through it.  Tile ids follow
+// a grouped ordering: 8 tile-rows at a time, column-major inside the group, so tiles in flight share A/B panels.
+// With a grid of round_up(ntiles, 8) every workgroup has at most one tile; a smaller grid makes the workgroups
+// persistent, which is what the 15.7k-tile vocabulary launches want (workgroup dispatch alone costs ~16 ns each).
+__host__ __device__ __forceinline__ int live_splits(int splits, int adaptive_slots, int ntiles) {
+  if (adaptive_slots <= 0) return splits;
+  const int fit = adaptive_slots / (ntiles > 0 ? ntiles : 1);
+  return fit < 1 ? 1 : (fit < splits ? fit : splits);
+}
+
+__device__ __forceinline__ void tile_of(int id, int nbm, int nbn, int& pm, int& pn) {
   const int width = 8 * nbn, grp = id / width, first_m = grp * 8;
   const int gsz = min(nbm - first_m, 8);
   pm = first_m + (id % width) % gsz;
@@ -55,8 +65,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi ep
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int c16 = lane & 15, q4 = lane >> 4;
+  // rows at and past *m_live carry ignored tokens: their tiles are not walked at all
+  const int m_rows = g.m_live ? min(g.M, *g.m_live) : g.M;
+  const int nbm = (m_rows + BM - 1) / BM, nbn = (g.N + BN - 1) / BN, ntiles = nbm * nbn;
+  const int splits = live_splits(g.splits, g.adaptive_slots, ntiles);
+  const int nitems = ntiles * splits;               // work items: (split, tile), split-major
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const int tq = nitems >> 3, tr = nitems & 7;
+  const int xbeg = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, xcnt = tq + (xcd < tr ? 1 : 0);
+
+  // fragment read offsets (bytes) inside a stage: row*128 + ((ks*4+q4) ^ ((row>>1)&7))*16
+  int offA[4], offB[4], swz[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 64 + i * 16 + c16, rb = wn * 64 + i * 16 + c16;
+    offA[i] = ra * 128;
+    offB[i] = BM * BK * 2 + rb * 128;
+    swz[i] = (c16 >> 1) & 7;   // (row>>1)&7 : rows are 16-aligned + c16, so only c16 matters
+  }
+  const int nk_all = g.k_live ? min(g.K / BK, (*g.k_live + BK - 1) / BK) : g.K / BK;
+  const int per_split = (nk_all + splits - 1) / splits;
+
+  for (int tc = blockIdx.x >> 3; tc < xcnt; tc += per_xcd) {
+  const int item = xbeg + tc, split = item / ntiles;
+  const int kt0 = split * per_split, nk = min(nk_all, kt0 + per_split);   // an empty range stores zeros
   int pm, pn;
-  tile_coords(g.M, g.N, pm, pn);
+  tile_of(item - split * ntiles, nbm, nbn, pm, pn);
   const int m0 = pm * BM, n0 = pn * BN;
 
   // --- per-lane source pointers for the 4+4 LDS-DMA pieces this wave issues per K-tile ----------
@@ -90,23 +124,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi ep
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets (bytes) inside a stage: row*128 + ((ks*4+q4) ^ ((row>>1)&7))*16
-  int offA[4], offB[4], swz[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = wm * 64 + i * 16 + c16, rb = wn * 64 + i * 16 + c16;
-    offA[i] = ra * 128;
-    offB[i] = BM * BK * 2 + rb * 128;
-    swz[i] = (c16 >> 1) & 7;   // (row>>1)&7 : rows are 16-aligned + c16, so only c16 matters
-  }
-
   // what the epilogue reads from global memory (bias, targets, row statistics) is requested now, a whole main loop
   // ahead of its use: at K = 512 a tile's main loop is ~4 us and an exposed load round trip in the epilogue ~1-2 us
   const typename Epi::Pre pre = epi.prefetch(m0 + wm * 64, n0 + wn * 64, lane);
-  const int nk_all = g.K / BK;
-  const int kt0 = g.kt_per_split ? blockIdx.y * g.kt_per_split : 0;
-  const int nk = g.kt_per_split ? min(nk_all, kt0 + g.kt_per_split) : nk_all;
-  stage(kt0 & 1, kt0);
+  if (kt0 < nk) stage(kt0 & 1, kt0);
   for (int kt = kt0; kt < nk; ++kt) {
     const int s = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -130,7 +151,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi ep
     }
   }
   __syncthreads();   // all waves done with the ring: epilogues may reuse smem
-  epi(acc, pre, m0 + wm * 64, n0 + wn * 64, w, lane, smem);
+  epi(acc, pre, m0 + wm * 64, n0 + wn * 64, w, lane, smem, split);
+  __syncthreads();   // ... and the next tile's first stage may overwrite what the epilogue kept there
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -142,12 +165,12 @@ struct EpiStore {
   bf16_t* Cb;
   const float* bias;
   int M, N, ldc, ldcb, accumulate, bias_per_row;
-  long split_stride;   // split-K: slab blockIdx.y of the fp32 output starts at C + y * split_stride
+  long split_stride;   // split-K: slab `split` of the fp32 output starts at C + split * split_stride
   struct Pre {};
   __device__ Pre prefetch(int, int, int) const { return Pre{}; }
-  __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem) const {
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem, int split) const {
     const int c16 = lane & 15, q4 = lane >> 4;
-    float* C = this->C ? this->C + (long)blockIdx.y * split_stride : nullptr;
+    float* C = this->C ? this->C + (long)split * split_stride : nullptr;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int col = col0 + ni * 16 + c16;
@@ -210,7 +233,7 @@ struct EpiSoftmax {
     for (int r = 0; r < 16; ++r) p.tgt[r] = (int)target[min(row0 + (r >> 2) * 16 + q4 * 4 + (r & 3), T - 1)];
     return p;
   }
-  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem) const {
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem, int split) const {
     if (col0 >= V) return;
     const int c16 = lane & 15, q4 = lane >> 4;
     float bv[4];
@@ -303,7 +326,7 @@ struct EpiArgmax {
     for (int ni = 0; ni < 4; ++ni) p.bv[ni] = bias[min(col0 + ni * 16 + (lane & 15), V - 1)];
     return p;
   }
-  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem) const {
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem, int split) const {
     if (col0 >= V) return;
     const int c16 = lane & 15, q4 = lane >> 4;
     ArgPart mine{0.f, 0.f, 0.f, -1};
@@ -392,7 +415,7 @@ struct EpiProb {
     }
     return p;
   }
-  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem) const {
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem, int split) const {
     const int c16 = lane & 15, q4 = lane >> 4;
     const bool slab_live = (col0 < Vpad) && (row0 < Tpad);
     char* my = smem + w * EPI_WAVE_BYTES;
@@ -484,7 +507,7 @@ struct EpiLogProb {
   float inv_temp;
   struct Pre {};
   __device__ Pre prefetch(int, int, int) const { return Pre{}; }
-  __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem) const {
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem, int split) const {
     const int c16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -507,11 +530,22 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float2* __restr
                                                             const float* __restrict__ tgt_logit,
                                                             const int64_t* __restrict__ target, int T,
                                                             int Tpad, int nslab, int64_t ignore_index,
+                                                            const int* __restrict__ live_rows,
                                                             float* __restrict__ lse,
                                                             float* __restrict__ nll) {
   __shared__ float sm[4][64], ss[4][64];
   const int r = threadIdx.x & 63, y = threadIdx.x >> 6;
   const int row = blockIdx.x * 64 + r;
+  if (live_rows) {                                   // tiles past the live rows were never computed
+    const int lim = (*live_rows + 127) / 128 * 128;
+    if ((int)blockIdx.x * 64 >= lim) {
+      if (y == 0 && row < T) {
+        lse[row] = 0.f;
+        nll[row] = 0.f;
+      }
+      return;
+    }
+  }
   float m = -INFINITY, s = 0.f;
   if (row < T) {
     for (int k = y; k < nslab; k += 4) {
@@ -538,6 +572,58 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float2* __restr
   }
 }
 
+// ---- ignored-token compaction ------------------------------------------------------------------------------------
+// Rows whose target is the ignore index (padding: 44 % of the 12 800 token rows of the bench batch) contribute exactly
+// zero to the loss (NLLLoss(ignore_index), criterions.py:38-41) and to every gradient.  A stable partition moves the
+// live rows to the front; the GEMMs take the live count from device memory (GemmArgs::m_live / k_live), so the launch
+// geometry is static (graph-capturable) while the work follows the batch.
+// perm[new] = old row; live rows first in their original order, then the ignored rows; count[0] = live rows.
+__global__ __launch_bounds__(256) void vocab_compact_kernel(const int64_t* __restrict__ target, int T, int64_t ignore,
+                                                             int64_t* __restrict__ perm, int* __restrict__ count) {
+  __shared__ int cnt[256];
+  const int per = (T + 255) / 256, t0 = threadIdx.x * per, t1 = min(T, t0 + per);
+  int live = 0;
+  for (int t = t0; t < t1; ++t) live += target[t] != ignore;
+  cnt[threadIdx.x] = live;
+  __syncthreads();
+  int before = 0, total = 0;
+  for (int i = 0; i < 256; ++i) {                 // 256 adds per thread: trivial next to the loads
+    const int c = cnt[i];
+    if (i < (int)threadIdx.x) before += c;
+    total += c;
+  }
+  int pl = before, pd = total + (t0 < T ? t0 : T) - before;
+  for (int t = t0; t < t1; ++t) {
+    if (target[t] != ignore) perm[pl++] = t;
+    else perm[pd++] = t;
+  }
+  if (threadIdx.x == 0) count[0] = total;
+}
+
+// h_c[new][:] = h[perm[new]][:] (bf16 rows, 16-byte chunks), target_c[new] = target[perm[new]]
+__global__ void vocab_gather_kernel(const bf16_t* __restrict__ h, int ldh, const int64_t* __restrict__ target,
+                                    const int64_t* __restrict__ perm, int T, int chunks, bf16_t* __restrict__ hc, int ldc,
+                                    int64_t* __restrict__ target_c) {
+  const long n = (long)T * chunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / chunks), ch = (int)(i % chunks);
+    const long src = perm[row];
+    *(uint4*)(hc + (size_t)row * ldc + ch * 8) = *(const uint4*)(h + (size_t)src * ldh + ch * 8);
+    if (ch == 0) target_c[row] = target[src];
+  }
+}
+
+// dst[perm[new]][:] = new < count ? src[new][:] : 0     (fp32 rows of `cols` floats)
+__global__ void scatter_rows_kernel(const float* __restrict__ src, long lds_, const int64_t* __restrict__ perm,
+                                    const int* __restrict__ count, int T, int cols, float* __restrict__ dst, long ldd) {
+  const long n = (long)T * cols;
+  const int live = *count;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / cols), c = (int)(i % cols);
+    dst[perm[row] * ldd + c] = row < live ? src[(size_t)row * lds_ + c] : 0.f;
+  }
+}
+
 int check_gemm(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const char* who) {
   PV_REQUIRE(A && B, "%s: null operand", who);
   PV_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty problem M=%d N=%d K=%d", who, M, N, K);
@@ -549,9 +635,17 @@ int check_gemm(const void* A, const void* B, int M, int N, int K, int lda, int l
 }
 
 // C[m][n] (+)= sum over splits of ws[s][m][n]   (fixed order: bitwise reproducible)
+// With m_live the rows past round_up(*m_live, 128) were never computed and are left alone, and the split count is
+// the one the GEMM kernel chose for that row count.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long slab, int M,
-                                                             int N, float* __restrict__ C, int ldc, int accumulate) {
+                                                             int N, float* __restrict__ C, int ldc, int accumulate,
+                                                             const int* __restrict__ m_live, int adaptive_slots) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m_live) {
+    const int nbm = (min(M, *m_live) + BM - 1) / BM;
+    M = min(M, nbm * BM);
+    splits = live_splits(splits, adaptive_slots, nbm * ((N + BN - 1) / BN));
+  }
   if (i >= (long)M * N) return;
   float s = 0.f;
   for (int k = 0; k < splits; ++k) s += ws[k * slab + i];
@@ -559,16 +653,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *dst = accumulate ? *dst + s : s;
 }
 
+int persistent_grid() {
+  static int grid = 0;
+  if (!grid) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (const char* e = getenv("PEVAE_GEMM_WGS_PER_CU")) grid = (cus * atoi(e) + 7) & ~7;
+    else grid = (cus * 2 + 7) & ~7;
+  }
+  return grid;
+}
+
 template <class Epi>
-int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who, int splits = 1) {
+int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who) {
   static bool attr_done = false;
   if (!attr_done) {
     PV_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                SMEM_BYTES));
     attr_done = true;
   }
-  const int nwg = cdiv(g.M, BM) * cdiv(g.N, BN);
-  hipLaunchKernelGGL(gemm_nt_kernel<Epi>, dim3(nwg, splits), dim3(NTHREADS), SMEM_BYTES, st, g, epi);
+  // one work item per workgroup while that fills the chip about once; beyond it two persistent workgroups per CU
+  // walk the items
+  const int gx = std::min((cdiv(g.M, BM) * cdiv(g.N, BN) * g.splits + 7) & ~7, persistent_grid());
+  hipLaunchKernelGGL(gemm_nt_kernel<Epi>, dim3(gx), dim3(NTHREADS), SMEM_BYTES, st, g, epi);
   PV_LAUNCH_CHECK(who);
   return PV_OK;
 }
@@ -579,12 +686,12 @@ extern "C" {
 
 int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                     const float* bias, int bias_per_row, float* C, int ldc, void* Cb, int ldcb, int accumulate,
-                    void* stream) {
+                    const int* m_live, const int* k_live, void* stream) {
   int rc = check_gemm(A, B, M, N, K, lda, ldb, "pv_gemm_bf16_nt");
   if (rc) return rc;
   PV_REQUIRE(C || Cb, "pv_gemm_bf16_nt: no output given");
   PV_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N), "pv_gemm_bf16_nt: output leading dimension < N");
-  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, 0};
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, 1, 0, m_live, k_live};
   PV_REQUIRE(!accumulate || C, "pv_gemm_bf16_nt: accumulate needs the fp32 output");
   EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb, accumulate, bias_per_row, 0};
   return launch(g, e, (hipStream_t)stream, "pv_gemm_bf16_nt");
@@ -596,7 +703,7 @@ struct EpiNone {
   float* sink;
   struct Pre {};
   __device__ Pre prefetch(int, int, int) const { return Pre{}; }
-  __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem) const {
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem, int split) const {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -607,7 +714,7 @@ struct EpiNone {
 };
 }
 extern "C" int pv_gemm_bf16_nt_noepi(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* sink, void* stream) {
-  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, 0};
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, 1, 0, nullptr, nullptr};
   EpiNone e{sink};
   return launch(g, e, (hipStream_t)stream, "noepi");
 }
@@ -641,21 +748,54 @@ int pv_gemm_splitk_plan(int M, int N, int K, int target_wgs, int* splits) {
 size_t pv_gemm_splitk_ws_bytes(int M, int N, int splits) { return (size_t)splits * M * N * sizeof(float); }
 
 int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits,
-                           void* workspace, float* C, int ldc, int accumulate, void* stream) {
+                           void* workspace, float* C, int ldc, int accumulate, const int* m_live, const int* k_live,
+                           void* stream) {
   int rc = check_gemm(A, B, M, N, K, lda, ldb, "pv_gemm_bf16_nt_splitk");
   if (rc) return rc;
   PV_REQUIRE(C && workspace && ldc >= N && splits >= 1 && splits <= K / BK, "pv_gemm_bf16_nt_splitk: bad argument");
-  const int per = cdiv(K / BK, splits);
-  PV_REQUIRE(cdiv(K / BK, per) == splits, "pv_gemm_bf16_nt_splitk: %d splits leave an empty split (use pv_gemm_splitk_plan)", splits);
-  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, per};
+  // with a device-side row bound `splits` is an upper limit: the kernel lowers it until live tiles x splits fits the
+  // resident workgroups once
+  const int slots = m_live ? persistent_grid() : 0;
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, splits, slots, m_live, k_live};
   EpiStore e{(float*)workspace, nullptr, nullptr, M, N, N, 0, 0, 0, (long)M * N};
   hipStream_t st = (hipStream_t)stream;
-  rc = launch(g, e, st, "pv_gemm_bf16_nt_splitk", splits);
+  rc = launch(g, e, st, "pv_gemm_bf16_nt_splitk");
   if (rc) return rc;
   const long n = (long)M * N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
-                     splits, n, M, N, C, ldc, accumulate);
+                     splits, n, M, N, C, ldc, accumulate, m_live, slots);
   PV_LAUNCH_CHECK("splitk_reduce_kernel");
+  return PV_OK;
+}
+
+int pv_vocab_compact(const int64_t* target, int T, int64_t ignore_index, int64_t* perm, int* count, void* stream) {
+  PV_REQUIRE(target && perm && count && T > 0, "pv_vocab_compact: bad argument");
+  hipLaunchKernelGGL(vocab_compact_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, target, T, ignore_index, perm, count);
+  PV_LAUNCH_CHECK("vocab_compact_kernel");
+  return PV_OK;
+}
+
+int pv_vocab_gather(const void* h, int ldh, const int64_t* target, const int64_t* perm, int T, int H, void* h_c, int ldc,
+                    int64_t* target_c, void* stream) {
+  PV_REQUIRE(h && target && perm && h_c && target_c && T > 0 && H > 0 && H % 8 == 0 && ldh % 8 == 0 && ldc % 8 == 0 &&
+                 ldh >= H && ldc >= H, "pv_vocab_gather: bad argument (H and the leading dimensions must be multiples of 8)");
+  PV_REQUIRE(((uintptr_t)h & 15) == 0 && ((uintptr_t)h_c & 15) == 0, "pv_vocab_gather: rows must be 16-byte aligned");
+  const long n = (long)T * (H / 8);
+  const long gx = (n + 255) / 256;
+  hipLaunchKernelGGL(vocab_gather_kernel, dim3((unsigned)(gx > 4096 ? 4096 : gx)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)h, ldh, target, perm, T, H / 8, (bf16_t*)h_c, ldc, target_c);
+  PV_LAUNCH_CHECK("vocab_gather_kernel");
+  return PV_OK;
+}
+
+int pv_scatter_rows_f32(const float* src, long lds, const int64_t* perm, const int* count, int T, int cols, float* dst,
+                        long ldd, void* stream) {
+  PV_REQUIRE(src && perm && count && dst && T > 0 && cols > 0 && lds >= cols && ldd >= cols, "pv_scatter_rows_f32: bad argument");
+  const long n = (long)T * cols;
+  const long gx = (n + 255) / 256;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)(gx > 4096 ? 4096 : gx)), dim3(256), 0, (hipStream_t)stream, src, lds,
+                     perm, count, T, cols, dst, ldd);
+  PV_LAUNCH_CHECK("scatter_rows_kernel");
   return PV_OK;
 }
 
@@ -665,7 +805,7 @@ size_t pv_vocab_nll_fwd_ws_bytes(int T, int V) {
 
 int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float* bias,
                      const int64_t* target, int T, int V, int H, float inv_temp, int64_t ignore_index,
-                     void* workspace, float* lse, float* nll, void* stream) {
+                     void* workspace, float* lse, float* nll, const int* live_rows, void* stream) {
   int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_nll_fwd");
   if (rc) return rc;
   PV_REQUIRE(bias && target && workspace && lse && nll, "pv_vocab_nll_fwd: null argument");
@@ -675,12 +815,12 @@ int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float
   hipStream_t st = (hipStream_t)stream;
   // rows whose target is out of range (e.g. ignore_index < 0) never get a target logit written
   PV_HIP(hipMemsetAsync(tgt_logit, 0, (size_t)Tpad * sizeof(float), st));
-  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 0};
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 1, 0, live_rows, nullptr};
   EpiSoftmax e{bias, target, part, tgt_logit, T, V, Tpad, inv_temp};
   rc = launch(g, e, st, "pv_vocab_nll_fwd");
   if (rc) return rc;
   hipLaunchKernelGGL(vocab_reduce_kernel, dim3(cdiv(T, 64)), dim3(256), 0, st, part, tgt_logit, target, T,
-                     Tpad, nslab, ignore_index, lse, nll);
+                     Tpad, nslab, ignore_index, live_rows, lse, nll);
   PV_LAUNCH_CHECK("vocab_reduce_kernel");
   return PV_OK;
 }
@@ -688,7 +828,7 @@ int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float
 int pv_vocab_nll_bwd_prob(const void* h, int ldh, const void* W, int ldw, const float* bias,
                           const int64_t* target, const float* lse, const float* gscale, int T, int V,
                           int H, float inv_temp, void* P, int ldp, void* PT, int ldpt,
-                          float* dbias_part, float* dbias, void* stream) {
+                          float* dbias_part, float* dbias, const int* live_rows, void* stream) {
   int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_nll_bwd_prob");
   if (rc) return rc;
   const int Tpad = round_up(T, 64), Vpad = round_up(V, 64);
@@ -697,7 +837,8 @@ int pv_vocab_nll_bwd_prob(const void* h, int ldh, const void* W, int ldw, const 
              "pv_vocab_nll_bwd_prob: need ldp >= %d and ldpt >= %d (multiples of 8)", Vpad, Tpad);
   PV_REQUIRE(((uintptr_t)P & 15) == 0 && ((uintptr_t)PT & 15) == 0, "pv_vocab_nll_bwd_prob: P/PT must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 0};
+  if (live_rows) PV_HIP(hipMemsetAsync(dbias_part, 0, (size_t)(Tpad / 64) * ldp * sizeof(float), st));   // skipped tiles
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 1, 0, live_rows, nullptr};
   EpiProb e{bias, target, lse, gscale, (bf16_t*)P, (bf16_t*)PT, dbias_part, T, V, Tpad, Vpad, ldp, ldpt, inv_temp};
   rc = launch(g, e, st, "pv_vocab_nll_bwd_prob");
   if (rc) return rc;
@@ -714,7 +855,7 @@ int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float*
   PV_REQUIRE(bias && workspace && ids && logp, "pv_vocab_argmax: null argument");
   const int Tpad = round_up(T, 64), nslab = cdiv(V, 64);
   hipStream_t st = (hipStream_t)stream;
-  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 0};
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 1, 0, nullptr, nullptr};
   EpiArgmax e{bias, (ArgPart*)workspace, T, V, Tpad, mask_col, inv_temp};
   rc = launch(g, e, st, "pv_vocab_argmax");
   if (rc) return rc;
@@ -729,7 +870,7 @@ int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const
   int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_logprob_dense");
   if (rc) return rc;
   PV_REQUIRE(bias && lse && out, "pv_vocab_logprob_dense: null argument");
-  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 0};
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 1, 0, nullptr, nullptr};
   EpiLogProb e{bias, lse, out, T, V, inv_temp};
   return launch(g, e, (hipStream_t)stream, "pv_vocab_logprob_dense");
 }

@@ -6,6 +6,8 @@ has a CPU path -- CPU tensors raise.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -142,18 +144,20 @@ def transpose_to_bf16(src, R, Cc, lds, rpad, out=None):
     return out
 
 
-def gemm_nt(A, lda, Bm, ldb, M, N, K, bias=None, out=None, out_bf16=None, accumulate=False, bias_per_row=False):
-    """C[M,N] (+)= A[M,K] B[N,K]^T (+bias) with bf16 operands on the MFMA core."""
+def gemm_nt(A, lda, Bm, ldb, M, N, K, bias=None, out=None, out_bf16=None, accumulate=False, bias_per_row=False,
+            m_live=None, k_live=None):
+    """C[M,N] (+)= A[M,K] B[N,K]^T (+bias) with bf16 operands on the MFMA core.  m_live / k_live: int32 device scalars
+    bounding the rows / the K extent at run time (pv_gemm_bf16_nt)."""
     _need_cuda(A, Bm)
     if out is None and out_bf16 is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     _lib.call("pv_gemm_bf16_nt", _p(A), lda, _p(Bm), ldb, M, N, K, _p(bias), 1 if bias_per_row else 0, _p(out),
               0 if out is None else out.stride(0), _p(out_bf16), 0 if out_bf16 is None else out_bf16.stride(0),
-              1 if accumulate else 0, _stream())
+              1 if accumulate else 0, _p(m_live), _p(k_live), _stream())
     return out if out is not None else out_bf16
 
 
-def gemm_nt_wgrad(A, lda, Bm, ldb, M, N, K, sink=None):
+def gemm_nt_wgrad(A, lda, Bm, ldb, M, N, K, sink=None, k_live=None):
     """Weight-gradient GEMM C[M,N] = A[M,K] B[N,K]^T whose K is the token count: split-K over ~2 workgroups per CU when
     the plain tiling would leave most of the chip idle.  Accumulates into `sink` when given, else returns C."""
     _need_cuda(A, Bm)
@@ -164,12 +168,25 @@ def gemm_nt_wgrad(A, lda, Bm, ldb, M, N, K, sink=None):
     _lib.call("pv_gemm_splitk_plan", M, N, K, 2 * cus, C.byref(splits))
     out = sink if sink is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
     if splits.value <= 1:
-        gemm_nt(A, lda, Bm, ldb, M, N, K, out=out, accumulate=sink is not None)
+        gemm_nt(A, lda, Bm, ldb, M, N, K, out=out, accumulate=sink is not None, k_live=k_live)
     else:
         ws = workspace("gemm_splitk", _lib.load().pv_gemm_splitk_ws_bytes(M, N, splits.value), torch.uint8, A.device)
         _lib.call("pv_gemm_bf16_nt_splitk", _p(A), lda, _p(Bm), ldb, M, N, K, splits.value, _p(ws), _p(out),
-                  out.stride(0), 1 if sink is not None else 0, _stream())
+                  out.stride(0), 1 if sink is not None else 0, None, _p(k_live), _stream())
     return None if sink is not None else out
+
+
+def gemm_nt_live_rows(A, lda, Bm, ldb, M, N, K, m_live, max_splits=4):
+    """C[M,N] = A[M,K] B[N,K]^T where only the first *m_live rows (int32 device scalar) are wanted: the kernel walks the
+    live tiles only and splits K on the device so that they still fill the chip (pv_gemm_bf16_nt_splitk with m_live).
+    Rows past round_up(*m_live, 128) of the result are uninitialised."""
+    _need_cuda(A, Bm)
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    splits = max(1, min(max_splits, K // 64 // 4))
+    ws = workspace("gemm_splitk_rows", _lib.load().pv_gemm_splitk_ws_bytes(M, N, splits), torch.uint8, A.device)
+    _lib.call("pv_gemm_bf16_nt_splitk", _p(A), lda, _p(Bm), ldb, M, N, K, splits, _p(ws), _p(out), out.stride(0), 0,
+              _p(m_live), None, _stream())
+    return out
 
 
 _DEV_CU = []
@@ -210,9 +227,17 @@ def _vocab_operands(hid, weight):
     return T, H, V, Hp, h_bf, ldh, w_bf
 
 
+SKIP_IGNORED_TOKENS = os.environ.get("PEVAE_VOCAB_DENSE", "0") != "1"     # see VocabNLL
+
+
 class VocabNLL(torch.autograd.Function):
     """nll_tok[t] = -log_softmax((h W^T + b) / temperature)[target[t]], 0 for ignored targets; the [T,V]
-    log-prob tensor is never built (decoders.py:191-193 + criterions.py:55-64 of the reference, fused)."""
+    log-prob tensor is never built (decoders.py:191-193 + criterions.py:55-64 of the reference, fused).
+
+    Rows whose target is the ignore index add exactly zero to the loss and to every gradient (NLLLoss(ignore_index),
+    criterions.py:38-41), so by default they are not multiplied at all: a stable partition moves the live rows to the
+    front (pv_vocab_compact / pv_vocab_gather) and the four GEMMs of the group take the live-row count from device
+    memory (static launch geometry, graph-capturable).  PEVAE_VOCAB_DENSE=1 computes every row like the reference."""
 
     @staticmethod
     def forward(ctx, hid, weight, bias, target, inv_temp, ignore_index, hid_bf16, layout):
@@ -224,14 +249,32 @@ class VocabNLL(torch.autograd.Function):
         dev = weight.device
         ctx.layout = layout
         target = target.contiguous()
+        perm = count = None
+        if SKIP_IGNORED_TOKENS and ignore_index >= 0:
+            perm = torch.empty(T, dtype=torch.int64, device=dev)
+            count = torch.empty(1, dtype=torch.int32, device=dev)
+            _lib.call("pv_vocab_compact", _p(target), T, ignore_index, _p(perm), _p(count), _stream())
+            h_c = torch.empty((T, Hp), dtype=BF16, device=dev)
+            t_c = torch.empty(T, dtype=torch.int64, device=dev)
+            _lib.call("pv_vocab_gather", _p(h_bf), ldh, _p(target), _p(perm), T, Hp, _p(h_c), Hp, _p(t_c), _stream())
+            h_bf, ldh, target = h_c, Hp, t_c
         ws = workspace("vocab_fwd", _lib.load().pv_vocab_nll_fwd_ws_bytes(T, V), torch.uint8, dev)
         lse = torch.empty(T, dtype=torch.float32, device=dev)
         nll = torch.empty(T, dtype=torch.float32, device=dev)
         bias_c = bias.contiguous()
         with timed("vocab_fwd"):
             _lib.call("pv_vocab_nll_fwd", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(target), T, V, Hp, inv_temp,
-                      ignore_index, _p(ws), _p(lse), _p(nll), _stream())
-        ctx.save_for_backward(h_bf, w_bf, bias_c, target, lse)
+                      ignore_index, _p(ws), _p(lse), _p(nll), _p(count), _stream())
+        if perm is not None:                           # back to the caller's row order (ignored rows: 0)
+            nll_c, lse_c = nll, lse
+            nll = torch.empty(T, dtype=torch.float32, device=dev)
+            lse = torch.empty(T, dtype=torch.float32, device=dev)
+            _lib.call("pv_scatter_rows_f32", _p(nll_c), 1, _p(perm), _p(count), T, 1, _p(nll), 1, _stream())
+            _lib.call("pv_scatter_rows_f32", _p(lse_c), 1, _p(perm), _p(count), T, 1, _p(lse), 1, _stream())
+            ctx.save_for_backward(h_bf, w_bf, bias_c, target, lse_c, perm, count)
+        else:
+            ctx.save_for_backward(h_bf, w_bf, bias_c, target, lse)
+        ctx.compact = perm is not None
         ctx.dims = (T, H, V, Hp, ldh, inv_temp, ignore_index)
         ctx.hid_dtype = hid.dtype
         ctx.params = (weight, bias)
@@ -240,34 +283,46 @@ class VocabNLL(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dnll, _dlse):
-        h_bf, w_bf, bias, target, lse = ctx.saved_tensors
+        if ctx.compact:
+            h_bf, w_bf, bias, target, lse, perm, count = ctx.saved_tensors
+        else:
+            h_bf, w_bf, bias, target, lse = ctx.saved_tensors
+            perm = count = None
         T, H, V, Hp, ldh, inv_temp, ignore_index = ctx.dims
         dev = w_bf.device
         Tp, Vp = round_up(T, 64), round_up(V, 64)
-        gscale = (dnll.to(torch.float32) * (target != ignore_index)).contiguous()
+        dn = dnll.to(torch.float32)
+        if perm is not None:
+            dn = dn.index_select(0, perm)              # `target` is already in compact order
+        gscale = (dn * (target != ignore_index)).contiguous()
         P = workspace("vocab_P", Tp * Vp, BF16, dev)
         PT = workspace("vocab_PT", Vp * Tp, BF16, dev)
         dbp = workspace("vocab_dbias_part", (Tp // 64) * Vp, torch.float32, dev)
         dbias = torch.empty(V, dtype=torch.float32, device=dev)
         with timed("vocab_bwd_prob"):
             _lib.call("pv_vocab_nll_bwd_prob", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(target), _p(lse),
-                      _p(gscale), T, V, Hp, inv_temp, _p(P), Vp, _p(PT), Tp, _p(dbp), _p(dbias), _stream())
+                      _p(gscale), T, V, Hp, inv_temp, _p(P), Vp, _p(PT), Tp, _p(dbp), _p(dbias), _p(count), _stream())
         weight, _bias = ctx.params
-        dH, dW = _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, grad_sink(weight, (V, H)))
+        dH, dW = _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, grad_sink(weight, (V, H)), count)
+        if perm is not None:
+            dH_c = dH
+            dH = torch.empty((T, H), dtype=torch.float32, device=dev)
+            _lib.call("pv_scatter_rows_f32", _p(dH_c), H, _p(perm), _p(count), T, H, _p(dH), H, _stream())
         if ctx.layout is not None:
             L, B, Bpad = ctx.layout
             dH = dH.view(L, Bpad, H)[:, :B].transpose(0, 1)
         return dH, dW, dbias, None, None, None, None, None
 
 
-def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, dw_sink=None):
+def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, dw_sink=None, live=None):
     dev = w_bf.device
     wT = transpose_to_bf16(w_bf, V, H, Hp, Vp, out=workspace("vocab_WT", H * Vp, BF16, dev).view(H, Vp))
     with timed("vocab_dH"):
-        dH = gemm_nt(P, Vp, wT, Vp, T, H, Vp)
+        # rows past the live count are never read (scattered as 0)
+        dH = gemm_nt(P, Vp, wT, Vp, T, H, Vp) if live is None else gemm_nt_live_rows(P, Vp, wT, Vp, T, H, Vp, live)
     hT = transpose_to_bf16(h_bf, T, H, ldh, Tp, out=workspace("vocab_hT", H * Tp, BF16, dev).view(H, Tp))
     with timed("vocab_dW"):
-        dW = gemm_nt_wgrad(PT, Tp, hT, Tp, V, H, Tp, dw_sink)      # split-K when the tile count leaves a ragged last round
+        dW = gemm_nt_wgrad(PT, Tp, hT, Tp, V, H, Tp, dw_sink, k_live=live)   # K = token rows: only the live ones
     return dH, dW
 
 
@@ -301,7 +356,7 @@ class VocabLogProbDense(torch.autograd.Function):
         tgt = torch.zeros(T, dtype=torch.int64, device=dev)
         bias_c = bias.contiguous()
         _lib.call("pv_vocab_nll_fwd", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(tgt), T, V, Hp, inv_temp, -1,
-                  _p(ws), _p(lse), _p(nll), _stream())
+                  _p(ws), _p(lse), _p(nll), None, _stream())
         logp = torch.empty((T, V), dtype=torch.float32, device=dev)
         _lib.call("pv_vocab_logprob_dense", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(lse), T, V, Hp, inv_temp,
                   _p(logp), _stream())

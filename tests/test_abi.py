@@ -40,7 +40,7 @@ def test_argument_validation_needs_no_gpu():
     """Bad arguments are rejected on the host before anything is launched."""
     from pevae_amd import _lib
     lib = _lib.load()
-    rc = lib.pv_gemm_bf16_nt(None, 64, None, 64, 4, 4, 64, None, 0, None, 0, None, 0, 0, None)
+    rc = lib.pv_gemm_bf16_nt(None, 64, None, 64, 4, 4, 64, None, 0, None, 0, None, 0, 0, None, None, None)
     assert rc == -1 and b"null operand" in lib.pv_last_error()
     hk, k3, bp, ng = (ctypes.c_int() for _ in range(4))
     assert lib.pv_gru_geometry(256, 512, ctypes.byref(hk), ctypes.byref(k3), ctypes.byref(bp), ctypes.byref(ng)) == 0

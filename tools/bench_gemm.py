@@ -62,7 +62,7 @@ def main():
     lse, nll = torch.empty(T, device=dev), torch.empty(T, device=dev)
     p, st = ops._p, ops._stream
     med, mn = timeit(lambda: _lib.call("pv_vocab_nll_fwd", p(hid), H, p(W), H, p(bias), p(tgt), T, V, H, 1.0, 0, p(ws), p(lse),
-                                       p(nll), st()), reps)
+                                       p(nll), None, st()), reps)
     print("%-34s %10.1f %10.1f %10.1f   %s" % ("vocab_nll_fwd", med, mn, 2.0 * T * V * H / med / 1e6, "fused softmax partials"))
     Tp, Vp = ops.round_up(T, 64), ops.round_up(V, 64)
     P = torch.empty((Tp, Vp), dtype=BF16, device=dev)
@@ -71,7 +71,7 @@ def main():
     dbias = torch.empty(V, device=dev)
     gs = torch.full((T,), 1.0 / 256, device=dev)
     med, mn = timeit(lambda: _lib.call("pv_vocab_nll_bwd_prob", p(hid), H, p(W), H, p(bias), p(tgt), p(lse), p(gs), T, V, H, 1.0,
-                                       p(P), Vp, p(PT), Tp, p(dbp), p(dbias), st()), reps)
+                                       p(P), Vp, p(PT), Tp, p(dbp), p(dbias), None, st()), reps)
     print("%-34s %10.1f %10.1f %10.1f   %s" % ("vocab_nll_bwd_prob", med, mn, 2.0 * T * V * H / med / 1e6, "P, P^T, dbias"))
 
 

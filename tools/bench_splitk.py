@@ -18,7 +18,7 @@ for (M, N, K) in ((20004, 512, 12800), (12800, 512, 20032), (1536, 512, 12800), 
             if splits == 1:
                 ops.gemm_nt(A, K, B, K, M, N, K, out=out, accumulate=True)
             else:
-                _lib.call("pv_gemm_bf16_nt_splitk", A.data_ptr(), K, B.data_ptr(), K, M, N, K, splits, ws.data_ptr(), out.data_ptr(), N, 1, torch.cuda.current_stream().cuda_stream)
+                _lib.call("pv_gemm_bf16_nt_splitk", A.data_ptr(), K, B.data_ptr(), K, M, N, K, splits, ws.data_ptr(), out.data_ptr(), N, 1, None, None, torch.cuda.current_stream().cuda_stream)
         for _ in range(3): f()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
