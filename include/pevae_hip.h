@@ -138,7 +138,7 @@ int pv_lstm_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn,
 int pv_embedding_gather(const float* table, long num_rows, int D, const int64_t* ids, int n, int n1, int n1p,
                         long s0, long s1, float* out, int ldo, void* out_bf16, int ldb, int* oob_counter,
                         void* stream);
-size_t pv_embedding_bwd_ws_bytes(int n);
+size_t pv_embedding_bwd_ws_bytes(int n, int D);
 int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n, int n1, int n1p, long s0, long s1,
                      long num_rows, int D, long padding_idx, int accumulate, float* dtable, void* workspace,
                      size_t ws_bytes, void* stream);
@@ -263,9 +263,10 @@ int pv_block_bwd(const pv_block_call* calls, int n, void* stream);
  * dis_layer2 (mean | log sigma halves).  ls = mean + exp(logsigma) * eps + a2 (:3299-3300), out = lay + ls (:3310),
  * kl[0] = (ew + cw) * mean_b sum_d KL(prior || posterior) (:3305-3306; the backward gives the prior's gradient the
  * weight ew and the posterior's cw, as the two detached-direction terms do).  pv_dls_inputs_*: q_in = [a1 + a2 | ls],
- * p_in = [a2 | lt] (:3289-3297) and the split of their gradients. */
+ * p_in = [a2 | lt] (:3289-3297) and the split of their gradients.  kl_part: 256 floats of scratch (per-workgroup KL
+ * partials, added in index order). */
 int pv_dls_level_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
-                     float ew, float cw, float* ls, float* out, float* kl, void* stream);
+                     float ew, float cw, float* ls, float* out, float* kl, float* kl_part, void* stream);
 int pv_dls_level_bwd(const float* Q, const float* Pr, const float* eps, const float* d_ls, const float* d_out,
                      const float* g_kl, int B, int n, float ew, float cw, float* dQ, float* dPr, float* da2, float* dlay,
                      void* stream);

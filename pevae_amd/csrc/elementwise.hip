@@ -364,15 +364,29 @@ namespace {
 //   out = lay + ls                                             (:3310)
 //   kl  = (ew + cw) * mean_b sum_d KL(prior || posterior)      (:3305-3306; as a VALUE both detached-direction terms are
 //         this number, their gradients differ: ew scales the prior's, cw the posterior's)
-// One workgroup (B * n <= a few 10^4 elements), fixed-order reduction.
+// Workgroup g handles a contiguous run of elements and leaves its KL partial in part[g]; dls_level_kl_kernel adds
+// the partials in index order (fixed-order reduction, run-to-run identical).  One workgroup alone took 56 us at the
+// widest level (B * n = 131072).
+constexpr int DLS_WG_ELEMS = 2048, DLS_MAX_PART = 256;
+__global__ __launch_bounds__(64) void dls_level_kl_kernel(const float* __restrict__ part, int nparts, float scale,
+                                                          float* __restrict__ kl) {
+  float s = 0.f;
+  for (int i0 = 0; i0 < nparts; i0 += 64) {                 // 64 partials per load, added in index order
+    const float v = i0 + (int)threadIdx.x < nparts ? part[i0 + threadIdx.x] : 0.f;
+    for (int k = 0; k < 64 && i0 + k < nparts; ++k) s += __shfl(v, k);
+  }
+  if (threadIdx.x == 0) kl[0] = scale * s;
+}
+
 __global__ __launch_bounds__(256) void dls_level_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Pr,
                                                              const float* __restrict__ a2, const float* __restrict__ eps,
                                                              const float* __restrict__ lay, int B, int n, float ew, float cw,
                                                              float* __restrict__ ls, float* __restrict__ out,
-                                                             float* __restrict__ kl) {
+                                                             float* __restrict__ part, int per_wg) {
   __shared__ float red[256];
   float acc = 0.f;
-  for (int i = threadIdx.x; i < B * n; i += 256) {
+  const int lo = blockIdx.x * per_wg, hi = min(B * n, lo + per_wg);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const int b = i / n, d = i % n;
     const float m = Q[(size_t)b * 2 * n + d], l = Q[(size_t)b * 2 * n + n + d];
     const float tm = Pr[(size_t)b * 2 * n + d], tl = Pr[(size_t)b * 2 * n + n + d];
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(256) void dls_level_fwd_kernel(const float* __restr
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) kl[0] = (ew + cw) * red[0] / B;
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
 // d_ls / d_out / g_kl: gradients of the three outputs (d_ls, d_out may be NULL).  dQ, dPr [B][2n]; da2, dlay [B][n].
@@ -453,11 +467,18 @@ __global__ void dls_inputs_bwd_kernel(const float* __restrict__ dq, const float*
 extern "C" {
 
 int pv_dls_level_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
-                     float ew, float cw, float* ls, float* out, float* kl, void* stream) {
-  PV_REQUIRE(Q && Pr && a2 && eps && lay && ls && out && kl && B > 0 && n > 0, "pv_dls_level_fwd: bad argument");
-  hipLaunchKernelGGL(dls_level_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Q, Pr, a2, eps, lay, B, n, ew, cw, ls,
-                     out, kl);
+                     float ew, float cw, float* ls, float* out, float* kl, float* kl_part, void* stream) {
+  PV_REQUIRE(Q && Pr && a2 && eps && lay && ls && out && kl && kl_part && B > 0 && n > 0, "pv_dls_level_fwd: bad argument");
+  const long total = (long)B * n;
+  PV_REQUIRE(total < (1l << 31), "pv_dls_level_fwd: B * n too large");
+  int wgs = (int)((total + DLS_WG_ELEMS - 1) / DLS_WG_ELEMS);
+  if (wgs > DLS_MAX_PART) wgs = DLS_MAX_PART;
+  const int per = (int)((total + wgs - 1) / wgs);
+  hipLaunchKernelGGL(dls_level_fwd_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, Q, Pr, a2, eps, lay, B, n, ew, cw, ls,
+                     out, kl_part, per);
   PV_LAUNCH_CHECK("dls_level_fwd_kernel");
+  hipLaunchKernelGGL(dls_level_kl_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_part, wgs, (ew + cw) / B, kl);
+  PV_LAUNCH_CHECK("dls_level_kl_kernel");
   return PV_OK;
 }
 

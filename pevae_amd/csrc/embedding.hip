@@ -50,27 +50,34 @@ __global__ void fill_keys_kernel(const int64_t* __restrict__ ids, int n, int n1,
   vals[r] = (r / n1) * n1p + r % n1;                                // row of the gradient matrix
 }
 
-// One wave per (sorted position that starts a segment, 64-column block).  The segment's rows are summed in
-// occurrence order (so the result has the bits of a sequential CPU index_add_), but 64 rows are kept in
-// flight per wave: the row ids of a batch are fetched with one coalesced load and broadcast with
-// v_readlane, all 64 row loads are issued back to back, and only then added in order.  A Zipf-heavy word
-// (~10^3 occurrences at the Yelp shape) costs ~20 dependent round trips instead of ~10^3, and the segment
-// end is found with ballots over 64 keys at a time instead of a serial scan.
+// One wave per (sorted position that starts a piece, 64-column block).  A segment (all occurrences of one row id) is
+// summed in occurrence order, so a row with fewer than SEG_CH occurrences gets the bits of a sequential CPU
+// index_add_.  64 gradient rows are kept in flight per wave: the row ids of a batch are fetched with one coalesced load
+// and broadcast with v_readlane, all 64 row loads are issued back to back, and only then added in order; the segment
+// end is found with ballots over 64 keys at a time.  A Zipf-heavy word (~10^3 occurrences at the Yelp shape) would
+// still be ~20 dependent batches of ~2.5 us, so long segments are cut into pieces: the head piece runs to the first
+// position that is a multiple of SEG_CH and at least SEG_CH past the head, every following multiple of SEG_CH inside the
+// segment starts another piece.  The head piece goes to the table row, the others to `part`, and
+// segment_combine_kernel adds those to the row in position order: a fixed association, deterministic run to run.
 constexpr int SEG_NB = 64;
+constexpr int SEG_CH = 256;
 __global__ __launch_bounds__(256) void segment_sum_kernel(const int* __restrict__ keys, const int* __restrict__ vals,
                                                            int n, const float* __restrict__ grad, int ldg, int D,
                                                            long num_rows, long padding_idx, int accumulate,
-                                                           float* __restrict__ dtable) {
+                                                           float* __restrict__ dtable, float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const int key = keys[i];
-  if (i > 0 && keys[i - 1] == key) return;                 // not a segment head
   if (key < 0 || key >= num_rows || key == padding_idx) return;
+  const bool head = i == 0 || keys[i - 1] != key;
+  const bool cut = !head && i % SEG_CH == 0 && keys[i - SEG_CH] == key;      // i >= SEG_CH: i is a non-zero multiple
+  if (!head && !cut) return;
+  const int stop = min(n, head ? (i + 2 * SEG_CH - 1) / SEG_CH * SEG_CH : i + SEG_CH);   // where the next piece would start
   int end = i + 1;
-  for (;;) {                                               // wave-uniform: first position whose key differs
+  while (end < stop) {                                     // wave-uniform: first position whose key differs
     const int p = end + lane;
-    const bool same = p < n && keys[p] == key;
+    const bool same = p < stop && keys[p] == key;
     const unsigned long long m = __ballot(same);
     if (m == ~0ull) {
       end += 64;
@@ -79,10 +86,11 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int* __restrict_
     end += __builtin_ctzll(~m);
     break;
   }
+  end = min(end, stop);
   const int c = blockIdx.y * 64 + lane;
   const bool cl = c < D;
-  float* dst = dtable + (size_t)key * D;
-  float s = (accumulate && cl) ? dst[c] : 0.f;
+  float* dst = head ? dtable + (size_t)key * D : part + (size_t)(i / SEG_CH) * D;
+  float s = (head && accumulate && cl) ? dst[c] : 0.f;
   for (int j0 = i; j0 < end; j0 += SEG_NB) {
     const int cnt = min(SEG_NB, end - j0);
     const int myv = (lane < cnt) ? vals[j0 + lane] : 0;
@@ -97,6 +105,25 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int* __restrict_
       if (k < cnt) s += r[k];
   }
   if (cl) dst[c] = s;
+}
+
+// One wave per (multiple q of SEG_CH, 64-column block): if q starts the FIRST cut piece of its segment, add that piece
+// and the following ones to the table row, in position order.
+__global__ __launch_bounds__(64) void segment_combine_kernel(const int* __restrict__ keys, int n, int D, long num_rows,
+                                                             long padding_idx, const float* __restrict__ part,
+                                                             float* __restrict__ dtable) {
+  const int q = (blockIdx.x + 1) * SEG_CH;
+  if (q >= n) return;
+  const int key = keys[q];
+  if (key < 0 || key >= num_rows || key == padding_idx) return;
+  if (keys[q - SEG_CH] != key) return;                                   // q is not a cut
+  if (q >= 2 * SEG_CH && keys[q - 2 * SEG_CH] == key) return;            // ... or not the first one of its segment
+  const int c = blockIdx.y * 64 + threadIdx.x;
+  if (c >= D) return;
+  float* dst = dtable + (size_t)key * D;
+  float s = dst[c];
+  for (int p = q; p < n && keys[p] == key; p += SEG_CH) s += part[(size_t)(p / SEG_CH) * D + c];
+  dst[c] = s;
 }
 
 size_t sort_temp_bytes(int n) {
@@ -123,9 +150,9 @@ int pv_embedding_gather(const float* table, long num_rows, int D, const int64_t*
   return PV_OK;
 }
 
-size_t pv_embedding_bwd_ws_bytes(int n) {
+size_t pv_embedding_bwd_ws_bytes(int n, int D) {
   const size_t a = round_up(n, 64) * sizeof(int);
-  return 4 * a + ((sort_temp_bytes(n) + 255) & ~(size_t)255) + 256;
+  return 4 * a + ((sort_temp_bytes(n) + 255) & ~(size_t)255) + 256 + ((size_t)(n / SEG_CH + 1) * D * sizeof(float));
 }
 
 int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n, int n1, int n1p, long s0, long s1,
@@ -133,7 +160,7 @@ int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n,
                      size_t ws_bytes, void* stream) {
   PV_REQUIRE(grad_rows && ids && dtable && workspace, "pv_embedding_bwd: null argument");
   PV_REQUIRE(n >= 0 && n1 > 0 && n1p >= n1 && D > 0 && ldg >= D, "pv_embedding_bwd: bad sizes");
-  PV_REQUIRE(ws_bytes >= pv_embedding_bwd_ws_bytes(n), "pv_embedding_bwd: workspace too small");
+  PV_REQUIRE(ws_bytes >= pv_embedding_bwd_ws_bytes(n, D), "pv_embedding_bwd: workspace too small");
   PV_REQUIRE(num_rows < (1l << 30), "pv_embedding_bwd: table rows must fit int32 sort keys");
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate) PV_HIP(hipMemsetAsync(dtable, 0, (size_t)num_rows * D * sizeof(float), st));
@@ -146,14 +173,20 @@ int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n,
   int* svals = (int*)(ws + 3 * a);
   void* temp = ws + 4 * a;
   size_t temp_bytes = sort_temp_bytes(n);
+  float* part = (float*)(ws + 4 * a + ((temp_bytes + 255) & ~(size_t)255) + 256);   // one row per multiple of SEG_CH
   hipLaunchKernelGGL(fill_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, n, n1, n1p, s0, s1, num_rows, keys, vals);
   PV_LAUNCH_CHECK("fill_keys_kernel");
   int bits = 1;
   while ((1l << bits) <= num_rows && bits < 31) ++bits;
   PV_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, skeys, vals, svals, n, 0, bits, st));
   hipLaunchKernelGGL(segment_sum_kernel, dim3(cdiv(n, 4), cdiv(D, 64)), dim3(256), 0, st, skeys, svals, n, grad_rows, ldg, D,
-                     num_rows, padding_idx, accumulate, dtable);
+                     num_rows, padding_idx, accumulate, dtable, part);
   PV_LAUNCH_CHECK("segment_sum_kernel");
+  if (n > SEG_CH) {
+    hipLaunchKernelGGL(segment_combine_kernel, dim3((n - 1) / SEG_CH, cdiv(D, 64)), dim3(64), 0, st, skeys, n, D, num_rows,
+                       padding_idx, part, dtable);
+    PV_LAUNCH_CHECK("segment_combine_kernel");
+  }
   return PV_OK;
 }
 

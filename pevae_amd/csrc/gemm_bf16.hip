@@ -578,26 +578,56 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float2* __restr
 // live rows to the front; the GEMMs take the live count from device memory (GemmArgs::m_live / k_live), so the launch
 // geometry is static (graph-capturable) while the work follows the batch.
 // perm[new] = old row; live rows first in their original order, then the ignored rows; count[0] = live rows.
-__global__ __launch_bounds__(256) void vocab_compact_kernel(const int64_t* __restrict__ target, int T, int64_t ignore,
-                                                             int64_t* __restrict__ perm, int* __restrict__ count) {
-  __shared__ int cnt[256];
-  const int per = (T + 255) / 256, t0 = threadIdx.x * per, t1 = min(T, t0 + per);
-  int live = 0;
-  for (int t = t0; t < t1; ++t) live += target[t] != ignore;
-  cnt[threadIdx.x] = live;
+__global__ __launch_bounds__(1024) void vocab_compact_kernel(const int64_t* __restrict__ target, int T, int64_t ignore,
+                                                              int64_t* __restrict__ perm, int* __restrict__ count) {
+  // one workgroup of 16 waves; position t = base + it*1024 + tid, so every load is coalesced and a wave's 64 flags are
+  // one ballot.  Live rank = live tokens before the chunk + (iteration, wave) prefix + popcount of the lower lanes.
+  __shared__ int red[16];
+  __shared__ int wc[256 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int c = 0;
+  for (int t = tid; t < T; t += 1024) c += target[t] != ignore;
+  for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0) red[w] = c;
   __syncthreads();
-  int before = 0, total = 0;
-  for (int i = 0; i < 256; ++i) {                 // 256 adds per thread: trivial next to the loads
-    const int c = cnt[i];
-    if (i < (int)threadIdx.x) before += c;
-    total += c;
+  int total = 0;
+  for (int i = 0; i < 16; ++i) total += red[i];
+  int live_before = 0;
+  for (int base = 0; base < T; base += 16 * 1024) {
+    unsigned long long m[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int t = base + it * 1024 + tid;
+      m[it] = __ballot(t < T && target[t] != ignore);
+      if (lane == 0) wc[it * 16 + w] = __builtin_popcountll(m[it]);
+    }
+    __syncthreads();
+    if (w == 0) {                                   // exclusive scan of the 256 (iteration, wave) counts
+      int v[4], sum = 0;
+      for (int j = 0; j < 4; ++j) { v[j] = wc[lane * 4 + j]; sum += v[j]; }
+      int incl = sum;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      int run = incl - sum;
+      for (int j = 0; j < 4; ++j) { wc[lane * 4 + j] = run; run += v[j]; }
+      if (lane == 63) wc[256] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int t = base + it * 1024 + tid;
+      if (t < T) {
+        const int rank = live_before + wc[it * 16 + w] + __builtin_popcountll(m[it] & ((1ull << lane) - 1));
+        if ((m[it] >> lane) & 1) perm[rank] = t;
+        else perm[total + (t - rank)] = t;          // dead tokens follow the live ones, in order too
+      }
+    }
+    live_before += wc[256];
+    __syncthreads();
   }
-  int pl = before, pd = total + (t0 < T ? t0 : T) - before;
-  for (int t = t0; t < t1; ++t) {
-    if (target[t] != ignore) perm[pl++] = t;
-    else perm[pd++] = t;
-  }
-  if (threadIdx.x == 0) count[0] = total;
+  if (tid == 0) count[0] = total;
 }
 
 // h_c[new][:] = h[perm[new]][:] (bf16 rows, 16-byte chunks), target_c[new] = target[perm[new]]
@@ -640,17 +670,27 @@ int check_gemm(const void* A, const void* B, int M, int N, int K, int lda, int l
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long slab, int M,
                                                              int N, float* __restrict__ C, int ldc, int accumulate,
                                                              const int* __restrict__ m_live, int adaptive_slots) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (m_live) {
     const int nbm = (min(M, *m_live) + BM - 1) / BM;
     M = min(M, nbm * BM);
     splits = live_splits(splits, adaptive_slots, nbm * ((N + BN - 1) / BN));
   }
-  if (i >= (long)M * N) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[k * slab + i];
-  float* dst = C + (i / N) * ldc + i % N;
-  *dst = accumulate ? *dst + s : s;
+  const long total = (long)M * N;
+  if ((N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0) {       // 16-byte path: four columns per thread
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    f32x4 s = *(const f32x4*)(ws + i);
+    for (int k = 1; k < splits; ++k) s += *(const f32x4*)(ws + k * slab + i);
+    f32x4* dst = (f32x4*)(C + (i / N) * ldc + i % N);
+    *dst = accumulate ? *dst + s : s;
+    return;
+  }
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4, e = min(total, i + 4); i < e; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[k * slab + i];
+    float* dst = C + (i / N) * ldc + i % N;
+    *dst = accumulate ? *dst + s : s;
+  }
 }
 
 int persistent_grid() {
@@ -762,7 +802,7 @@ int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M
   rc = launch(g, e, st, "pv_gemm_bf16_nt_splitk");
   if (rc) return rc;
   const long n = (long)M * N;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (const float*)workspace,
                      splits, n, M, N, C, ldc, accumulate, m_live, slots);
   PV_LAUNCH_CHECK("splitk_reduce_kernel");
   return PV_OK;
@@ -770,7 +810,7 @@ int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M
 
 int pv_vocab_compact(const int64_t* target, int T, int64_t ignore_index, int64_t* perm, int* count, void* stream) {
   PV_REQUIRE(target && perm && count && T > 0, "pv_vocab_compact: bad argument");
-  hipLaunchKernelGGL(vocab_compact_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, target, T, ignore_index, perm, count);
+  hipLaunchKernelGGL(vocab_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, target, T, ignore_index, perm, count);
   PV_LAUNCH_CHECK("vocab_compact_kernel");
   return PV_OK;
 }

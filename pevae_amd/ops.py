@@ -591,7 +591,7 @@ class EmbeddingLookup(torch.autograd.Function):
         dev = dout.device
         sink = grad_sink(ctx.param, (rows, D))
         dw = sink if sink is not None else torch.empty((rows, D), dtype=torch.float32, device=dev)
-        nbytes = _lib.load().pv_embedding_bwd_ws_bytes(max(n, 1))
+        nbytes = _lib.load().pv_embedding_bwd_ws_bytes(max(n, 1), D)
         ws = workspace("emb_bwd", nbytes, torch.uint8, dev)
         g = dout.contiguous().view(-1, D)
         _lib.call("pv_embedding_bwd", _p(g), D, _p(ids_c), n, max(n, 1), max(n, 1), 0, 1, rows, D, pad,
@@ -1290,7 +1290,8 @@ class DlsLevel(torch.autograd.Function):
         ls = torch.empty((B, n), dtype=torch.float32, device=dev)
         out = torch.empty((B, n), dtype=torch.float32, device=dev)
         kl = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.call("pv_dls_level_fwd", _p(Q), _p(Pr), _p(a2), _p(eps), _p(lay), B, n, ew, cw, _p(ls), _p(out), _p(kl), _stream())
+        _lib.call("pv_dls_level_fwd", _p(Q), _p(Pr), _p(a2), _p(eps), _p(lay), B, n, ew, cw, _p(ls), _p(out), _p(kl),
+                  _p(workspace("dls_level_kl_part", 256, torch.float32, Q.device)), _stream())
         ctx.save_for_backward(Q, Pr, eps)
         ctx.w = (ew, cw)
         ctx.set_materialize_grads(False)

@@ -192,6 +192,44 @@ def test_embedding_gather_scatter_bit_exact(dev):
     assert e.shape == (0, 4, D)
 
 
+def test_embedding_scatter_long_segments(dev):
+    """Rows with >= 256 occurrences are summed in pieces (embedding.hip SEG_CH): the head piece up to the first multiple
+    of 256 that lies >= 256 past the segment head, then 256-position pieces, combined in position order.  Bit-exact
+    against that association in numpy, within fp32 rounding of the sequential sum, identical run to run."""
+    from pevae_amd import ops
+    g = torch.Generator().manual_seed(6)
+    rows, D, n, CH = 300, 100, 3000, 256
+    ids = torch.randint(1, rows, (n,), generator=g)
+    ids[torch.rand(n, generator=g) < 0.5] = 7               # ~1500 occurrences
+    ids[torch.rand(n, generator=g) < 0.12] = 250            # ~300: crosses one or two cuts
+    grad = torch.randn(n, D, generator=g)
+    tw = torch.zeros(rows, D, device=dev).requires_grad_()
+    ops.embedding(tw, ids.to(dev), 0).backward(grad.to(dev))
+    got = tw.grad.cpu().numpy().copy()
+    order = np.argsort(ids.numpy(), kind="stable")
+    keys, gf = ids.numpy()[order], grad.numpy()[order]
+    want = np.zeros((rows, D), dtype=np.float32)
+    i = 0
+    while i < n:
+        j = i
+        while j < n and keys[j] == keys[i]:
+            j += 1
+        cuts = [i] + [q for q in range(0, n, CH) if i + CH <= q < j] + [j]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            piece = np.zeros(D, dtype=np.float32)
+            for r in range(a, b):
+                piece += gf[r]
+            want[keys[i]] = piece if a == i else want[keys[i]] + piece
+        i = j
+    assert np.array_equal(got, want)
+    seq = np.zeros((rows, D), dtype=np.float64)
+    np.add.at(seq, ids.numpy(), grad.numpy().astype(np.float64))
+    np.testing.assert_allclose(got, seq, rtol=1e-5, atol=1e-4)
+    tw.grad = None
+    ops.embedding(tw, ids.to(dev), 0).backward(grad.to(dev))
+    assert np.array_equal(tw.grad.cpu().numpy(), got)
+
+
 def test_reparam_kl(dev):
     from pevae_amd import ops
     torch.manual_seed(6)
