@@ -19,7 +19,9 @@ if len(sys.argv) > 1:
                 ops.GRULayer.apply(x, h0, w_ih, w_hh, b, b, save)
         torch.cuda.synchronize()
         ts = sorted(a.elapsed_time(c) for a, c in ops.TIMERS["gru_fwd"][5:])
+        if os.environ.get("PV_GRU_SERIES"):
+            print("series", " ".join("%.0f" % (a.elapsed_time(c) * 1e3) for a, c in ops.TIMERS["gru_fwd"]))
         print("dbg=%s save=%d median %.1f us  min %.1f us" % (sys.argv[1], save, ts[len(ts) // 2] * 1e3, ts[0] * 1e3), flush=True)
 else:
-    for d in (0, 1, 1 + 2, 1 + 2 + 4, 1 + 2 + 4 + 8 + 16, 1 + 2 + 4 + 8 + 16 + 32, 127, 32, 2, 8, 4, 64, 1 + 16):
+    for d in ([int(v) for v in os.environ['PV_GRU_ONLY'].split(',')] if os.environ.get('PV_GRU_ONLY') else (0, 1, 1 + 2, 1 + 2 + 4, 1 + 2 + 4 + 8 + 16, 1 + 2 + 4 + 8 + 16 + 32, 127, 32, 2, 8, 4, 64, 1 + 16)):
         subprocess.run([sys.executable, __file__, str(d)], env=dict(os.environ, PV_GRU_DBG=str(d)))
