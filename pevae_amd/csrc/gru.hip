@@ -201,6 +201,14 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
   const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hseq, 0, a.hseq_bytes, 0x00020000);
   const bool single = a.NG <= a.G;                            // one row group per workgroup: state stays in registers
   float hp[4] = {0.f, 0.f, 0.f, 0.f}, cp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (single && active) {                                     // the state lives in registers: read slot 0 once, here
+    const int rb0 = g * RW + mt * 16 + q4 * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hp[j] = a.hall[((size_t)rb0 + j) * H + unit];
+      if constexpr (LSTM) cp[j] = a.call[((size_t)rb0 + j) * H + unit];
+    }
+  }
   __syncthreads();
 #ifdef PV_GRU_STAMPS
   unsigned stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -211,28 +219,30 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
     const int t = a.reverse ? a.L - 1 - step : step;
     for (int rg = g; rg < a.NG; rg += a.G) {
       const int row0 = rg * RW, rbase = row0 + mt * 16 + q4 * 4;
-      // (a) independent of h_{t-1}: this lane's input projections, 4 batch rows per 16-byte load
+      // (a) independent of h_{t-1}: this lane's input projections, 4 batch rows per 16-byte load.  The loads are only
+      //     issued here: xg is left undefined for waves that do not use it, because merging it with a default value
+      //     made the compiler wait for the loads at the merge (2.2 us per step, serial, on every workgroup).
       f32x4 xg[NGT];
-#pragma unroll
-      for (int gt = 0; gt < NGT; ++gt) xg[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (active && !(a.dbg & 64)) {
+      if (active) {
         const float* xp = a.xprojT + (size_t)unit * a.ldx + (size_t)t * a.Bpad + rbase;
 #pragma unroll
         for (int gt = 0; gt < NGT; ++gt) xg[gt] = *(const f32x4*)(xp + (size_t)gt * H * a.ldx);
-        if (step == 0 || !single) {
+        if (!single) {                                       // several row groups per workgroup: state in memory
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            hp[j] = single ? a.hall[((size_t)rbase + j) * H + unit]
-                           : (rbase + j < a.B ? a.hstate[(size_t)(rbase + j) * H + unit] : 0.f);
-            if constexpr (LSTM)
-              cp[j] = single ? a.call[((size_t)rbase + j) * H + unit]
-                             : (rbase + j < a.B ? a.cstate[(size_t)(rbase + j) * H + unit] : 0.f);
+            hp[j] = rbase + j < a.B ? a.hstate[(size_t)(rbase + j) * H + unit] : 0.f;
+            if constexpr (LSTM) cp[j] = rbase + j < a.B ? a.cstate[(size_t)(rbase + j) * H + unit] : 0.f;
           }
+          // wait here, inside the branch: otherwise the compiler waits for every load of the step where the two paths
+          // merge, on the common single-group path too
+          __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
         }
       }
       STAMP(0);
       // (b) wait for the group's h_{step-1}
-      if (step > 0 && tid == 256 && !(a.dbg & 1)) wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
+      if (step > 0 && w == 4 && !(a.dbg & 1)) {             // wave-uniform branch: only the poller wave enters
+        if (lane == 0) wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
+      }
       STAMP(1);
       __syncthreads();
       STAMP(2);
@@ -453,6 +463,7 @@ struct GruBwdArgs {
   u32* err;
   int L, B, H, K3, Bpad, NG, G, S, reverse, xmap;
   unsigned dg_bytes;
+  u32* stamps;            // diagnostic build only
 };
 
 // Backward through time.  Per step: rec = dgh[previously handled step] @ W_hh (K = 3H, split over the 4
@@ -497,7 +508,20 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   const bool single = a.NG <= a.G;
   float carry[4] = {0.f, 0.f, 0.f, 0.f};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float gx[4] = {0.f, 0.f, 0.f, 0.f};                    // dL/dh_n (and the LSTM's dL/dc_n in carry): enter at step 0
+  if (single) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int bclamp = min(g * ROWS + mt * 16 + q4 * 4 + j, a.B - 1);
+      if (a.dhn) gx[j] = a.dhn[(size_t)bclamp * H + unit];
+      if constexpr (LSTM) carry[j] = a.dcn ? a.dcn[(size_t)bclamp * H + unit] : 0.f;
+    }
+  }
   __syncthreads();
+#ifdef PV_GRU_STAMPS
+  unsigned stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_t = wall_clock64();
+#endif
 
   // steps run from the last processed time step back to the first; one extra pass (step == L)
   // only folds the recurrent term of the first step into dL/dh0.
@@ -506,10 +530,14 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     const int t = a.reverse ? a.L - 1 - ti : ti;         // time index of that step
     for (int rg = g; rg < a.NG; rg += a.G) {
       const int row0 = rg * ROWS, rbase = row0 + mt * 16 + q4 * 4;
-      // (a) independent of the exchange: saved gates / states / upstream gradients of this lane's 4 rows
+      // (a) independent of the exchange: saved gates / states / upstream gradients of this lane's 4 rows.  Everything is
+      //     loaded unconditionally from clamped (always valid) addresses and masked where it is used: loads under
+      //     data-dependent branches made the compiler wait for each one at the branch merge -- five serial round trips,
+      //     2.6 us per step.  (Rows up to Bpad exist in gsaveT / hall / call; dout has B rows only, hence the clamp.)
       float gr[4], gz[4], gn[4], ghn[4], ghp[4], gdo[4], gtc[4];   // LSTM: ghp = c_{t-1}, gtc = tanh(c_t)
-      if (active && step < a.L) {
-        const float* gs = a.gsaveT + ((size_t)t * 4 * H + unit) * a.Bpad + rbase;
+      {
+        const int tc = step < a.L ? t : (a.reverse ? a.L - 1 : 0), tic = step < a.L ? ti : 0;
+        const float* gs = a.gsaveT + ((size_t)tc * 4 * H + unit) * a.Bpad + rbase;
         const size_t gq = (size_t)H * a.Bpad;
         const float4 v0 = *(const float4*)gs, v1 = *(const float4*)(gs + gq), v2 = *(const float4*)(gs + 2 * gq),
                      v3 = *(const float4*)(gs + 3 * gq);
@@ -517,35 +545,44 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         gz[0] = v1.x; gz[1] = v1.y; gz[2] = v1.z; gz[3] = v1.w;
         gn[0] = v2.x; gn[1] = v2.y; gn[2] = v2.z; gn[3] = v2.w;
         ghn[0] = v3.x; ghn[1] = v3.y; ghn[2] = v3.z; ghn[3] = v3.w;
-      } else {
+        const float* dsrc = a.dout ? a.dout : a.hall;            // a readable dummy when there is no dL/d out
+        const long dsb = a.dout ? a.dout_sb : 0, dst_ = a.dout ? a.dout_st : 0;
+        const float dscale = a.dout ? 1.f : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gr[j] = gz[j] = gn[j] = ghn[j] = 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ghp[j] = gdo[j] = gtc[j] = 0.f;
-        const int brow = rbase + j;
-        if (active && brow < a.B && step < a.L) {
+        for (int j = 0; j < 4; ++j) {
+          const int brow = rbase + j, bclamp = min(brow, a.B - 1);
           if constexpr (LSTM) {
-            ghp[j] = a.call[((size_t)ti * a.Bpad + brow) * H + unit];
-            gtc[j] = fast_tanh(a.call[((size_t)(ti + 1) * a.Bpad + brow) * H + unit]);
+            ghp[j] = a.call[((size_t)tic * a.Bpad + brow) * H + unit];
+            gtc[j] = a.call[((size_t)(tic + 1) * a.Bpad + brow) * H + unit];    // tanh applied at use
           } else {
-            ghp[j] = a.hall[((size_t)ti * a.Bpad + brow) * H + unit];
+            ghp[j] = a.hall[((size_t)tic * a.Bpad + brow) * H + unit];
+            gtc[j] = 0.f;
           }
-          if (a.dout) gdo[j] = a.dout[brow * a.dout_sb + t * a.dout_st + unit];
+          gdo[j] = dsrc[bclamp * dsb + tc * dst_ + unit] * dscale;
+        }
+        if (!single) {                                           // several row groups per workgroup: state in memory
           if (step == 0) {
-            if (a.dhn) gdo[j] += a.dhn[(size_t)brow * H + unit];
-            if constexpr (LSTM) carry[j] = a.dcn ? a.dcn[(size_t)brow * H + unit] : 0.f;
-          } else if (!single) {
-            carry[j] = a.dcarry[(size_t)brow * H + unit];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int bclamp = min(rbase + j, a.B - 1);
+              gx[j] = a.dhn ? a.dhn[(size_t)bclamp * H + unit] : 0.f;
+              if constexpr (LSTM) carry[j] = a.dcn ? a.dcn[(size_t)bclamp * H + unit] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) carry[j] = a.dcarry[(size_t)min(rbase + j, a.B - 1) * H + unit];
           }
+          __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0) inside the branch (see the forward kernel)
         }
       }
       // (b) recurrent term from the previously handled step: dgh[prev] @ W_hh  (K = 3H)
       float rec[4] = {0.f, 0.f, 0.f, 0.f};
+      STAMP(0);
       if (step > 0) {
         if (tid == 0) wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
+        STAMP(1);
         __syncthreads();
+        STAMP(2);
         const int tprev = a.reverse ? a.L - 1 - (ti + 1) : ti + 1;
         f32x4 acc[2][UT];
 #pragma unroll
@@ -581,7 +618,9 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < UT; ++j) part[(w * NTILE + i * UT + j) * 64 + lane] = acc[i][j];
+        STAMP(3);
         __syncthreads();
+        STAMP(4);
         if (active) {
 #pragma unroll
           for (int ww = 0; ww < 4; ++ww) {
@@ -615,7 +654,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         const bool live = active && rbase + j < a.B;
         if constexpr (LSTM) {
           // saved slots: gr = i, gz = f, gn = g, ghn = o.  (dr, dz, dn, dnr) carry (di, df, dg, do) pre-activation
-          const float dh = rec[j] + gdo[j];
+          const float dh = rec[j] + gdo[j] + (step == 0 ? gx[j] : 0.f);
+          gtc[j] = fast_tanh(gtc[j]);
           const float dc = dh * ghn[j] * (1.f - gtc[j] * gtc[j]) + carry[j];
           dr[j] = dc * gn[j] * gr[j] * (1.f - gr[j]);
           dz[j] = dc * ghp[j] * gz[j] * (1.f - gz[j]);
@@ -623,7 +663,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
           dnr[j] = dh * gtc[j] * ghn[j] * (1.f - ghn[j]);
           carry[j] = dc * gz[j];
         } else {
-          const float dh = rec[j] + gdo[j] + (step > 0 ? carry[j] : 0.f);
+          const float dh = rec[j] + gdo[j] + (step > 0 ? carry[j] : gx[j]);
           dn[j] = dh * (1.f - gz[j]) * (1.f - gn[j] * gn[j]);
           dz[j] = dh * (ghp[j] - gn[j]) * gz[j] * (1.f - gz[j]);
           dr[j] = dn[j] * ghn[j] * gr[j] * (1.f - gr[j]);
@@ -652,6 +692,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         }
       }
       __syncthreads();
+      STAMP(5);
       // (d) publish dgh (write-through), drain, barrier, arrive; then the copies nobody waits for
       constexpr int NCH = ROWS * NGT * U / 8;                // 16-byte chunks per image
       for (int c = tid; c < NCH; c += 256) {
@@ -661,9 +702,11 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(v, grsrc, off, 0, AUX_SC1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(6);
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(a.counters + rg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("" ::: "memory");
+      STAMP(7);
       if constexpr (!LSTM) {
         for (int c = tid; c < NCH; c += 256) {
           const int row = c / (3 * U / 8), rem = c % (3 * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
@@ -676,8 +719,13 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         for (int j = 0; j < 4; ++j)
           if (active && rbase + j < a.B) a.dcarry[(size_t)(rbase + j) * H + unit] = carry[j];
       }
+      STAMP(8);
     }
   }
+#ifdef PV_GRU_STAMPS
+  if (tid == 0 && blockIdx.x < 16)
+    for (int i = 0; i < 10; ++i) a.stamps[blockIdx.x * 10 + i] = stamp_acc[i];
+#endif
   // bias-gradient partials: reduce this workgroup's rows in a fixed order
   {
     if (active) {
@@ -912,7 +960,7 @@ int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float*
   }
   GruBwdArgs a{dout, dout_sb, dout_st, dhn, gsaveT, hall, (const bf16_t*)whhT_bf16, (bf16_t*)dgi_bf16,
                (bf16_t*)dgh_bf16, ngt == 4 ? dc0 : dh0, call, dcn, dh0, dbias_part, counters, err, L, B, H, K3, Bpad,
-               NG, G, S, reverse, xmap, (unsigned)dg_bytes};
+               NG, G, S, reverse, xmap, (unsigned)dg_bytes, (u32*)sync + 64};
 #define PV_GRU_LAUNCH_B4(UTv, NKv, NGv)                                                            \
   do {                                                                                             \
     static size_t seen = 0;                                                                        \
