@@ -112,7 +112,7 @@ int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float*
                float* hn, void* sync, int max_wgs, void* stream);
 /* Backward through time.  whhT_bf16 [H][K3] = W_hh^T.  Emits dgi_bf16 / dgh_bf16 [L][Bpad][K3] (gate
  * gradients w.r.t. the input / hidden pre-activations; GEMM operands for dW_ih, dx, dW_hh), dh0 [B][H],
- * db_ih / db_hh [3H].  dbias_part: NG*4*H floats of scratch. */
+ * db_ih / db_hh [3H].  dbias_part: 2*NG*4*H floats of scratch. */
 int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsaveT,
                const float* hall, const void* whhT_bf16, int L, int B, int H, int reverse, void* dgi_bf16,
                void* dgh_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,

@@ -474,14 +474,16 @@ struct GruBwdArgs {
 // NGT = 4 (LSTM): one gate-gradient image (di, df, dg, do) serves both the exchange and the weight-gradient
 // GEMMs (dgi is not written), K = 4H, and the carried gradient is dL/dc while dL/dh arrives only through
 // the recurrent term.
-template <int UT, int NKS_C, int NGT>
+// MT: 16-row MFMA tiles per row group (2: 32-row groups, 1: 16-row groups -- twice the workgroups, each fetching half
+// the exchanged bytes per step; the step is bound by that fetch).
+template <int UT, int NKS_C, int NGT, int MT>
 __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
-  constexpr int U = UT * 16, NTILE = 2 * UT;
+  constexpr int U = UT * 16, RW = MT * 16, NTILE = MT * UT;
   constexpr bool LSTM = NGT == 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q4 = lane >> 4;
-  const int mt = w & 1, ut = w >> 1;
+  const int mt = MT == 2 ? (w & 1) : 0, ut = MT == 2 ? (w >> 1) : w;
   const bool active = ut < UT;
   int g, s;
   if (!group_slice(a.xmap, a.G, a.S, g, s)) return;
@@ -489,9 +491,9 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   const int K3 = NKS_C ? NKS_C * 32 : a.K3, nch = K3 / 8, mask = swz_mask_for(nch), NKS = K3 / 32, H = a.H;
   char* wl = smem;                                                   // [U][K3] bf16 swizzled (W_hh^T slice)
   f32x4* part = (f32x4*)(smem + (size_t)U * K3 * 2);                 // [4 waves][NTILE][64 lanes]
-  bf16_t* tgh = (bf16_t*)(part + 4 * NTILE * 64);                    // [ROWS][NGT][U] bf16: dr, dz, dn*r | di, df, dg, do
-  bf16_t* tgi = tgh + ROWS * NGT * U;                                // [ROWS][3][U] bf16: dr, dz, dn (GRU only)
-  float* bred = (float*)(tgi + (LSTM ? 0 : ROWS * NGT * U));         // [8][4][U] bias-grad reduction
+  bf16_t* tgh = (bf16_t*)(part + 4 * NTILE * 64);                    // [RW][NGT][U] bf16: dr, dz, dn*r | di, df, dg, do
+  bf16_t* tgi = tgh + RW * NGT * U;                                  // [RW][3][U] bf16: dr, dz, dn (GRU only)
+  float* bred = (float*)(tgi + (LSTM ? 0 : RW * NGT * U));           // [4*MT][4][U] bias-grad reduction
 
   for (int i = tid; i < U * nch; i += 256) {
     const int n = i / nch, ch = i % nch;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   if (single) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int bclamp = min(g * ROWS + mt * 16 + q4 * 4 + j, a.B - 1);
+      const int bclamp = min(g * RW + mt * 16 + q4 * 4 + j, a.B - 1);
       if (a.dhn) gx[j] = a.dhn[(size_t)bclamp * H + unit];
       if constexpr (LSTM) carry[j] = a.dcn ? a.dcn[(size_t)bclamp * H + unit] : 0.f;
     }
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     const int ti = a.L - 1 - step;                       // processing index whose gradients we form
     const int t = a.reverse ? a.L - 1 - ti : ti;         // time index of that step
     for (int rg = g; rg < a.NG; rg += a.G) {
-      const int row0 = rg * ROWS, rbase = row0 + mt * 16 + q4 * 4;
+      const int row0 = rg * RW, rbase = row0 + mt * 16 + q4 * 4;
       // (a) independent of the exchange: saved gates / states / upstream gradients of this lane's 4 rows.  Everything is
       //     loaded unconditionally from clamped (always valid) addresses and masked where it is used: loads under
       //     data-dependent branches made the compiler wait for each one at the branch merge -- five serial round trips,
@@ -584,19 +586,19 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         __syncthreads();
         STAMP(2);
         const int tprev = a.reverse ? a.L - 1 - (ti + 1) : ti + 1;
-        f32x4 acc[2][UT];
+        f32x4 acc[MT][UT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < UT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned abase = (unsigned)((((size_t)tprev * a.Bpad + row0 + c16) * K3 + q4 * 8) * 2);
         for (int ks0 = w; ks0 < NKS; ks0 += 48) {           // wave w takes k-steps w, w+4, ... (12 per pass)
-          u32x4 av[12][2];
+          u32x4 av[12][MT];
 #pragma unroll
           for (int kk = 0; kk < 12; ++kk)
             if (ks0 + kk * 4 < NKS) {
 #pragma unroll
-              for (int i = 0; i < 2; ++i)
+              for (int i = 0; i < MT; ++i)
                 av[kk][i] = __builtin_amdgcn_raw_buffer_load_b128(
                     grsrc, abase + (unsigned)(i * 16 * K3 * 2) + (ks0 + kk * 4) * 64, 0, AUX_SC1);
             }
@@ -608,14 +610,14 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
               for (int j = 0; j < UT; ++j) {
                 const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + boff[j] + (ks0 >> 2) * 256 + kk * 256));
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
                   acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[kk][i]), b, acc[i][j], 0, 0, 0);
               }
             }
           }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < UT; ++j) part[(w * NTILE + i * UT + j) * 64 + lane] = acc[i][j];
         STAMP(3);
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
       __syncthreads();
       STAMP(5);
       // (d) publish dgh (write-through), drain, barrier, arrive; then the copies nobody waits for
-      constexpr int NCH = ROWS * NGT * U / 8;                // 16-byte chunks per image
+      constexpr int NCH = RW * NGT * U / 8;                // 16-byte chunks per image
       for (int c = tid; c < NCH; c += 256) {
         const int row = c / (NGT * U / 8), rem = c % (NGT * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
         const u32x4 v = *(const u32x4*)(tgh + row * NGT * U + gt * U + ch * 8);
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     __syncthreads();
     for (int i = tid; i < 4 * U; i += 256) {
       float sacc = 0.f;
-      for (int r = 0; r < 8; ++r) sacc += bred[r * 4 * U + i];
+      for (int r = 0; r < 4 * MT; ++r) sacc += bred[r * 4 * U + i];
       a.dbias_part[((size_t)g * 4 + i / U) * H + u0 + i % U] = sacc;
     }
   }
@@ -938,13 +940,19 @@ int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float*
   auto lds_need = [&](int ut) {
     const size_t u = (size_t)ut * 16;
     return u * K3 * 2 + (size_t)4 * 2 * ut * 64 * 16 + (ngt == 4 ? 1 : 2) * (size_t)ROWS * ngt * u * 2 + (size_t)8 * 4 * u * 4;
-  };
+  };                                                     // sized for 32-row groups; 16-row groups need less
   int UT = (H % 32 == 0) ? 2 : 1;
   if (UT == 2 && lds_need(2) > 160 * 1024) UT = 1;
   const int U = UT * 16, S = H / U;
   const int cap = max_wgs > 0 ? max_wgs : cu_count();
   PV_REQUIRE(S <= cap, "pv_gru_bwd: %d unit slices exceed the %d co-resident workgroups available", S, cap);
-  const int G = NG < cap / S ? NG : cap / S;
+  // Group shape: 16-row groups when all of them fit the chip at one workgroup per CU (B=256, H=512: 16 x 16 = 256
+  // workgroups instead of 8 x 16), because a step is bound by fetching the group's exchanged gate gradients
+  // (rows x 3H bf16 per workgroup) and that halves; 32-row groups otherwise.  PV_GRU_BWD_MT=2 forces the latter.
+  int MT = (Bpad / 16) * S <= cap ? 1 : 2;
+  if (const char* e = getenv("PV_GRU_BWD_MT")) MT = atoi(e) == 1 ? MT : 2;
+  const int NGk = Bpad / (MT * 16);
+  const int G = NGk < cap / S ? NGk : cap / S;
   const int xmap = xcd_map(G, S, cap), grid = xmap ? 8 * cdiv(G, 8) * S : G * S;
   const size_t smem = lds_need(UT);
   PV_REQUIRE(smem <= 160 * 1024, "pv_gru_bwd: LDS need %zu exceeds 160 KiB", smem);
@@ -953,19 +961,24 @@ int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float*
   PV_HIP(hipMemsetAsync(sync, 0, pv_gru_sync_bytes(B), st));
   PV_HIP(hipMemsetAsync(dh0, 0, (size_t)B * H * sizeof(float), st));
   if (ngt == 4) PV_HIP(hipMemsetAsync(dc0, 0, (size_t)B * H * sizeof(float), st));
-  PV_HIP(hipMemsetAsync(dbias_part, 0, (size_t)NG * 4 * H * sizeof(float), st));
+  PV_HIP(hipMemsetAsync(dbias_part, 0, (size_t)2 * NG * 4 * H * sizeof(float), st));
   if (K3 != ngt * H || Bpad != B) {
     if (dgi_bf16) PV_HIP(hipMemsetAsync(dgi_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
     PV_HIP(hipMemsetAsync(dgh_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
   }
   GruBwdArgs a{dout, dout_sb, dout_st, dhn, gsaveT, hall, (const bf16_t*)whhT_bf16, (bf16_t*)dgi_bf16,
                (bf16_t*)dgh_bf16, ngt == 4 ? dc0 : dh0, call, dcn, dh0, dbias_part, counters, err, L, B, H, K3, Bpad,
-               NG, G, S, reverse, xmap, (unsigned)dg_bytes, (u32*)sync + 64};
-#define PV_GRU_LAUNCH_B4(UTv, NKv, NGv)                                                            \
-  do {                                                                                             \
-    static size_t seen = 0;                                                                        \
-    if ((rc = ensure_lds(gru_bwd_kernel<UTv, NKv, NGv>, smem, &seen))) return rc;                  \
-    hipLaunchKernelGGL((gru_bwd_kernel<UTv, NKv, NGv>), dim3(grid), dim3(256), smem, st, a);      \
+               NGk, G, S, reverse, xmap, (unsigned)dg_bytes, (u32*)sync + 64};
+#define PV_GRU_LAUNCH_B5(UTv, NKv, NGv, MTv)                                                            \
+  do {                                                                                                  \
+    static size_t seen = 0;                                                                             \
+    if ((rc = ensure_lds(gru_bwd_kernel<UTv, NKv, NGv, MTv>, smem, &seen))) return rc;                  \
+    hipLaunchKernelGGL((gru_bwd_kernel<UTv, NKv, NGv, MTv>), dim3(grid), dim3(256), smem, st, a);       \
+  } while (0)
+#define PV_GRU_LAUNCH_B4(UTv, NKv, NGv)                     \
+  do {                                                      \
+    if (MT == 1) PV_GRU_LAUNCH_B5(UTv, NKv, NGv, 1);        \
+    else PV_GRU_LAUNCH_B5(UTv, NKv, NGv, 2);                \
   } while (0)
 #define PV_GRU_LAUNCH_B(UTv, NKv) PV_GRU_LAUNCH_B4(UTv, NKv, 3)
   if (ngt == 4) {
@@ -978,6 +991,7 @@ int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float*
   else PV_GRU_LAUNCH_B(1, 0);
 #undef PV_GRU_LAUNCH_B
 #undef PV_GRU_LAUNCH_B4
+#undef PV_GRU_LAUNCH_B5
   PV_LAUNCH_CHECK("gru_bwd_kernel");
   hipLaunchKernelGGL(gru_bias_reduce_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, dbias_part, G, H, ngt == 4 ? 1 : 0,
                      db_ih, db_hh);

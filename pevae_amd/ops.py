@@ -450,7 +450,7 @@ class GRULayer(torch.autograd.Function):
         dgi = torch.empty((L * Bpad, K3), dtype=BF16, device=dev)
         dgh = torch.empty((L * Bpad, K3), dtype=BF16, device=dev)
         dh0 = torch.empty((B, H), dtype=torch.float32, device=dev)
-        dbp = workspace("gru_dbias_part", NG * 4 * H, torch.float32, dev)
+        dbp = workspace("gru_dbias_part", 2 * NG * 4 * H, torch.float32, dev)
         db_ih = torch.empty(3 * H, dtype=torch.float32, device=dev)
         db_hh = torch.empty(3 * H, dtype=torch.float32, device=dev)
         sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
@@ -530,7 +530,7 @@ class LSTMLayer(torch.autograd.Function):
         dg = torch.empty((L * Bpad, K4), dtype=BF16, device=dev)
         dh0 = torch.empty((B, H), dtype=torch.float32, device=dev)
         dc0 = torch.empty((B, H), dtype=torch.float32, device=dev)
-        dbp = workspace("gru_dbias_part", NG * 4 * H, torch.float32, dev)
+        dbp = workspace("gru_dbias_part", 2 * NG * 4 * H, torch.float32, dev)
         db_ih = torch.empty(4 * H, dtype=torch.float32, device=dev)
         db_hh = torch.empty(4 * H, dtype=torch.float32, device=dev)
         sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
