@@ -12,33 +12,27 @@ import os
 import statistics
 import sys
 
-T, V, H = 12800, 20004, 512
-
-
-def classify(name, grid):
-    if "EpiSoftmax" in name:
-        return "vocab_fwd"
-    if "EpiProb" in name:
-        return "vocab_bwd_prob"
-    if "EpiStore" in name:
-        tiles = grid // 256
-        if tiles == (T // 128) * (H // 128):
-            return "vocab_dH"
-        vt = -(-V // 128) * (H // 128)
-        if tiles % vt == 0 and tiles // vt <= 8:
-            return "vocab_dW"
-    if "splitk_reduce" in name and grid == -(-(V * H) // 256) * 256:
-        return "vocab_dW_reduce"
-    return None
-
-
 def collect(d, counter):
+    """Kernels of the vocabulary group are recognised by launch order (the persistent tile walk gives every large GEMM
+    the same grid): EpiSoftmax = forward; after each EpiProb the next two EpiStore launches are dH and dW and the next two
+    splitk_reduce launches their slab reductions."""
     f = sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     vals = {}
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
-            continue
-        k = classify(r["Kernel_Name"], int(r["Grid_Size"]))
+    stores, reduces = [], []
+    for r in rows:
+        name = r["Kernel_Name"]
+        k = None
+        if "EpiSoftmax" in name:
+            k = "vocab_fwd"
+        elif "EpiProb" in name:
+            k = "vocab_bwd_prob"
+            stores, reduces = ["vocab_dH", "vocab_dW"], ["vocab_dH_reduce", "vocab_dW_reduce"]
+        elif "EpiStore" in name and stores:
+            k = stores.pop(0)
+        elif "splitk_reduce" in name and reduces:
+            k = reduces.pop(0)
         if k:
             vals.setdefault(k, []).append(float(r["Counter_Value"]))
     return {k: statistics.median(v) for k, v in vals.items()}, f
