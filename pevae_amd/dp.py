@@ -36,20 +36,81 @@ def bucket_bounds(n, bucket_elems):
     return [(s, min(s + bucket_elems, n)) for s in range(0, n, bucket_elems)]
 
 
+def pack_sparse_rows(table_grad, ids):
+    """What one rank contributes for a table whose gradient is non-zero only in the rows it looked up: (ids [n],
+    rows [n, D]) where every distinct id carries its (already locally summed) gradient row once -- later
+    occurrences of the same id carry zeros, so the merge may simply add all of them."""
+    ids = ids.reshape(-1)
+    n = ids.numel()
+    pos = torch.arange(n, device=ids.device)
+    first = torch.full((table_grad.shape[0],), n, dtype=torch.long, device=ids.device)
+    first.scatter_reduce_(0, ids, pos, reduce="amin")
+    keep = (first.index_select(0, ids) == pos).to(table_grad.dtype).unsqueeze(1)
+    return ids, table_grad.index_select(0, ids) * keep
+
+
+def merge_sparse_rows(table_grad, local_ids, ids_all, rows_all):
+    """table_grad <- sum over ranks, given every rank's packed contribution (this rank's included): the locally touched
+    rows are cleared and all contributions added in a fixed order, so every rank ends with the same bits.  On the GPU
+    the add is the library's sorted segmented sum (pv_embedding_bwd, no atomics); CPU tensors (gloo rehearsal of the
+    exchange logic) use index_add_, which is sequential there."""
+    table_grad.index_fill_(0, local_ids.reshape(-1), 0.0)
+    ids_all, rows_all = ids_all.reshape(-1).contiguous(), rows_all.reshape(-1, table_grad.shape[1]).contiguous()
+    if table_grad.is_cuda:
+        from . import _lib, ops
+        n, (rows, D) = ids_all.numel(), table_grad.shape
+        nbytes = _lib.load().pv_embedding_bwd_ws_bytes(n, D)
+        ws = ops.workspace("dp_sparse_merge", nbytes, torch.uint8, table_grad.device)
+        _lib.call("pv_embedding_bwd", ops._p(rows_all), D, ops._p(ids_all), n, n, n, 0, 1, rows, D, -1, 1,
+                  ops._p(table_grad), ops._p(ws), nbytes, ops._stream())
+    else:
+        table_grad.index_add_(0, ids_all, rows_all)
+    return table_grad
+
+
 class FlatGradReducer(object):
-    """Averages a flat fp32 gradient buffer across ranks in fixed-size buckets (async, then one wait)."""
+    """Averages a flat fp32 gradient buffer across ranks: fixed-size buckets of all-reduce (async, then one wait) for
+    the dense part, and for `sparse_tables` -- [(offset, rows, dim)] ranges of embedding tables whose local gradient is
+    non-zero only in the rows looked up this step (user / item tables: 256 of 30000 / 20000 rows) -- one all-gather of
+    (ids, rows) per step instead of all-reducing the whole table (0.26 MB instead of 2 x 25 MB per rank at
+    the Yelp shape).  reduce(ids) takes the looked-up ids of each sparse table, in the same order."""
 
-    def __init__(self, flat_grad, world_size, bucket_bytes=16 << 20, group=None):
+    def __init__(self, flat_grad, world_size, bucket_bytes=16 << 20, group=None, sparse_tables=()):
         self.flat, self.world, self.group = flat_grad, world_size, group
-        self.bounds = bucket_bounds(flat_grad.numel(), max(1, bucket_bytes // 4))
+        self.tables = sorted(tuple(t) for t in sparse_tables)
+        be = max(1, bucket_bytes // 4)
+        self.bounds, at = [], 0
+        for off, rows, dim in self.tables + [(flat_grad.numel(), 0, 0)]:       # dense stretches between the tables
+            if off < at:
+                raise ValueError("FlatGradReducer: sparse tables overlap")
+            self.bounds += [(at + s, at + e) for s, e in bucket_bounds(off - at, be)]
+            at = off + rows * dim
+        if at > flat_grad.numel():
+            raise ValueError("FlatGradReducer: sparse table beyond the buffer")
 
-    def reduce(self):
+    def table_view(self, i):
+        off, rows, dim = self.tables[i]
+        return self.flat[off:off + rows * dim].view(rows, dim)
+
+    def reduce(self, sparse_ids=()):
         if self.world <= 1:
             return
+        if len(sparse_ids) != len(self.tables):
+            raise ValueError("FlatGradReducer.reduce: %d sparse tables need %d id tensors" % (len(self.tables), len(sparse_ids)))
         works = [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                  for s, e in self.bounds]
+        packed = [pack_sparse_rows(self.table_view(i), ids) for i, ids in enumerate(sparse_ids)]
+        gathered = []
+        for ids, rows in packed:                         # every rank looks up the same number of ids (its batch)
+            ids_all = torch.empty(self.world * ids.shape[0], dtype=ids.dtype, device=ids.device)
+            rows_all = torch.empty((self.world * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
+            works.append(dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=self.group, async_op=True))
+            works.append(dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=self.group, async_op=True))
+            gathered.append((ids_all, rows_all))
         for w in works:
             w.wait()
+        for i, ((ids, _), (ids_all, rows_all)) in enumerate(zip(packed, gathered)):
+            merge_sparse_rows(self.table_view(i), ids, ids_all, rows_all)
         self.flat.mul_(1.0 / self.world)
 
 

@@ -41,6 +41,13 @@ class FlatAdam(object):
         self.offsets = offs
         self.state = torch.zeros(_lib.load().pv_optim_state_bytes(), dtype=torch.uint8, device=dev)
 
+    def table_range(self, param):
+        """(offset, rows, dim) of a 2-D parameter inside the flat buffers (dp.FlatGradReducer sparse_tables)."""
+        for p, o in zip(self.params, self.offsets):
+            if p is param:
+                return (o, p.shape[0], p.shape[1])
+        raise KeyError("FlatAdam.table_range: not one of this optimizer's parameters")
+
     def zero_grad(self):
         self.flat_g.zero_()
         for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-attach the view

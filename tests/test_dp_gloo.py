@@ -49,3 +49,37 @@ def test_bucket_bounds_cover_exactly():
         bounds = bucket_bounds(n, b)
         assert [s for s, _ in bounds] == list(range(0, n, b))
         assert sum(e - s for s, e in bounds) == n
+
+
+def _sparse_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from pevae_amd import dp
+    dp.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(200 + rank)
+    # layout: dense 37 | table A 50 x 8 | dense 1001 | table B 20 x 8 | dense 5
+    offA, offB, n = 37, 37 + 400 + 1001, 37 + 400 + 1001 + 160 + 5
+    flat = torch.randn(n, generator=g)
+    ids = [torch.randint(0, 50, (12,), generator=g), torch.randint(0, 20, (12,), generator=g)]
+    ids[0][3] = ids[0][7] = ids[0][0]                      # duplicates inside the local batch
+    for off, rows, idv in ((offA, 50, ids[0]), (offB, 20, ids[1])):
+        t = flat[off:off + rows * 8].view(rows, 8)
+        mask = torch.zeros(rows, dtype=torch.bool)
+        mask[idv] = True
+        t[~mask] = 0.0                                     # an embedding table's gradient: looked-up rows only
+    dense_copy = flat.clone()
+    red = dp.FlatGradReducer(flat, world, bucket_bytes=1 << 10, sparse_tables=[(offB, 20, 8), (offA, 50, 8)])
+    red.reduce(ids)                                        # ids in table (offset) order: A, B
+    torch.save((flat, dense_copy), os.path.join(out, "s%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_sparse_table_exchange_matches_dense_average(tmp_path):
+    """User / item tables exchanged as (ids, rows) all-gathers give what a dense all-reduce of the table gives."""
+    port = _free_port()
+    mp.spawn(_sparse_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "s%d.pt" % r), weights_only=True) for r in range(2)]
+    want = (outs[0][1] + outs[1][1]) / 2
+    for flat, _ in outs:
+        torch.testing.assert_close(flat, want, rtol=1e-6, atol=1e-6)
+    assert torch.equal(outs[0][0], outs[1][0])             # bit-identical replicas
