@@ -1,0 +1,187 @@
+"""Training / validation loop of the DLS_VAE step: the control flow of main_pretrain.train / validate
+(models/main_pretrain.py:148-399) around the HIP step.
+
+Kept from the reference: the epoch / batch iteration over a feed with epoch_init / next_batch, TEACH_FORCE before
+`teach_force_bound` evaluations and GEN after (:200-203), `model.backward` on the selected loss (:205), global-norm clip
+and the two skip rules (:207-225; evaluated on the device inside FlatAdam, same arithmetic), the freeze phase (:227-266:
+reload the best checkpoint, freeze embedding / encoder / decoder / init connector, fresh optimizer), evaluation every
+`ckpt_step` batches with plateau decay `lr *= lr_decay_rate` when the validation loss did not improve by 1 % (:343-348),
+patience bookkeeping and best-checkpoint save (:354-366), LossManager's report format (:21-73).
+Changed: LossManager keeps the per-batch losses on the device and reads them back once per report instead of one
+`.item()` (a host sync) per loss per batch; TensorBoard, generation previews and the text metrics (:264-265, :319-338,
+:401-1286) are out of scope."""
+import logging
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from .enc2dec.decoders import GEN, TEACH_FORCE
+from .optim import FlatAdam
+
+logger = logging.getLogger("pevae_amd.engine")
+
+
+class LossManager(object):
+    """main_pretrain.py:21-73 with device-side accumulation: add_loss appends 0-d device tensors; the averages are
+    formed (one stacked read-back per key) only when a report asks for them."""
+
+    def __init__(self):
+        self.losses = defaultdict(list)
+        self.backward_losses = []
+
+    def add_loss(self, loss):
+        for key, val in loss.items():
+            if val is not None and type(val) is not bool and type(val) is not int:
+                self.losses[key].append(val.detach() if torch.is_tensor(val) else torch.tensor(float(val)))
+
+    def add_backward_loss(self, loss):
+        self.backward_losses.append(loss.detach())
+
+    def clear(self):
+        self.losses = defaultdict(list)
+        self.backward_losses = []
+
+    def _avg(self, vals, window):
+        vals = vals if window is None else vals[-window:]
+        return float(torch.stack([v.reshape(()).float() for v in vals]).mean().item())
+
+    def return_dict(self, window=None):
+        ret = {}
+        for key, vals in self.losses.items():
+            if not vals:
+                continue
+            avg = self._avg(vals, window)
+            ret[key] = avg
+            if "nll" in key and "PPL" not in self.losses:
+                ret[key.split("nll")[0] + "PPL"] = float(np.exp(avg))
+        return ret
+
+    def pprint(self, name, window=None, prefix=None):
+        parts = []
+        for key, vals in self.losses.items():
+            if not vals:
+                continue
+            avg = self._avg(vals, window)
+            parts.append("{} {:.3f}".format(key, avg))
+            if "nll" in key and "PPL" not in self.losses:
+                parts.append("PPL {:.3f}".format(np.exp(avg)))
+        body = "{} {}".format(name, " ".join(parts))
+        return "{}: {}".format(prefix, body) if prefix else body
+
+    def avg_loss(self):
+        return self._avg(self.losses["vae_nll"], None)
+
+
+def adjust_learning_rate(optimizer, last_lr, decay_rate=0.5):           # main_pretrain.py:75-80
+    lr = last_lr * decay_rate
+    optimizer.lr = optimizer.lr * decay_rate
+    return lr
+
+
+def validate(model, valid_feed, config, batch_cnt=None):                # main_pretrain.py:373-399
+    model.eval()
+    with torch.no_grad():
+        valid_feed.epoch_init(config, shuffle=True, verbose=True)
+        losses = LossManager()
+        while True:
+            batch = valid_feed.next_batch()
+            if batch is None:
+                break
+            losses.add_loss(model(batch, mode=TEACH_FORCE))
+        valid_loss = losses.avg_loss()
+        logger.info(losses.pprint(valid_feed.name))
+        logger.info("Total valid loss {}".format(valid_loss))
+        res = losses.return_dict()
+    return valid_loss, res
+
+
+FROZEN_IN_PHASE_2 = ("x_embedding", "x_encoder", "x_decoder", "x_init_connector")    # main_pretrain.py:238-247
+
+
+def make_optimizer(model, config):
+    return FlatAdam([p for p in model.parameters() if p.requires_grad], lr=config.init_lr, max_norm=config.grad_clip,
+                    warmup_steps=getattr(config, "warmup_steps", 0))
+
+
+def train(model, train_feed, valid_feed, config, max_evals=None, checkpoint=None):
+    """Runs until the reference's stop rule (done_epoch > 100, :184; five evaluations after the freeze phase add 100,
+    :333-334) or `max_evals` evaluations.  Returns the history of (batch_cnt, valid_loss, lr) per evaluation.
+    config fields used (the reference's names): init_lr, grad_clip, batch_size, teach_force_bound, freeze_step,
+    ckpt_step, print_step, lr_decay_rate, improve_threshold, patient_increase, exp_name."""
+    patience = 2
+    valid_loss_threshold = np.inf
+    best_valid_loss = np.inf
+    learning_rate = config.init_lr
+    batch_cnt = 0
+    optimizer = make_optimizer(model, config)
+    best_model_name = checkpoint or os.path.join("./runs/", "model_" + getattr(config, "exp_name", "pevae") + ".pt")
+    os.makedirs(os.path.dirname(os.path.abspath(best_model_name)), exist_ok=True)
+    done_epoch, final_epoch, evals = 0, 0, 0
+    history = []
+    train_loss = LossManager()
+    model.train()
+    model.restarted = getattr(model, "restarted", False)
+    freeze_step = getattr(config, "freeze_step", None)
+    logger.info("**** Training Begins ****")
+    while done_epoch <= 100 and (max_evals is None or evals < max_evals):
+        train_feed.epoch_init(config, shuffle=True)
+        while max_evals is None or evals < max_evals:
+            batch = train_feed.next_batch()
+            if batch is None:
+                break
+            optimizer.zero_grad()
+            model.steps = batch_cnt
+            mode = TEACH_FORCE if done_epoch < config.teach_force_bound else GEN
+            loss = model(batch, mode=mode)
+            model.backward(batch_cnt, loss, step=batch_cnt)
+            if freeze_step is not None and batch_cnt >= freeze_step and not model.restarted:
+                # :227-266 second phase: best weights back, sentence side frozen, fresh optimizer and counters
+                logger.info("Switch to another train!")
+                best_valid_loss = np.inf
+                if os.path.exists(best_model_name):
+                    model.load_state_dict(torch.load(best_model_name, weights_only=True), strict=False)
+                    logger.info("Model {}: Load Done!".format(best_model_name))
+                model.restarted = True
+                for name in FROZEN_IN_PHASE_2:
+                    mod = getattr(model, name, None)
+                    if mod is not None:
+                        for p in mod.parameters():
+                            p.requires_grad = False
+                            p.grad = None
+                optimizer = make_optimizer(model, config)
+                learning_rate = config.init_lr
+                batch_cnt = 0
+                continue
+            optimizer.step()                       # clip, skip rules and Adam on the device (:207-225, :268-269)
+            train_loss.add_loss(loss)
+            batch_cnt += 1
+            if batch_cnt % config.print_step == 0:
+                logger.info(train_loss.pprint("Train", window=config.print_step,
+                                              prefix="{}/{}".format(batch_cnt % (config.ckpt_step + 1), config.ckpt_step)))
+            if batch_cnt % config.ckpt_step == 0:
+                optimizer.zero_grad()
+                logger.info("\n=== Evaluating Model ===")
+                logger.info(train_loss.pprint("Train"))
+                done_epoch += 1
+                evals += 1
+                valid_loss, _ = validate(model, valid_feed, config, batch_cnt)
+                if model.restarted:
+                    final_epoch += 1
+                    if final_epoch >= 5:
+                        done_epoch += 100
+                if learning_rate > 1e-6 and valid_loss > best_valid_loss * 0.99:             # :343-348
+                    learning_rate = adjust_learning_rate(optimizer, learning_rate, config.lr_decay_rate)
+                    logger.info("Adjust learning rete to {}".format(learning_rate))
+                if valid_loss <= valid_loss_threshold * config.improve_threshold:             # :354-366
+                    patience = max(patience, done_epoch * config.patient_increase)
+                    valid_loss_threshold = valid_loss
+                    if not model.restarted:
+                        torch.save(model.state_dict(), best_model_name)
+                    best_valid_loss = valid_loss
+                history.append((batch_cnt, valid_loss, learning_rate))
+                model.train()
+                train_loss.clear()
+                logger.info("\n**** Epoch {} ****".format(done_epoch))
+    return history
