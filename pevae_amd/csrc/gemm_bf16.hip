@@ -59,15 +59,20 @@ __device__ __forceinline__ void tile_of(int id, int nbm, int nbn, int& pm, int& 
   pn = (id % width) / gsz;
 }
 
-template <class Epi>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi epi) {
+// WM = 64-row waves per tile column: 2 -> the 128x128 tile, 4 waves, 2 LDS stages, 2 workgroups per CU;
+//                                   4 -> a 256x128 tile, 8 waves, 3 LDS stages (144 KiB), 1 workgroup per CU: 85 instead of
+//                                        64 flop per byte staged and two K-tiles in flight, for the K = 512 kernels.
+// Every wave owns a 64x64 sub-tile either way, so the epilogues are the same.
+template <class Epi, int WM>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_nt_kernel(GemmArgs g, Epi epi) {
+  constexpr int BMT = WM * 64, NW = WM * 2, NST = WM == 2 ? 2 : 3, PB = 16 / NW, STAGE = (BMT + BN) * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int c16 = lane & 15, q4 = lane >> 4;
   // rows at and past *m_live carry ignored tokens: their tiles are not walked at all
   const int m_rows = g.m_live ? min(g.M, *g.m_live) : g.M;
-  const int nbm = (m_rows + BM - 1) / BM, nbn = (g.N + BN - 1) / BN, ntiles = nbm * nbn;
+  const int nbm = (m_rows + BMT - 1) / BMT, nbn = (g.N + BN - 1) / BN, ntiles = nbm * nbn;
   const int splits = live_splits(g.splits, g.adaptive_slots, ntiles);
   const int nitems = ntiles * splits;               // work items: (split, tile), split-major
   const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi ep
   for (int i = 0; i < 4; ++i) {
     const int ra = wm * 64 + i * 16 + c16, rb = wn * 64 + i * 16 + c16;
     offA[i] = ra * 128;
-    offB[i] = BM * BK * 2 + rb * 128;
+    offB[i] = BMT * BK * 2 + rb * 128;
     swz[i] = (c16 >> 1) & 7;   // (row>>1)&7 : rows are 16-aligned + c16, so only c16 matters
   }
   const int nk_all = g.k_live ? min(g.K / BK, (*g.k_live + BK - 1) / BK) : g.K / BK;
@@ -91,30 +96,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi ep
   const int kt0 = split * per_split, nk = min(nk_all, kt0 + per_split);   // an empty range stores zeros
   int pm, pn;
   tile_of(item - split * ntiles, nbm, nbn, pm, pn);
-  const int m0 = pm * BM, n0 = pn * BN;
+  const int m0 = pm * BMT, n0 = pn * BN;
 
   // --- per-lane source pointers for the 4+4 LDS-DMA pieces this wave issues per K-tile ----------
   const bf16_t* srcA[4];
-  const bf16_t* srcB[4];
+  const bf16_t* srcB[PB];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (w * 4 + i) * 8 + (lane >> 3);          // tile row this lane fills
     const int c = (lane & 7) ^ ((r >> 1) & 7);            // logical 16-B chunk stored at phys lane&7
-    const int ra = min(m0 + r, g.M - 1), rb = min(n0 + r, g.N - 1);
-    srcA[i] = g.A + (size_t)ra * g.lda + c * 8;
-    srcB[i] = g.B + (size_t)rb * g.ldb + c * 8;
+    srcA[i] = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int r = (w * PB + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    srcB[i] = g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb + c * 8;
   }
   auto stage = [&](int s, int kt) {
-    char* base = smem + s * STAGE_BYTES;
+    char* base = smem + s * STAGE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + kt * BK),
                                        (lptr_t)(base + (w * 4 + i) * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PB; ++i) {
       __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + kt * BK),
-                                       (lptr_t)(base + BM * BK * 2 + (w * 4 + i) * 1024), 16, 0, 0);
+                                       (lptr_t)(base + BMT * BK * 2 + (w * PB + i) * 1024), 16, 0, 0);
     }
   };
 
@@ -127,13 +136,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g, Epi ep
   // what the epilogue reads from global memory (bias, targets, row statistics) is requested now, a whole main loop
   // ahead of its use: at K = 512 a tile's main loop is ~4 us and an exposed load round trip in the epilogue ~1-2 us
   const typename Epi::Pre pre = epi.prefetch(m0 + wm * 64, n0 + wn * 64, lane);
-  if (kt0 < nk) stage(kt0 & 1, kt0);
+  // NST-deep ring, NST-1 K-tiles requested ahead.  vmcnt retires in issue order, so "at most the 4 + PB LDS-DMA
+  // instructions of the younger stage outstanding" means stage kt has landed.
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (kt0 + p < nk) stage((kt0 + p) % NST, kt0 + p);
   for (int kt = kt0; kt < nk; ++kt) {
-    const int s = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int s = kt % NST;
+    if (NST == 3 && kt + 1 < nk) {
+      if constexpr (PB == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    if (kt + 1 < nk) stage(s ^ 1, kt + 1);
-    const char* base = smem + s * STAGE_BYTES;
+    if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, kt + NST - 1);   // the slot every wave finished reading before this barrier
+    const char* base = smem + s * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
@@ -704,20 +722,30 @@ int persistent_grid() {
   return grid;
 }
 
-template <class Epi>
+template <class Epi, int WM = 2>
 int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who) {
+  constexpr int BMT = WM * 64, LDS = (WM == 2 ? 2 : 3) * (BMT + BN) * BK * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    PV_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               SMEM_BYTES));
+    PV_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<Epi, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
-  // one work item per workgroup while that fills the chip about once; beyond it two persistent workgroups per CU
-  // walk the items
-  const int gx = std::min((cdiv(g.M, BM) * cdiv(g.N, BN) * g.splits + 7) & ~7, persistent_grid());
-  hipLaunchKernelGGL(gemm_nt_kernel<Epi>, dim3(gx), dim3(NTHREADS), SMEM_BYTES, st, g, epi);
+  // one work item per workgroup while that fills the chip about once; beyond it the resident workgroups (two per CU
+  // for the 128-row tile, one for the 256-row tile) walk the items
+  const int gx = std::min((cdiv(g.M, BMT) * cdiv(g.N, BN) * g.splits + 7) & ~7, persistent_grid() * 2 / WM);
+  hipLaunchKernelGGL((gemm_nt_kernel<Epi, WM>), dim3(gx), dim3(WM * 128), LDS, st, g, epi);
   PV_LAUNCH_CHECK(who);
   return PV_OK;
+}
+
+// The 256-row tile for the two K = 512 vocabulary kernels is an experiment, off unless PEVAE_GEMM_BIG_TILE=1: measured
+// SLOWER than the 128-row tile (forward 464 vs 400 us, probabilities 579 vs 483 us at T = 12800) although it stages a
+// third fewer bytes per flop and keeps two K-tiles in flight -- with one 8-wave workgroup per CU nothing overlaps a
+// tile's epilogue, whereas two 4-wave workgroups per CU run one's epilogue under the other's main loop.
+bool big_tile(int M, int N, int K) {
+  const char* e = getenv("PEVAE_GEMM_BIG_TILE");
+  if (!e || atoi(e) != 1) return false;
+  return K <= 1024 && (long)cdiv(M, 256) * cdiv(N, BN) >= 4L * persistent_grid();
 }
 
 }  // namespace
@@ -857,7 +885,7 @@ int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float
   PV_HIP(hipMemsetAsync(tgt_logit, 0, (size_t)Tpad * sizeof(float), st));
   GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 1, 0, live_rows, nullptr};
   EpiSoftmax e{bias, target, part, tgt_logit, T, V, Tpad, inv_temp};
-  rc = launch(g, e, st, "pv_vocab_nll_fwd");
+  rc = big_tile(T, V, H) ? launch<decltype(e), 4>(g, e, st, "pv_vocab_nll_fwd") : launch(g, e, st, "pv_vocab_nll_fwd");
   if (rc) return rc;
   hipLaunchKernelGGL(vocab_reduce_kernel, dim3(cdiv(T, 64)), dim3(256), 0, st, part, tgt_logit, target, T,
                      Tpad, nslab, ignore_index, live_rows, lse, nll);
@@ -880,7 +908,7 @@ int pv_vocab_nll_bwd_prob(const void* h, int ldh, const void* W, int ldw, const 
   if (live_rows) PV_HIP(hipMemsetAsync(dbias_part, 0, (size_t)(Tpad / 64) * ldp * sizeof(float), st));   // skipped tiles
   GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 1, 0, live_rows, nullptr};
   EpiProb e{bias, target, lse, gscale, (bf16_t*)P, (bf16_t*)PT, dbias_part, T, V, Tpad, Vpad, ldp, ldpt, inv_temp};
-  rc = launch(g, e, st, "pv_vocab_nll_bwd_prob");
+  rc = big_tile(T, V, H) ? launch<decltype(e), 4>(g, e, st, "pv_vocab_nll_bwd_prob") : launch(g, e, st, "pv_vocab_nll_bwd_prob");
   if (rc) return rc;
   // dbias[v] = sum over row-slabs of dbias_part[slab][v]   (fixed order: bitwise reproducible)
   return pv_colsum_f32(dbias_part, Tpad / 64, ldp, V, dbias, 0, stream);
