@@ -128,6 +128,19 @@ def gen_encoder(encoders):
     save("encoder_gru_varlen", x=x, lens=np.array(lens), out=out, hn=hn, **sd(enc))
 
 
+def gen_encoder_bi_varlen(encoders):
+    """Bidirectional GRU through the reference's pack_padded_sequence path (encoders.py:55-65): the reverse direction
+    starts at each row's own last token."""
+    torch.manual_seed(13)
+    enc = encoders.EncoderRNN(8, 16, variable_lengths=True, bidirection=True)
+    x = torch.randn(5, 7, 8, requires_grad=True)
+    lens = [7, 6, 4, 2, 1]
+    out, hn = enc(x, input_lengths=lens)
+    w = torch.randn(out.shape)
+    ((out * w).sum() + hn.sum()).backward()
+    save("encoder_gru_bi_varlen", x=x, lens=np.array(lens), out=out, hn=hn, w=w, dx=x.grad, **sd(enc), **grads(enc))
+
+
 def gen_decoder(decoders):
     V, L, E, H, B = 37, 7, 12, 16, 4
     for tag, kw, lat in (("gru", dict(rnn_cell="gru"), 0),
@@ -403,7 +416,7 @@ def main():
     torch.set_num_threads(4)
     torch.use_deterministic_algorithms(False)
     encoders, decoders, base_modules, nn_lib, criterions, utils = import_reference()
-    todo = dict(encoder=lambda: gen_encoder(encoders), decoder=lambda: gen_decoder(decoders),
+    todo = dict(encoder=lambda: gen_encoder(encoders), encoder_bi_varlen=lambda: gen_encoder_bi_varlen(encoders), decoder=lambda: gen_decoder(decoders),
                 attention=lambda: gen_attention(decoders), connectors=lambda: gen_connectors(nn_lib),
                 criterions=lambda: gen_criterions(criterions),
                 dialog=lambda: gen_dialog_pieces(utils), den=gen_den_auto)

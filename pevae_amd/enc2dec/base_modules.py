@@ -38,26 +38,34 @@ class RNNWeights(nn.Module):
     def forward(self, x, state=None, lengths=None):
         """x [B,L,in] -> (out [B,L,H*dirs], h_n [layers*dirs,B,H] (LSTM: (h_n, c_n)), hseq_bf16 of the last layer or None).
         lengths (list / tensor [B]): pack_padded_sequence semantics (encoders.py:55-65): a row's state stops at its
-        length, outputs past it are zero and the time axis is cut to max(lengths); unidirectional only."""
+        length, outputs past it are zero and the time axis is cut to max(lengths).  The reverse direction of a
+        bidirectional RNN then starts at each row's own last token: its input is the row's valid prefix reversed in
+        place (one gather), which turns it into the forward problem with the same lengths.  GRU cell only."""
         lstm = self.cell == "lstm"
         if lstm and lengths is not None:
             raise NotImplementedError("pevae_amd: variable_lengths with the LSTM cell has no HIP path")
         ndir = 2 if self.bidirectional else 1
         lens = mask = None
+        rev_idx = None
         if lengths is not None:
-            if self.bidirectional:
-                raise NotImplementedError("pevae_amd: variable_lengths with a bidirectional RNN has no HIP path")
             lens_l = torch.as_tensor(lengths, dtype=torch.int64)
             x = x[:, :int(lens_l.max())]
             lens = lens_l.to(device=x.device, dtype=torch.int32)
-            mask = (torch.arange(x.size(1), device=x.device).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1).to(x.dtype)
+            pos = torch.arange(x.size(1), device=x.device).unsqueeze(0)
+            mask = (pos < lens.unsqueeze(1)).unsqueeze(-1).to(x.dtype)
+            if self.bidirectional:                        # position j of row b <-> position len_b - 1 - j (j < len_b)
+                ll = lens.to(torch.int64).unsqueeze(1)
+                rev_idx = torch.where(pos < ll, ll - 1 - pos, pos).unsqueeze(-1)
         save = torch.is_grad_enabled()
         finals, cfinals, hseq = [], [], None
         for layer in range(self.num_layers):
             outs = []
             for d in range(ndir):
                 w_ih, w_hh, b_ih, b_hh = self.layer_weights(layer, d)
-                xin = x.flip(1) if d else x
+                if d and rev_idx is not None:
+                    xin = torch.gather(x, 1, rev_idx.expand(-1, -1, x.size(2)))
+                else:
+                    xin = x.flip(1) if d else x
                 if lstm:                                      # state is (h_0, c_0), returns (h_n, c_n)
                     h0 = None if state is None else state[0][layer * ndir + d]
                     c0 = None if state is None else state[1][layer * ndir + d]
@@ -68,7 +76,10 @@ class RNNWeights(nn.Module):
                     out, hn, hs = ops.GRULayer.apply(xin, h0, w_ih, w_hh, b_ih, b_hh, save, lens)
                 if mask is not None:
                     out, hs = out * mask, None            # zero rows past each length (pad_packed_sequence)
-                outs.append(out.flip(1) if d else out)
+                if d and rev_idx is not None:
+                    outs.append(torch.gather(out, 1, rev_idx.expand(-1, -1, out.size(2))))
+                else:
+                    outs.append(out.flip(1) if d else out)
                 finals.append(hn)
                 hseq = hs if ndir == 1 else None
             x = outs[0] if ndir == 1 else torch.cat(outs, dim=-1)

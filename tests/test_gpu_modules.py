@@ -150,6 +150,29 @@ def test_encoder_varlen(dev):
         assert relmax(p.grad, q.grad) < 5e-2, n
 
 
+def test_encoder_bidirectional_varlen(dev):
+    """variable_lengths=True with bidirection=True: golden (outputs and gradients) from the reference's pack_padded path,
+    where the reverse direction starts at each row's own last token."""
+    from pevae_amd.enc2dec.encoders import EncoderRNN
+    from pevae_amd import ops
+    g = load_golden("encoder_gru_bi_varlen")
+    enc = load_params(EncoderRNN(8, 16, variable_lengths=True, bidirection=True), g).to(dev)
+    lens = g["lens"].tolist()
+    x = T(g["x"], dev).requires_grad_()
+    out, hn = enc(x, input_lengths=lens)
+    ((out * T(g["w"], dev)).sum() + hn.sum()).backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    assert tuple(out.shape) == (5, 7, 32) and tuple(hn.shape) == (2, 5, 16)
+    assert relmax(out, g["out"]) < 3e-2 and relmax(hn, g["hn"]) < 3e-2           # bf16 operands vs fp32 golden
+    for b, n in enumerate(lens):
+        if n < out.shape[1]:
+            assert float(out.detach()[b, n:].abs().max()) == 0.0
+    assert relmax(x.grad, g["dx"]) < 5e-2
+    for n, p in enc.named_parameters():
+        assert relmax(p.grad, g["g." + n]) < 5e-2, n
+
+
 def test_encoder_errors(dev):
     from pevae_amd.enc2dec.encoders import EncoderRNN
     with pytest.raises(ValueError):

@@ -64,6 +64,17 @@ def test_encoder_varlen():
     close(hn, g["hn"])
 
 
+def test_encoder_bidirectional_varlen():
+    g = load_golden("encoder_gru_bi_varlen")
+    enc = load_params(R.EncoderRNN(8, 16, variable_lengths=True, bidirection=True), g)
+    x = T(g["x"]).requires_grad_()
+    out, hn = enc(x, input_lengths=g["lens"].tolist())
+    ((out * T(g["w"])).sum() + hn.sum()).backward()
+    close(out, g["out"])
+    close(hn, g["hn"])
+    close(x.grad, g["dx"])
+
+
 def test_gru_cell_matches_torch_gru():
     torch.manual_seed(0)
     gru = torch.nn.GRU(10, 16, batch_first=True)
