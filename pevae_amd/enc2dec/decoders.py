@@ -255,9 +255,6 @@ class DecoderRNN(BaseRNN):
                     if self.use_attention:
                         ret_dict[DecoderRNN.KEY_ATTN_SCORE].append(step_attn)
                     sequence_symbols.append(symbols)
-                    eos_batches = symbols.data.eq(self.eos_id).cpu().view(-1).numpy()
-                    update_idx = ((lengths > di) & eos_batches) != 0
-                    lengths[update_idx] = len(sequence_symbols)
                     decoder_input = symbols
                     continue
                 step_output, decoder_hidden, step_attn = self.forward_step(decoder_input, decoder_hidden,
@@ -284,11 +281,12 @@ class DecoderRNN(BaseRNN):
                 else:
                     raise ValueError("Unsupported decoding mode")
                 sequence_symbols.append(symbols)
-                eos_batches = symbols.data.eq(self.eos_id).cpu().view(-1).numpy()
-                update_idx = ((lengths > di) & eos_batches) != 0
-                lengths[update_idx] = len(sequence_symbols)
                 decoder_input = symbols
             decoder_outputs = torch.cat(step_outputs, dim=1)
+            # lengths (decoders.py:256-259 updates them with one device->host copy per token): position of the first EOS
+            # + 1, max_length without one -- formed on the device after the loop, one copy per decode
+            before_eos = (torch.cat(sequence_symbols, dim=1).eq(self.eos_id).cumsum(1) == 0).sum(1)
+            lengths = torch.clamp(before_eos + 1, max=self.max_length).cpu().numpy()
             if gen_type == 'beam':
                 best = cum_sum.view(-1, beam_size).topk(1)[1].view(-1)
                 rows = torch.arange(batch_size, device=dev)
