@@ -121,15 +121,16 @@ int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, 
  * decoders.py:182): the same persistent kernels with four gates per unit.  xprojT [4H][ldx], whh_bf16 [4H][Hk],
  * gsaveT [L][4][H][Bpad] = i, f, g, o; call [(L+1)][Bpad][H] fp32 cell states (slot 0 = c0); cn [B][H].
  * Backward: whhT_bf16 [H][K4] = W_hh^T (K4 from pv_lstm_geometry); dg_bf16 [L][Bpad][K4] is the single gate-gradient
- * image (operand of dW_ih, dW_hh and dx); db_ih == db_hh [4H].  Variable lengths are not supported for this cell. */
+ * image (operand of dW_ih, dW_hh and dx); db_ih == db_hh [4H].  lengths (optional [B], both calls): rows keep (h, c) at
+ * t >= lengths[b] (pack_padded_sequence semantics, encoders.py:55-65); the backward needs one row group per workgroup. */
 int pv_lstm_geometry(int B, int H, int* Hk, int* K4, int* Bpad, int* NG);
 int pv_lstm_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0,
-                const float* c0, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall,
-                float* call, float* hn, float* cn, void* sync, int max_wgs, void* stream);
+                const float* c0, const int* lengths, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT,
+                float* hall, float* call, float* hn, float* cn, void* sync, int max_wgs, void* stream);
 int pv_lstm_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* dcn,
                 const float* gsaveT, const float* hall, const float* call, const void* whhT_bf16, int L, int B, int H,
                 int reverse, void* dg_bf16, float* dh0, float* dc0, float* dbias_part, float* db_ih, float* db_hh,
-                void* sync, int max_wgs, void* stream);
+                const int* lengths, void* sync, int max_wgs, void* stream);
 
 /* ---- embedding gather / sorted scatter-add -----------------------------------------------------------------
  * Occurrence r = i0*n1 + i1 reads ids[i0*s0 + i1*s1] and is row i0*n1p + i1 of the output (n1p >= n1).  Replaces nn.Embedding forward at

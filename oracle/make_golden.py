@@ -141,6 +141,19 @@ def gen_encoder_bi_varlen(encoders):
     save("encoder_gru_bi_varlen", x=x, lens=np.array(lens), out=out, hn=hn, w=w, dx=x.grad, **sd(enc), **grads(enc))
 
 
+def gen_encoder_lstm_varlen(encoders):
+    """LSTM through the reference's pack_padded_sequence path, unidirectional and bidirectional."""
+    for tag, bi in (("lstm_varlen", False), ("lstm_bi_varlen", True)):
+        torch.manual_seed(14)
+        enc = encoders.EncoderRNN(8, 16, rnn_cell="lstm", variable_lengths=True, bidirection=bi)
+        x = torch.randn(5, 7, 8, requires_grad=True)
+        lens = [7, 6, 4, 2, 1]
+        out, (hn, cn) = enc(x, input_lengths=lens)
+        w = torch.randn(out.shape)
+        ((out * w).sum() + hn.sum() + 0.5 * cn.sum()).backward()
+        save("encoder_" + tag, x=x, lens=np.array(lens), out=out, hn=hn, cn=cn, w=w, dx=x.grad, **sd(enc), **grads(enc))
+
+
 def gen_decoder(decoders):
     V, L, E, H, B = 37, 7, 12, 16, 4
     for tag, kw, lat in (("gru", dict(rnn_cell="gru"), 0),
@@ -416,7 +429,8 @@ def main():
     torch.set_num_threads(4)
     torch.use_deterministic_algorithms(False)
     encoders, decoders, base_modules, nn_lib, criterions, utils = import_reference()
-    todo = dict(encoder=lambda: gen_encoder(encoders), encoder_bi_varlen=lambda: gen_encoder_bi_varlen(encoders), decoder=lambda: gen_decoder(decoders),
+    todo = dict(encoder=lambda: gen_encoder(encoders), encoder_bi_varlen=lambda: gen_encoder_bi_varlen(encoders),
+                encoder_lstm_varlen=lambda: gen_encoder_lstm_varlen(encoders), decoder=lambda: gen_decoder(decoders),
                 attention=lambda: gen_attention(decoders), connectors=lambda: gen_connectors(nn_lib),
                 criterions=lambda: gen_criterions(criterions),
                 dialog=lambda: gen_dialog_pieces(utils), den=gen_den_auto)

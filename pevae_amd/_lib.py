@@ -58,8 +58,8 @@ SIGNATURES = {
     "pv_dls_inputs_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "pv_dls_inputs_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "pv_lstm_geometry": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
-    "pv_lstm_fwd": (i32, [vp, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
-    "pv_lstm_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "pv_lstm_fwd": (i32, [vp, lng, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "pv_lstm_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pv_embedding_gather": (i32, [vp, lng, i32, vp, i32, i32, i32, lng, lng, vp, i32, vp, i32, vp, vp]),
     "pv_embedding_bwd_ws_bytes": (sz, [i32, i32]),
     "pv_embedding_bwd": (i32, [vp, i32, vp, i32, i32, i32, lng, lng, lng, i32, lng, i32, vp, vp, sz, vp]),

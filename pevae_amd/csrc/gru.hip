@@ -355,6 +355,15 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
             const bool live = rbase + j < a.B;
             cv[j] = live ? zz[j] * cp[j] + rr[j] * nn[j] : 0.f;
             hv[j] = live ? hn[j] * fast_tanh(cv[j]) : 0.f;
+            if (a.lens && live && t >= a.lens[rbase + j]) {
+              // packed-sequence semantics (encoders.py:55-65): past its length a row keeps (h, c); saving i = g = o = 0
+              // and f = 1 zeroes every gate gradient of the step and passes dL/dc through, the backward kernel carries
+              // dL/dh across it
+              hv[j] = hp[j];
+              cv[j] = cp[j];
+              zz[j] = 1.f;
+              rr[j] = nn[j] = hn[j] = 0.f;
+            }
             cp[j] = cv[j];
             hp[j] = hv[j];
             continue;
@@ -464,6 +473,7 @@ struct GruBwdArgs {
   int L, B, H, K3, Bpad, NG, G, S, reverse, xmap;
   unsigned dg_bytes;
   u32* stamps;            // diagnostic build only
+  const int* lens;        // LSTM only: rows frozen at t >= lens[b] (the GRU encodes a frozen step in its saved gates)
 };
 
 // Backward through time.  Per step: rec = dgh[previously handled step] @ W_hh (K = 3H, split over the 4
@@ -511,6 +521,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   float carry[4] = {0.f, 0.f, 0.f, 0.f};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   float gx[4] = {0.f, 0.f, 0.f, 0.f};                    // dL/dh_n (and the LSTM's dL/dc_n in carry): enter at step 0
+  float hcarry[4] = {0.f, 0.f, 0.f, 0.f};                // LSTM with lengths: dL/dh carried across a row's frozen steps
   if (single) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
             const float prev = single ? carry[j] : a.dcarry[(size_t)brow * H + unit];
             if constexpr (LSTM) {
               a.dcarry[(size_t)brow * H + unit] = prev;
-              a.dh0[(size_t)brow * H + unit] = rec[j];
+              a.dh0[(size_t)brow * H + unit] = rec[j] + hcarry[j];
             } else {
               a.dcarry[(size_t)brow * H + unit] = prev + rec[j];
             }
@@ -656,7 +667,11 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         const bool live = active && rbase + j < a.B;
         if constexpr (LSTM) {
           // saved slots: gr = i, gz = f, gn = g, ghn = o.  (dr, dz, dn, dnr) carry (di, df, dg, do) pre-activation
-          const float dh = rec[j] + gdo[j] + (step == 0 ? gx[j] : 0.f);
+          // a frozen step (t >= lens[row]; the forward kernel saved i = g = o = 0, f = 1): every gate gradient is zero,
+          // dL/dc passes through (carry = dc * f) and dL/dh is handed to the step before through hcarry
+          const bool frozen = a.lens != nullptr && live && t >= a.lens[rbase + j];
+          const float dh = rec[j] + gdo[j] + (step == 0 ? gx[j] : 0.f) + hcarry[j];
+          hcarry[j] = frozen ? dh : 0.f;
           gtc[j] = fast_tanh(gtc[j]);
           const float dc = dh * ghn[j] * (1.f - gtc[j] * gtc[j]) + carry[j];
           dr[j] = dc * gn[j] * gr[j] * (1.f - gr[j]);
@@ -849,7 +864,6 @@ int rnn_fwd(int ngt, const float* xprojT, long ldx, const void* whh_bf16, const 
   if (rc) return rc;
   PV_REQUIRE(xprojT && whh_bf16 && bhh && hseq_bf16 && hall && hn && sync && L > 0, "pv_gru_fwd/pv_lstm_fwd: null/empty argument");
   PV_REQUIRE(ngt == 3 || (call && cn), "pv_lstm_fwd: null cell-state buffer");
-  PV_REQUIRE(ngt == 3 || !lengths, "pv_lstm_fwd: variable lengths are not supported for the LSTM cell");
   PV_REQUIRE(((uintptr_t)whh_bf16 & 15) == 0 && ((uintptr_t)hseq_bf16 & 15) == 0, "pv_gru_fwd: bf16 buffers must be 16-byte aligned");
   PV_REQUIRE(ldx >= (long)L * Bpad && ldx % 4 == 0 && ((uintptr_t)xprojT & 15) == 0 && ((uintptr_t)gsaveT & 15) == 0,
              "pv_gru_fwd: xprojT needs ldx >= L*Bpad = %ld, ldx %% 4 == 0 and 16-byte alignment (also gsaveT)", (long)L * Bpad);
@@ -927,7 +941,7 @@ int rnn_fwd(int ngt, const float* xprojT, long ldx, const void* whh_bf16, const 
 int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float* dhn, const float* dcn,
             const float* gsaveT, const float* hall, const float* call, const void* whhT_bf16, int L, int B, int H,
             int reverse, void* dgi_bf16, void* dgh_bf16, float* dh0, float* dc0, float* dbias_part, float* db_ih,
-            float* db_hh, void* sync, int max_wgs, void* stream) {
+            float* db_hh, const int* lengths, void* sync, int max_wgs, void* stream) {
   int Hk, K3, Bpad, NG;
   int rc = rnn_geometry(ngt, B, H, &Hk, &K3, &Bpad, &NG);
   if (rc) return rc;
@@ -953,6 +967,7 @@ int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float*
   if (const char* e = getenv("PV_GRU_BWD_MT")) MT = atoi(e) == 1 ? MT : 2;
   const int NGk = Bpad / (MT * 16);
   const int G = NGk < cap / S ? NGk : cap / S;
+  PV_REQUIRE(!lengths || NGk <= G, "pv_lstm_bwd: variable lengths need one row group per workgroup (B=%d too large)", B);
   const int xmap = xcd_map(G, S, cap), grid = xmap ? 8 * cdiv(G, 8) * S : G * S;
   const size_t smem = lds_need(UT);
   PV_REQUIRE(smem <= 160 * 1024, "pv_gru_bwd: LDS need %zu exceeds 160 KiB", smem);
@@ -968,7 +983,7 @@ int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float*
   }
   GruBwdArgs a{dout, dout_sb, dout_st, dhn, gsaveT, hall, (const bf16_t*)whhT_bf16, (bf16_t*)dgi_bf16,
                (bf16_t*)dgh_bf16, ngt == 4 ? dc0 : dh0, call, dcn, dh0, dbias_part, counters, err, L, B, H, K3, Bpad,
-               NGk, G, S, reverse, xmap, (unsigned)dg_bytes, (u32*)sync + 64};
+               NGk, G, S, reverse, xmap, (unsigned)dg_bytes, (u32*)sync + 64, lengths};
 #define PV_GRU_LAUNCH_B5(UTv, NKv, NGv, MTv)                                                            \
   do {                                                                                                  \
     static size_t seen = 0;                                                                             \
@@ -1011,9 +1026,9 @@ int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float*
 }
 
 int pv_lstm_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0,
-                const float* c0, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall,
-                float* call, float* hn, float* cn, void* sync, int max_wgs, void* stream) {
-  return rnn_fwd(4, xprojT, ldx, whh_bf16, bhh, h0, c0, nullptr, L, B, H, reverse, hseq_bf16, gsaveT, hall, call, hn, cn,
+                const float* c0, const int* lengths, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT,
+                float* hall, float* call, float* hn, float* cn, void* sync, int max_wgs, void* stream) {
+  return rnn_fwd(4, xprojT, ldx, whh_bf16, bhh, h0, c0, lengths, L, B, H, reverse, hseq_bf16, gsaveT, hall, call, hn, cn,
                  sync, max_wgs, stream);
 }
 
@@ -1022,15 +1037,15 @@ int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, 
                void* dgh_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
                int max_wgs, void* stream) {
   return rnn_bwd(3, dout, dout_sb, dout_st, dhn, nullptr, gsaveT, hall, nullptr, whhT_bf16, L, B, H, reverse, dgi_bf16,
-                 dgh_bf16, dh0, nullptr, dbias_part, db_ih, db_hh, sync, max_wgs, stream);
+                 dgh_bf16, dh0, nullptr, dbias_part, db_ih, db_hh, nullptr, sync, max_wgs, stream);
 }
 
 int pv_lstm_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* dcn,
                 const float* gsaveT, const float* hall, const float* call, const void* whhT_bf16, int L, int B, int H,
                 int reverse, void* dg_bf16, float* dh0, float* dc0, float* dbias_part, float* db_ih, float* db_hh,
-                void* sync, int max_wgs, void* stream) {
+                const int* lengths, void* sync, int max_wgs, void* stream) {
   return rnn_bwd(4, dout, dout_sb, dout_st, dhn, dcn, gsaveT, hall, call, whhT_bf16, L, B, H, reverse, nullptr, dg_bf16,
-                 dh0, dc0, dbias_part, db_ih, db_hh, sync, max_wgs, stream);
+                 dh0, dc0, dbias_part, db_ih, db_hh, lengths, sync, max_wgs, stream);
 }
 
 }  // extern "C"

@@ -40,10 +40,8 @@ class RNNWeights(nn.Module):
         lengths (list / tensor [B]): pack_padded_sequence semantics (encoders.py:55-65): a row's state stops at its
         length, outputs past it are zero and the time axis is cut to max(lengths).  The reverse direction of a
         bidirectional RNN then starts at each row's own last token: its input is the row's valid prefix reversed in
-        place (one gather), which turns it into the forward problem with the same lengths.  GRU cell only."""
+        place (one gather), which turns it into the forward problem with the same lengths."""
         lstm = self.cell == "lstm"
-        if lstm and lengths is not None:
-            raise NotImplementedError("pevae_amd: variable_lengths with the LSTM cell has no HIP path")
         ndir = 2 if self.bidirectional else 1
         lens = mask = None
         rev_idx = None
@@ -69,7 +67,7 @@ class RNNWeights(nn.Module):
                 if lstm:                                      # state is (h_0, c_0), returns (h_n, c_n)
                     h0 = None if state is None else state[0][layer * ndir + d]
                     c0 = None if state is None else state[1][layer * ndir + d]
-                    out, hn, cn, hs = ops.LSTMLayer.apply(xin, h0, c0, w_ih, w_hh, b_ih, b_hh, save)
+                    out, hn, cn, hs = ops.LSTMLayer.apply(xin, h0, c0, w_ih, w_hh, b_ih, b_hh, save, lens)
                     cfinals.append(cn)
                 else:
                     h0 = None if state is None else state[layer * ndir + d]

@@ -486,8 +486,8 @@ class LSTMLayer(torch.autograd.Function):
     hseq bf16 as GRULayer).  One gate-gradient image feeds dx, dW_ih and dW_hh; db_ih == db_hh."""
 
     @staticmethod
-    def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, save):
-        _need_cuda(x, w_ih, w_hh, b_ih, b_hh, h0, c0)
+    def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, save, lengths=None):
+        _need_cuda(x, w_ih, w_hh, b_ih, b_hh, h0, c0, lengths)
         B, L, E = x.shape
         H = w_hh.shape[1]
         dev = x.device
@@ -508,7 +508,8 @@ class LSTMLayer(torch.autograd.Function):
         h0c = None if h0 is None else h0.contiguous()
         c0c = None if c0 is None else c0.contiguous()
         with timed("lstm_fwd"):
-            _lib.call("pv_lstm_fwd", _p(xprojT), L * Bpad, _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), _p(c0c), L, B, H, 0,
+            _lib.call("pv_lstm_fwd", _p(xprojT), L * Bpad, _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), _p(c0c), _p(lengths),
+                      L, B, H, 0,
                       _p(hseq), _p(gsave), _p(hall), _p(call), _p(hn), _p(cn), _p(sync), GRU_MAX_WGS, _stream())
         out = hall[1:, :B].transpose(0, 1)
         if save:
@@ -517,6 +518,7 @@ class LSTMLayer(torch.autograd.Function):
             LAST_GRU_SYNC.append((sync, NG, "pv_lstm_fwd"))
         ctx.dims = (B, L, E, H, Hk, K4, Bpad, NG, Ep)
         ctx.params = (w_ih, w_hh)
+        ctx.lengths = lengths
         ctx.has_state = (h0 is not None, c0 is not None)
         ctx.mark_non_differentiable(hseq)
         return out, hn, cn, hseq
@@ -541,8 +543,8 @@ class LSTMLayer(torch.autograd.Function):
         with timed("lstm_bwd"):
             _lib.call("pv_lstm_bwd", _p(dout), 0 if dout is None else dout.stride(0),
                       0 if dout is None else dout.stride(1), _p(dhn_c), _p(dcn_c), _p(gsave), _p(hall), _p(call),
-                      _p(whhT), L, B, H, 0, _p(dg), _p(dh0), _p(dc0), _p(dbp), _p(db_ih), _p(db_hh), _p(sync),
-                      GRU_MAX_WGS, _stream())
+                      _p(whhT), L, B, H, 0, _p(dg), _p(dh0), _p(dc0), _p(dbp), _p(db_ih), _p(db_hh), _p(ctx.lengths),
+                      _p(sync), GRU_MAX_WGS, _stream())
         if len(LAST_GRU_SYNC) < 64:
             LAST_GRU_SYNC.append((sync, NG, "pv_lstm_bwd"))
         Tt = L * Bpad
@@ -557,7 +559,7 @@ class LSTMLayer(torch.autograd.Function):
         dw_ih = gemm_nt_wgrad(dgT, Tp, xT, Tp, 4 * H, E, Tp, grad_sink(p_ih, (4 * H, E)))
         dw_hh = gemm_nt_wgrad(dgT, Tp, hpT, Tp, 4 * H, H, Tp, grad_sink(p_hh, (4 * H, H)))
         has_h0, has_c0 = ctx.has_state
-        return dx, (dh0 if has_h0 else None), (dc0 if has_c0 else None), dw_ih, dw_hh, db_ih, db_hh, None
+        return dx, (dh0 if has_h0 else None), (dc0 if has_c0 else None), dw_ih, dw_hh, db_ih, db_hh, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -90,8 +90,6 @@ def test_encoder_lstm(dev):
     out0, (hn0, _) = enc(T(g["x"], dev))
     close(out0, g["out_nostate"], rtol=0, atol=3e-2)
     close(hn0, g["hn_nostate"], rtol=0, atol=3e-2)
-    with pytest.raises(NotImplementedError):
-        EncoderRNN(E, H, rnn_cell="lstm", variable_lengths=True).to(dev)(T(g["x"], dev), input_lengths=[L] * B)
 
 
 @pytest.mark.parametrize("B,L,E,H", [(70, 6, 40, 64), (33, 4, 24, 512)])
@@ -165,6 +163,29 @@ def test_encoder_bidirectional_varlen(dev):
     ops.gru_check_all()
     assert tuple(out.shape) == (5, 7, 32) and tuple(hn.shape) == (2, 5, 16)
     assert relmax(out, g["out"]) < 3e-2 and relmax(hn, g["hn"]) < 3e-2           # bf16 operands vs fp32 golden
+    for b, n in enumerate(lens):
+        if n < out.shape[1]:
+            assert float(out.detach()[b, n:].abs().max()) == 0.0
+    assert relmax(x.grad, g["dx"]) < 5e-2
+    for n, p in enc.named_parameters():
+        assert relmax(p.grad, g["g." + n]) < 5e-2, n
+
+
+@pytest.mark.parametrize("tag,bi", [("lstm_varlen", False), ("lstm_bi_varlen", True)])
+def test_encoder_lstm_varlen(dev, tag, bi):
+    """variable_lengths=True with the LSTM cell (rows keep (h, c) past their length; dL/dh and dL/dc carried across the
+    frozen steps): outputs, final states and gradients against goldens from the reference's pack_padded path."""
+    from pevae_amd.enc2dec.encoders import EncoderRNN
+    from pevae_amd import ops
+    g = load_golden("encoder_" + tag)
+    enc = load_params(EncoderRNN(8, 16, rnn_cell="lstm", variable_lengths=True, bidirection=bi), g).to(dev)
+    lens = g["lens"].tolist()
+    x = T(g["x"], dev).requires_grad_()
+    out, (hn, cn) = enc(x, input_lengths=lens)
+    ((out * T(g["w"], dev)).sum() + hn.sum() + 0.5 * cn.sum()).backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    assert relmax(out, g["out"]) < 3e-2 and relmax(hn, g["hn"]) < 3e-2 and relmax(cn, g["cn"]) < 3e-2
     for b, n in enumerate(lens):
         if n < out.shape[1]:
             assert float(out.detach()[b, n:].abs().max()) == 0.0

@@ -75,6 +75,19 @@ def test_encoder_bidirectional_varlen():
     close(x.grad, g["dx"])
 
 
+@pytest.mark.parametrize("tag,bi", [("lstm_varlen", False), ("lstm_bi_varlen", True)])
+def test_encoder_lstm_varlen(tag, bi):
+    g = load_golden("encoder_" + tag)
+    enc = load_params(R.EncoderRNN(8, 16, rnn_cell="lstm", variable_lengths=True, bidirection=bi), g)
+    x = T(g["x"]).requires_grad_()
+    out, (hn, cn) = enc(x, input_lengths=g["lens"].tolist())
+    ((out * T(g["w"])).sum() + hn.sum() + 0.5 * cn.sum()).backward()
+    close(out, g["out"])
+    close(hn, g["hn"])
+    close(cn, g["cn"])
+    close(x.grad, g["dx"])
+
+
 def test_gru_cell_matches_torch_gru():
     torch.manual_seed(0)
     gru = torch.nn.GRU(10, 16, batch_first=True)
