@@ -380,25 +380,47 @@ struct EpiArgmax {
   }
 };
 
-// one thread per row: slabs in ascending order (fixed order; the first maximum wins)
+// 16 threads per row, 16 rows per workgroup: thread (row r, chunk c) folds slabs c, c+16, ... in ascending order, then
+// the 16 chunk results of a row are folded in chunk order through LDS.  Fixed order (run-to-run identical); among equal
+// maxima the smallest column wins, as a left-to-right scan would choose.  (One thread per row walking all 313 slabs of
+// the Yelp vocabulary in a dependent chain took 89 us per decoded token -- a third of the greedy decode.)
 __global__ __launch_bounds__(256) void vocab_argmax_reduce_kernel(const ArgPart* __restrict__ part, int T, int Tpad, int nslab,
                                                                    int64_t* __restrict__ ids, float* __restrict__ logp) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  if (row >= T) return;
+  __shared__ float sm_m[256], sm_s[256], sm_b[256];
+  __shared__ int sm_i[256];
+  const int r = threadIdx.x & 15, c = threadIdx.x >> 4;
+  const int row = min(blockIdx.x * 16 + r, Tpad - 1);
   float m = -INFINITY, s = 0.f, best = -INFINITY;
   int idx = -1;
-  for (int k = 0; k < nslab; ++k) {
+  for (int k = c; k < nslab; k += 16) {
     const ArgPart p = part[(size_t)k * Tpad + row];
     const float mn = fmaxf(m, p.m);
-    s = s * __expf(m - mn) + p.s * __expf(p.m - mn);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (p.m == -INFINITY ? 0.f : p.s * __expf(p.m - mn));
     m = mn;
-    if (p.idx >= 0 && p.best > best) {
+    if (p.idx >= 0 && (p.best > best || (p.best == best && (idx < 0 || p.idx < idx)))) {
       best = p.best;
       idx = p.idx;
     }
   }
-  ids[row] = idx;
-  logp[row] = best - (m + logf(s));
+  sm_m[threadIdx.x] = m;
+  sm_s[threadIdx.x] = s;
+  sm_b[threadIdx.x] = best;
+  sm_i[threadIdx.x] = idx;
+  __syncthreads();
+  if (c != 0 || blockIdx.x * 16 + r >= T) return;
+  for (int k = 1; k < 16; ++k) {
+    const float pm = sm_m[k * 16 + r], ps = sm_s[k * 16 + r], pb = sm_b[k * 16 + r];
+    const int pi = sm_i[k * 16 + r];
+    const float mn = fmaxf(m, pm);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (pm == -INFINITY ? 0.f : ps * __expf(pm - mn));
+    m = mn;
+    if (pi >= 0 && (pb > best || (pb == best && (idx < 0 || pi < idx)))) {
+      best = pb;
+      idx = pi;
+    }
+  }
+  ids[blockIdx.x * 16 + r] = idx;
+  logp[blockIdx.x * 16 + r] = best - (m + logf(s));
 }
 
 constexpr int EPI_LD = 144;            // bytes per staged 64-element bf16 row (128 + 16 pad)
@@ -927,7 +949,7 @@ int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float*
   EpiArgmax e{bias, (ArgPart*)workspace, T, V, Tpad, mask_col, inv_temp};
   rc = launch(g, e, st, "pv_vocab_argmax");
   if (rc) return rc;
-  hipLaunchKernelGGL(vocab_argmax_reduce_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, (const ArgPart*)workspace, T, Tpad,
+  hipLaunchKernelGGL(vocab_argmax_reduce_kernel, dim3(cdiv(T, 16)), dim3(256), 0, st, (const ArgPart*)workspace, T, Tpad,
                      nslab, ids, logp);
   PV_LAUNCH_CHECK("vocab_argmax_reduce_kernel");
   return PV_OK;

@@ -198,6 +198,10 @@ class DecoderRNN(BaseRNN):
 
     def forward(self, batch_size, inputs=None, init_state=None, attn_context=None, mode=TEACH_FORCE,
                 gen_type='greedy', beam_size=4, latent_variable=None, feature_input=None):
+        if (mode == GEN and gen_type == 'greedy' and getattr(self, "graph_decode", False)
+                and getattr(self, "fused_greedy", False) and not self.training and not torch.is_grad_enabled()
+                and attn_context is None and not self.use_attention and torch.is_tensor(init_state)):
+            return self._graphed_greedy(batch_size, inputs, init_state, latent_variable)
         ret_dict = dict()
         self.max_length = inputs.size(1)                # decoders.py:201 (GEN still needs `inputs` for this)
         if self.use_attention:
@@ -240,53 +244,57 @@ class DecoderRNN(BaseRNN):
         else:
             step_outputs, cum_sum = [], None
             fused = getattr(self, "fused_greedy", False) and gen_type == 'greedy'
-            for di in range(self.max_length):
-                if fused:
-                    # opt-in (self.fused_greedy = True): arg-max fused into the projection GEMM, no [B,V] log-probs; the
-                    # returned decoder_outputs is then [B, L] = log-probability of each emitted symbol (a deviation from
-                    # the reference's [B, L, V] return value, for callers that only consume ret_dict['sequence'])
-                    output, decoder_hidden, step_attn, _ = self._hidden_states(decoder_input, decoder_hidden,
+            # the projection / recurrence weights are packed to bf16 once for the whole decode, not once per token
+            with ops.packed_weights():
+                for di in range(self.max_length):
+                    if fused:
+                        # opt-in (self.fused_greedy = True): arg-max fused into the projection GEMM, no [B,V] log-probs; the
+                        # returned decoder_outputs is then [B, L] = log-probability of each emitted symbol (a deviation from
+                        # the reference's [B, L, V] return value, for callers that only consume ret_dict['sequence'])
+                        output, decoder_hidden, step_attn, _ = self._hidden_states(decoder_input, decoder_hidden,
+                                                                                   attn_context, latent_variable)
+                        w, b = self._out_weights()
+                        symbols, lp = ops.vocab_argmax(output.reshape(-1, output.shape[-1]), w, b,
+                                                       1.0 / self.softmax_temperature, self.unk_id if self.mask_unk else -1)
+                        symbols = symbols.view(-1, 1)
+                        step_outputs.append(lp.view(-1, 1))
+                        if self.use_attention:
+                            ret_dict[DecoderRNN.KEY_ATTN_SCORE].append(step_attn)
+                        sequence_symbols.append(symbols)
+                        decoder_input = symbols
+                        continue
+                    step_output, decoder_hidden, step_attn = self.forward_step(decoder_input, decoder_hidden,
                                                                                attn_context, latent_variable)
-                    w, b = self._out_weights()
-                    symbols, lp = ops.vocab_argmax(output.reshape(-1, output.shape[-1]), w, b,
-                                                   1.0 / self.softmax_temperature, self.unk_id if self.mask_unk else -1)
-                    symbols = symbols.view(-1, 1)
-                    step_outputs.append(lp.view(-1, 1))
+                    step_outputs.append(step_output)
+                    scores = step_output.squeeze(1)
+                    if self.mask_unk:
+                        scores = scores + self.unk_mask
                     if self.use_attention:
                         ret_dict[DecoderRNN.KEY_ATTN_SCORE].append(step_attn)
+                    if gen_type == 'greedy':
+                        symbols = scores.topk(1)[1]
+                    elif gen_type == 'sample':
+                        symbols = self.multinomial_sampling(torch.exp(scores))
+                    elif gen_type == 'beam':
+                        if di == 0:
+                            seq_score = scores.view(batch_size, -1)[:, 0:self.output_size]
+                        else:
+                            seq_score = (cum_sum + scores).view(batch_size, -1)
+                        top_v, top_id = seq_score.topk(beam_size)
+                        back_pointers.append(torch.div(top_id, self.output_size, rounding_mode='floor').view(-1, 1))
+                        symbols = top_id.fmod(self.output_size).view(-1, 1)
+                        cum_sum = top_v.view(-1, 1)
+                    else:
+                        raise ValueError("Unsupported decoding mode")
                     sequence_symbols.append(symbols)
                     decoder_input = symbols
-                    continue
-                step_output, decoder_hidden, step_attn = self.forward_step(decoder_input, decoder_hidden,
-                                                                           attn_context, latent_variable)
-                step_outputs.append(step_output)
-                scores = step_output.squeeze(1)
-                if self.mask_unk:
-                    scores = scores + self.unk_mask
-                if self.use_attention:
-                    ret_dict[DecoderRNN.KEY_ATTN_SCORE].append(step_attn)
-                if gen_type == 'greedy':
-                    symbols = scores.topk(1)[1]
-                elif gen_type == 'sample':
-                    symbols = self.multinomial_sampling(torch.exp(scores))
-                elif gen_type == 'beam':
-                    if di == 0:
-                        seq_score = scores.view(batch_size, -1)[:, 0:self.output_size]
-                    else:
-                        seq_score = (cum_sum + scores).view(batch_size, -1)
-                    top_v, top_id = seq_score.topk(beam_size)
-                    back_pointers.append(torch.div(top_id, self.output_size, rounding_mode='floor').view(-1, 1))
-                    symbols = top_id.fmod(self.output_size).view(-1, 1)
-                    cum_sum = top_v.view(-1, 1)
-                else:
-                    raise ValueError("Unsupported decoding mode")
-                sequence_symbols.append(symbols)
-                decoder_input = symbols
             decoder_outputs = torch.cat(step_outputs, dim=1)
             # lengths (decoders.py:256-259 updates them with one device->host copy per token): position of the first EOS
             # + 1, max_length without one -- formed on the device after the loop, one copy per decode
             before_eos = (torch.cat(sequence_symbols, dim=1).eq(self.eos_id).cumsum(1) == 0).sum(1)
-            lengths = torch.clamp(before_eos + 1, max=self.max_length).cpu().numpy()
+            lengths = torch.clamp(before_eos + 1, max=self.max_length)
+            if not getattr(self, "_device_lengths", False):
+                lengths = lengths.cpu().numpy()
             if gen_type == 'beam':
                 best = cum_sum.view(-1, beam_size).topk(1)[1].view(-1)
                 rows = torch.arange(batch_size, device=dev)
@@ -297,5 +305,40 @@ class DecoderRNN(BaseRNN):
                 sequence_symbols = final[::-1]
 
         ret_dict[DecoderRNN.KEY_SEQUENCE] = sequence_symbols
-        ret_dict[DecoderRNN.KEY_LENGTH] = lengths.tolist()
+        ret_dict[DecoderRNN.KEY_LENGTH] = lengths if getattr(self, "_device_lengths", False) else lengths.tolist()
         return decoder_outputs, decoder_hidden, ret_dict
+
+    def _graphed_greedy(self, batch_size, inputs, init_state, latent_variable):
+        """Opt-in (self.graph_decode = self.fused_greedy = True, eval mode, no grad, GRU cell, no attention): the whole
+        free-running greedy decode -- max_length x (embedding, input projection, one recurrence step, projection +
+        arg-max) -- captured once per (batch, length) into a HIP graph and replayed; the only host work per decode is the
+        copy of the initial state in and one read-back of the lengths.  Weights are re-packed inside the graph, so a
+        replay follows parameter updates.  Same return value as the fused greedy path."""
+        L = inputs.size(1)
+        key = (batch_size, L, tuple(init_state.shape), None if latent_variable is None else tuple(latent_variable.shape))
+        cache = self.__dict__.setdefault("_decode_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            st = init_state.detach().clone()
+            lt = None if latent_variable is None else latent_variable.detach().clone()
+            width = torch.zeros((batch_size, L), dtype=torch.long, device=st.device)     # only its width is read
+            self.graph_decode, self._device_lengths = False, True
+            try:
+                self.forward(batch_size, width, st, None, GEN, 'greedy', 1, lt)            # warm-up: every workspace exists
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    outs, hid, ret = self.forward(batch_size, width, st, None, GEN, 'greedy', 1, lt)
+                    seq = torch.cat(ret[DecoderRNN.KEY_SEQUENCE], dim=1)
+                    lens = ret[DecoderRNN.KEY_LENGTH]
+            finally:
+                self.graph_decode, self._device_lengths = True, False
+            ent = cache[key] = (graph, st, lt, outs, hid, seq, lens)
+        graph, st, lt, outs, hid, seq, lens = ent
+        st.copy_(init_state)
+        if lt is not None:
+            lt.copy_(latent_variable)
+        graph.replay()
+        seq_out = seq.clone()
+        ret_dict = {DecoderRNN.KEY_SEQUENCE: list(seq_out.split(1, dim=1)), DecoderRNN.KEY_LENGTH: lens.cpu().tolist()}
+        return outs.clone(), hid.clone(), ret_dict

@@ -127,10 +127,35 @@ def cast_pack(src, n0, n1, n1p, ncol, s0, s1, sc, ldd, out=None):
     return out
 
 
+_PACK_CACHE = None      # see packed_weights()
+
+
+class packed_weights(object):
+    """Scope in which the bf16 operand copy of a weight matrix is made once and reused: a free-running decode calls the
+    same projection and recurrence weights once per token, and nothing updates them in between (decoders.py:243-262 runs
+    under the caller's no-grad evaluation or between two optimizer steps).  Never keep it open across an optimizer step."""
+
+    def __enter__(self):
+        global _PACK_CACHE
+        self.prev, _PACK_CACHE = _PACK_CACHE, ({} if _PACK_CACHE is None else _PACK_CACHE)
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_CACHE
+        _PACK_CACHE = self.prev
+        return False
+
+
 def pack_matrix(w, ld=None):
     """fp32 [R,C] contiguous -> bf16 [R][ld] (ld = round_up(C,64) by default)."""
     R, Cc = w.shape
     ld = round_up(Cc, 64) if ld is None else ld
+    if _PACK_CACHE is not None:
+        key = (w.data_ptr(), R, Cc, tuple(w.stride()), ld)
+        hit = _PACK_CACHE.get(key)
+        if hit is None:
+            hit = _PACK_CACHE[key] = cast_pack(w.contiguous(), 1, R, R, Cc, 0, Cc, 1, ld)
+        return hit
     return cast_pack(w.contiguous(), 1, R, R, Cc, 0, Cc, 1, ld)
 
 

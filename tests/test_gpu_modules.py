@@ -319,6 +319,34 @@ def test_decoder_gen_fused_greedy(dev, mask_unk):
     close(lp_f, logp.gather(2, seq.unsqueeze(-1)).squeeze(-1).cpu(), rtol=0, atol=1e-4)
 
 
+def test_decoder_gen_graphed_greedy(dev):
+    """Opt-in graph_decode: the whole greedy decode replayed from one HIP graph gives what the eager fused path gives --
+    for the inputs it was captured with, for new inputs, and after the weights have changed."""
+    from pevae_amd.enc2dec import decoders as D
+    g = load_golden("decoder_gen_greedy")
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb), g).to(dev)
+    dec.eval()
+    dec.fused_greedy = True
+    ids = T(g["ids"], dev)
+    gen = torch.Generator().manual_seed(5)
+    states = [T(g["h0"], dev), torch.randn(g["h0"].shape, generator=gen).to(dev), T(g["h0"], dev) * 0.5]
+    with torch.no_grad():
+        for k, h0 in enumerate(states):
+            if k == 2:
+                dec.project.weight.mul_(1.5)                  # a replay must see updated parameters
+                dec.rnn.weight_hh_l0.add_(0.05)
+            dec.graph_decode = False
+            lp_e, hid_e, ret_e = dec(B, ids, h0, mode=D.GEN, gen_type="greedy")
+            dec.graph_decode = True
+            lp_g, hid_g, ret_g = dec(B, ids, h0, mode=D.GEN, gen_type="greedy")
+            assert torch.equal(torch.cat(ret_e["sequence"], 1), torch.cat(ret_g["sequence"], 1)), k
+            assert ret_e["length"] == ret_g["length"]
+            assert torch.equal(lp_e, lp_g) and torch.equal(hid_e, hid_g), k
+    assert len(dec._decode_graphs) == 1
+
+
 def test_vocab_argmax_large(dev):
     """pv_vocab_argmax at the step's vocabulary (V = 20004, ragged last slab) against torch on the same bf16 operands."""
     from pevae_amd import ops
