@@ -23,6 +23,24 @@ __global__ void cast_pack_kernel(const float* __restrict__ src, int n0, int n1, 
   }
 }
 
+// the same for unit column stride and 4-element alignment: one 16-byte load and one 8-byte store per thread
+__global__ void cast_pack_vec4_kernel(const float* __restrict__ src, int n0, int n1, int n1p, int C, long s0, long s1,
+                                      bf16_t* __restrict__ dst, int ldd) {
+  const int q = ldd / 4;
+  const long total = (long)n0 * n1 * q;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % q) * 4;
+    const long r = i / q;
+    const int i1 = (int)(r % n1);
+    const long i0 = r / n1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) v = *(const f32x4*)(src + i0 * s0 + i1 * s1 + c);
+    ushort4 o;
+    o.x = f2bf(v[0]); o.y = f2bf(v[1]); o.z = f2bf(v[2]); o.w = f2bf(v[3]);
+    *(ushort4*)(dst + (i0 * n1p + i1) * ldd + c) = o;
+  }
+}
+
 // dst[c*ldd + r] = bf16(src[r*lds + c]) for r < R, c < C; dst columns R..Rpad zero-filled.  64x64 LDS tiles.
 template <typename TS>
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restrict__ src, int R, int C, long lds_,
@@ -310,6 +328,13 @@ extern "C" {
 int pv_cast_pack_bf16(const float* src, int n0, int n1, int n1p, int C, long s0, long s1, long sc, void* dst,
                       int ldd, void* stream) {
   PV_REQUIRE(src && dst && n0 > 0 && n1 > 0 && n1p >= n1 && C > 0 && ldd >= C, "pv_cast_pack_bf16: bad argument");
+  if (sc == 1 && C % 4 == 0 && ldd % 4 == 0 && s0 % 4 == 0 && s1 % 4 == 0 && ((uintptr_t)src & 15) == 0 &&
+      ((uintptr_t)dst & 7) == 0) {
+    hipLaunchKernelGGL(cast_pack_vec4_kernel, dim3(grid_for((long)n0 * n1 * (ldd / 4), 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, n0, n1, n1p, C, s0, s1, (bf16_t*)dst, ldd);
+    PV_LAUNCH_CHECK("cast_pack_vec4_kernel");
+    return PV_OK;
+  }
   hipLaunchKernelGGL(cast_pack_kernel, dim3(grid_for((long)n0 * n1 * ldd, 256)), dim3(256), 0, (hipStream_t)stream,
                      src, n0, n1, n1p, C, s0, s1, sc, (bf16_t*)dst, ldd);
   PV_LAUNCH_CHECK("cast_pack_kernel");

@@ -565,7 +565,8 @@ struct EpiLogProb {
   }
 };
 
-// combine the per-slab (max, sumexp) partials: 64 rows per block, 4 slab-strided lanes per row
+// combine the per-slab (max, sumexp) partials: 16 rows per block, 16 slab-strided lanes per row (a lane's dependent
+// chain is nslab/16 = 20 links at the Yelp vocabulary), then the 16 lane results of a row in lane order through LDS
 __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float2* __restrict__ part,
                                                             const float* __restrict__ tgt_logit,
                                                             const int64_t* __restrict__ target, int T,
@@ -573,12 +574,12 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float2* __restr
                                                             const int* __restrict__ live_rows,
                                                             float* __restrict__ lse,
                                                             float* __restrict__ nll) {
-  __shared__ float sm[4][64], ss[4][64];
-  const int r = threadIdx.x & 63, y = threadIdx.x >> 6;
-  const int row = blockIdx.x * 64 + r;
+  __shared__ float sm[16][16], ss[16][16];
+  const int r = threadIdx.x & 15, y = threadIdx.x >> 4;
+  const int row = blockIdx.x * 16 + r;
   if (live_rows) {                                   // tiles past the live rows were never computed
     const int lim = (*live_rows + 127) / 128 * 128;
-    if ((int)blockIdx.x * 64 >= lim) {
+    if ((int)blockIdx.x * 16 >= lim) {
       if (y == 0 && row < T) {
         lse[row] = 0.f;
         nll[row] = 0.f;
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float2* __restr
   }
   float m = -INFINITY, s = 0.f;
   if (row < T) {
-    for (int k = y; k < nslab; k += 4) {
+    for (int k = y; k < nslab; k += 16) {
       const float2 p = part[(size_t)k * Tpad + row];
       const float mn = fmaxf(m, p.x);
       s = s * __expf(m - mn) + p.y * __expf(p.x - mn);
@@ -601,10 +602,10 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float2* __restr
   if (y == 0 && row < T) {
     float M = sm[0][r];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) M = fmaxf(M, sm[k][r]);
+    for (int k = 1; k < 16; ++k) M = fmaxf(M, sm[k][r]);
     float S = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) S += ss[k][r] * __expf(sm[k][r] - M);
+    for (int k = 0; k < 16; ++k) S += sm[k][r] == -INFINITY ? 0.f : ss[k][r] * __expf(sm[k][r] - M);
     const float l = M + logf(S);
     lse[row] = l;
     const int64_t t = target[row];
@@ -909,7 +910,7 @@ int pv_vocab_nll_fwd(const void* h, int ldh, const void* W, int ldw, const float
   EpiSoftmax e{bias, target, part, tgt_logit, T, V, Tpad, inv_temp};
   rc = big_tile(T, V, H) ? launch<decltype(e), 4>(g, e, st, "pv_vocab_nll_fwd") : launch(g, e, st, "pv_vocab_nll_fwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(vocab_reduce_kernel, dim3(cdiv(T, 64)), dim3(256), 0, st, part, tgt_logit, target, T,
+  hipLaunchKernelGGL(vocab_reduce_kernel, dim3(cdiv(T, 16)), dim3(256), 0, st, part, tgt_logit, target, T,
                      Tpad, nslab, ignore_index, live_rows, lse, nll);
   PV_LAUNCH_CHECK("vocab_reduce_kernel");
   return PV_OK;

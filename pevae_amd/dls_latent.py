@@ -152,7 +152,8 @@ class DLSAuto(nn.Module):
     def forward(self, output, rec_output, act1, act2, restarted=False, noise=None):
         cfg = self.config
         cip, ew, cw = getattr(cfg, "cip_weight", 1.0), cfg.expand_weight, cfg.converge_weight
-        rkl = ops.cons_loss(output, rec_output) * cip
+        scaled = (lambda v: v) if cip == 1.0 else (lambda v: v * cip)     # cip_weight = 1 (the default): no launch
+        rkl = scaled(ops.cons_loss(output, rec_output))
         last_sample = last_t = None
         for i, (layer, dis, dis2) in enumerate(zip(self.layers, self.dis_layers, self.dis_layers2)):
             a1, a2 = act1[-i - 1], act2[-i - 1]
@@ -176,7 +177,7 @@ class DLSAuto(nn.Module):
                 # sample (:3292/:3299-3300), output (:3310) and ew * KL(t || q.detach) + cw * KL(t.detach || q) (:3305-3306)
                 last_sample, output, klw = ops.DlsLevel.apply(res[2], res[0], a2, eps, lay_out, float(ew), float(cw))
                 last_t = t_mean
-                rkl = rkl + klw + ops.cons_loss(a1, a2) * cip                                      # :3307
+                rkl = rkl + klw + scaled(ops.cons_loss(a1, a2))                                    # :3307
             else:
                 if self.training:
                     eps = noise[i] if noise is not None else torch.rand_like(t_lv)
