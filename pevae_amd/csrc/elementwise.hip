@@ -64,6 +64,47 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const TS* __restric
   }
 }
 
+// The same with 16-byte global accesses on both sides (source rows read as 8 bf16 / 4 fp32 per lane, destination rows
+// written as 8 bf16 per lane); the element-wise kernel above moved 128 bytes per wave instruction.  Needs C % 8 == 0 for
+// nothing (columns are clamped), but 16-byte aligned rows on both sides: see pv_transpose_to_bf16.
+template <typename TS>
+__global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const TS* __restrict__ src, int R, int C, long lds_,
+                                                                  bf16_t* __restrict__ dst, long ldd, int Rpad) {
+  constexpr int EPL = 16 / sizeof(TS);                 // source elements per 16-byte load: 8 (bf16) or 4 (fp32)
+  constexpr int CPR = 64 / EPL;                        // loads per 64-column tile row
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];   // [column][row], 144-byte pitch
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int it = 0; it < 64 * CPR / 256; ++it) {
+    const int idx = threadIdx.x + it * 256, r = idx / CPR, ch = idx % CPR, c = c0 + ch * EPL;
+    bf16_t v[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = 0;
+    if (r0 + r < R && c < C) {                         // C is a multiple of EPL (checked by the host): whole chunk valid
+      const TS* p = src + (size_t)(r0 + r) * lds_ + c;
+      if constexpr (sizeof(TS) == 4) {
+        const f32x4 q = *(const f32x4*)p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f2bf(q[e]);
+      } else {
+        const uint4 q = *(const uint4*)p;
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)(w[e >> 1] >> (16 * (e & 1)));
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) tile[ch * EPL + e][r] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = threadIdx.x + it * 256, cc = idx >> 3, rch = idx & 7;
+    if (c0 + cc < C && r0 + rch * 8 < Rpad)
+      *(uint4*)(dst + (size_t)(c0 + cc) * ldd + r0 + rch * 8) = *(const uint4*)(&tile[cc][rch * 8]);
+  }
+}
+
 // mode 0: logvar = log sigma^2 (NormKLLoss);  mode 1: inputs are log sigma (gaussian_analytical_kl).
 // z = mu_q + exp(lv_q) * eps in both (the reference's std = exp(logvar), dialog_models.py:194).
 __global__ void reparam_kl_fwd_kernel(const float* __restrict__ mq, const float* __restrict__ lq,
@@ -345,6 +386,18 @@ int pv_transpose_to_bf16(const void* src, int src_is_f32, int R, int C, long lds
                          void* stream) {
   PV_REQUIRE(src && dst && R > 0 && C > 0 && lds_ >= C && Rpad >= R && ldd >= Rpad, "pv_transpose_to_bf16: bad argument");
   dim3 grid(cdiv(C, 64), cdiv(Rpad, 64));
+  const int epl = src_is_f32 ? 4 : 8;
+  if (C % epl == 0 && lds_ % epl == 0 && ((uintptr_t)src & 15) == 0 && Rpad % 8 == 0 && ldd % 8 == 0 &&
+      ((uintptr_t)dst & 15) == 0) {
+    if (src_is_f32)
+      hipLaunchKernelGGL(transpose_bf16_vec_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, R, C,
+                         lds_, (bf16_t*)dst, ldd, Rpad);
+    else
+      hipLaunchKernelGGL(transpose_bf16_vec_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                         R, C, lds_, (bf16_t*)dst, ldd, Rpad);
+    PV_LAUNCH_CHECK("transpose_bf16_vec_kernel");
+    return PV_OK;
+  }
   if (src_is_f32)
     hipLaunchKernelGGL(transpose_bf16_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, R, C,
                        lds_, (bf16_t*)dst, ldd, Rpad);

@@ -437,3 +437,20 @@ def test_dp_sparse_pack_merge_on_device(dev):
         if r == 0:
             first = mine.clone()
     assert torch.equal(first, mine)                        # both "ranks" end with the same bits
+
+
+@pytest.mark.parametrize("R,C,lds", [(200, 96, 96), (130, 512, 520), (77, 100, 100), (64, 36, 40), (300, 30, 30)])
+def test_transpose_to_bf16_both_paths(dev, R, C, lds):
+    """pv_transpose_to_bf16 from fp32 and from bf16 sources: shapes that take the 16-byte path and shapes that fall back
+    to the element-wise kernel, zero fill of the padded columns; bit-exact (a cast and a copy)."""
+    from pevae_amd import ops
+    g = torch.Generator().manual_seed(R + C)
+    src = torch.randn(R, lds, generator=g)
+    rpad = ops.round_up(R, 64)
+    for dt in (torch.float32, torch.bfloat16):
+        s = src.to(dt).to(dev)
+        out = torch.full((C, rpad), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.transpose_to_bf16(s, R, C, lds, rpad, out=out)
+        want = torch.zeros(C, rpad, dtype=torch.bfloat16)
+        want[:, :R] = src[:, :C].to(dt).to(torch.bfloat16).t()
+        assert torch.equal(out.cpu(), want), (dt, R, C)
