@@ -37,6 +37,12 @@ int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N
                     int bias_per_row, float* C, int ldc, void* Cb, int ldcb, int accumulate, const int* m_live,
                     const int* k_live, void* stream);
 
+/* The same product stored transposed, fp32: Ct[n * ldct + m] = sum_k A[m][k] B[n][k] + bias[n] (M % 4 == 0, ldct % 4 == 0).
+ * A lane's four accumulator rows are 16 contiguous bytes of C^T.  Builds xprojT [3H][tokens] of the recurrence
+ * (base_modules.py:42 input-to-hidden product) from A = tokens x E, B = W_ih. */
+int pv_gemm_bf16_nt_ct(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, float* Ct,
+                       int ldct, void* stream);
+
 /* Split-K form for weight-gradient GEMMs with few output tiles and a long K (dW_ih / dW_hh of the GRU: K = all
  * L*B tokens): `splits` slices of K are computed by separate workgroups into fp32 slabs of `workspace`
  * (pv_gemm_splitk_ws_bytes) and summed in slice order by a second kernel (bitwise reproducible, no atomics);

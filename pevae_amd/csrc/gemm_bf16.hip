@@ -184,11 +184,26 @@ struct EpiStore {
   const float* bias;
   int M, N, ldc, ldcb, accumulate, bias_per_row;
   long split_stride;   // split-K: slab `split` of the fp32 output starts at C + split * split_stride
+  int transposed;      // fp32 only: store C^T, C[(col) * ldc + row] -- a lane's 4 accumulator rows are 16 contiguous bytes
   struct Pre {};
   __device__ Pre prefetch(int, int, int) const { return Pre{}; }
   __device__ void operator()(f32x4 (&acc)[4][4], const Pre&, int row0, int col0, int w, int lane, char* smem, int split) const {
     const int c16 = lane & 15, q4 = lane >> 4;
     float* C = this->C ? this->C + (long)split * split_stride : nullptr;
+    if (transposed) {          // host guarantees M % 4 == 0, ldc % 4 == 0, 16-byte aligned C, no accumulate, bias per column
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int col = col0 + ni * 16 + c16;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int row = row0 + mi * 16 + q4 * 4;
+          if (row < M) *(f32x4*)(C + (size_t)col * ldc + row) = acc[mi][ni] + bv;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int col = col0 + ni * 16 + c16;
@@ -784,8 +799,23 @@ int pv_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N
   PV_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N), "pv_gemm_bf16_nt: output leading dimension < N");
   GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, 1, 0, m_live, k_live};
   PV_REQUIRE(!accumulate || C, "pv_gemm_bf16_nt: accumulate needs the fp32 output");
-  EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb, accumulate, bias_per_row, 0};
+  EpiStore e{C, (bf16_t*)Cb, bias, M, N, ldc, ldcb, accumulate, bias_per_row, 0, 0};
   return launch(g, e, (hipStream_t)stream, "pv_gemm_bf16_nt");
+}
+
+/* C^T (+bias per column of C) in fp32: Ct[n * ldct + m] = sum_k A[m][k] B[n][k] + bias[n].  The accumulator layout gives
+ * every lane four consecutive m of one n, so the transposed image leaves as 16-byte stores (the row-major epilogue
+ * stores 4 bytes per lane).  Used for the recurrence's input projections, which the kernels read unit-major:
+ * xprojT [3H][tokens] = (x W_ih^T + b_ih)^T with A = x, B = W_ih. */
+int pv_gemm_bf16_nt_ct(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, float* Ct,
+                       int ldct, void* stream) {
+  int rc = check_gemm(A, B, M, N, K, lda, ldb, "pv_gemm_bf16_nt_ct");
+  if (rc) return rc;
+  PV_REQUIRE(Ct && M % 4 == 0 && ldct % 4 == 0 && ldct >= M && ((uintptr_t)Ct & 15) == 0,
+             "pv_gemm_bf16_nt_ct: M and ldct must be multiples of 4, ldct >= M, Ct 16-byte aligned");
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, 1, 0, nullptr, nullptr};
+  EpiStore e{Ct, nullptr, bias, M, N, ldct, 0, 0, 0, 0, 1};
+  return launch(g, e, (hipStream_t)stream, "pv_gemm_bf16_nt_ct");
 }
 
 #ifdef PV_GEMM_DEBUG
@@ -848,7 +878,7 @@ int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M
   // resident workgroups once
   const int slots = m_live ? persistent_grid() : 0;
   GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, splits, slots, m_live, k_live};
-  EpiStore e{(float*)workspace, nullptr, nullptr, M, N, N, 0, 0, 0, (long)M * N};
+  EpiStore e{(float*)workspace, nullptr, nullptr, M, N, N, 0, 0, 0, (long)M * N, 0};
   hipStream_t st = (hipStream_t)stream;
   rc = launch(g, e, st, "pv_gemm_bf16_nt_splitk");
   if (rc) return rc;

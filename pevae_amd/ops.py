@@ -182,6 +182,13 @@ def gemm_nt(A, lda, Bm, ldb, M, N, K, bias=None, out=None, out_bf16=None, accumu
     return out if out is not None else out_bf16
 
 
+def gemm_nt_ct(A, lda, Bm, ldb, M, N, K, bias, out_t):
+    """out_t[N, M] = (A[M,K] B[N,K]^T + bias[N])^T in fp32, stored with 16-byte stores (pv_gemm_bf16_nt_ct)."""
+    _need_cuda(A, Bm, out_t)
+    _lib.call("pv_gemm_bf16_nt_ct", _p(A), lda, _p(Bm), ldb, M, N, K, _p(bias), _p(out_t), out_t.stride(0), _stream())
+    return out_t
+
+
 def gemm_nt_wgrad(A, lda, Bm, ldb, M, N, K, sink=None, k_live=None):
     """Weight-gradient GEMM C[M,N] = A[M,K] B[N,K]^T whose K is the token count: split-K over ~2 workgroups per CU when
     the plain tiling would leave most of the chip idle.  Accumulates into `sink` when given, else returns C."""
@@ -443,8 +450,8 @@ class GRULayer(torch.autograd.Function):
         wih_bf = pack_matrix(w_ih, Ep)
         whh_bf = pack_matrix(w_hh, Hk)
         # xproj^T [3H][L*Bpad]: the weight is the A operand, so a lane of the recurrence finds its 4 batch rows in 16 bytes
-        xprojT = gemm_nt(wih_bf, Ep, x_bf, Ep, 3 * H, L * Bpad, Ep, bias=b_ih.contiguous(), bias_per_row=True,
-                         out=workspace("gru_xprojT", 3 * H * L * Bpad, torch.float32, dev).view(3 * H, L * Bpad))
+        xprojT = gemm_nt_ct(x_bf, Ep, wih_bf, Ep, L * Bpad, 3 * H, Ep, b_ih.contiguous(),
+                            workspace("gru_xprojT", 3 * H * L * Bpad, torch.float32, dev).view(3 * H, L * Bpad))
         hseq = torch.empty(((L + 1) * Bpad, Hk), dtype=BF16, device=dev)
         hn = torch.empty((B, H), dtype=torch.float32, device=dev)
         gsave = torch.empty((L * 4 * H, Bpad), dtype=torch.float32, device=dev) if save else None
@@ -521,8 +528,8 @@ class LSTMLayer(torch.autograd.Function):
         x_bf = cast_pack(x, L, B, Bpad, E, x.stride(1), x.stride(0), x.stride(2), Ep)
         wih_bf = pack_matrix(w_ih, Ep)
         whh_bf = pack_matrix(w_hh, Hk)
-        xprojT = gemm_nt(wih_bf, Ep, x_bf, Ep, 4 * H, L * Bpad, Ep, bias=b_ih.contiguous(), bias_per_row=True,
-                         out=workspace("lstm_xprojT", 4 * H * L * Bpad, torch.float32, dev).view(4 * H, L * Bpad))
+        xprojT = gemm_nt_ct(x_bf, Ep, wih_bf, Ep, L * Bpad, 4 * H, Ep, b_ih.contiguous(),
+                            workspace("lstm_xprojT", 4 * H * L * Bpad, torch.float32, dev).view(4 * H, L * Bpad))
         hseq = torch.empty(((L + 1) * Bpad, Hk), dtype=BF16, device=dev)
         hn = torch.empty((B, H), dtype=torch.float32, device=dev)
         cn = torch.empty((B, H), dtype=torch.float32, device=dev)

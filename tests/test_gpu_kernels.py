@@ -454,3 +454,17 @@ def test_transpose_to_bf16_both_paths(dev, R, C, lds):
         want = torch.zeros(C, rpad, dtype=torch.bfloat16)
         want[:, :R] = src[:, :C].to(dt).to(torch.bfloat16).t()
         assert torch.equal(out.cpu(), want), (dt, R, C)
+
+
+def test_gemm_transposed_store_exact(dev):
+    """pv_gemm_bf16_nt_ct: C^T + bias per column of C, exact on integer data, ragged N and a leading dimension > M."""
+    from pevae_amd import ops
+    g = torch.Generator().manual_seed(23)
+    for (M, N, K, ld) in [(256, 100, 64, 256), (1000, 1536, 128, 1024), (132, 70, 192, 200)]:
+        A = torch.randint(-2, 3, (M, K), generator=g).float()
+        Bm = torch.randint(-2, 3, (N, K), generator=g).float()
+        bias = torch.randint(-3, 4, (N,), generator=g).float()
+        out = torch.full((N, ld), 9.0, device=dev)
+        ops.gemm_nt_ct(A.to(dev).to(torch.bfloat16), K, Bm.to(dev).to(torch.bfloat16), K, M, N, K, bias.to(dev), out)
+        assert torch.equal(out[:, :M].cpu(), (A @ Bm.t() + bias).t())
+        assert float((out[:, M:] - 9.0).abs().max()) == 0.0 if ld > M else True
