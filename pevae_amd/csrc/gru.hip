@@ -760,14 +760,28 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
 
 // hseq slot 0 / hstate <- h0 (or zeros); also used to zero padded rows
 __global__ void gru_pack_h0_kernel(const float* __restrict__ h0, int B, int H, int Hk, bf16_t* __restrict__ hseq0,
-                                   float* __restrict__ hstate, float* __restrict__ hall0) {
+                                   float* __restrict__ hstate, float* __restrict__ hall0, u32* __restrict__ sync,
+                                   int sync_words) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < sync_words) sync[i] = 0;                       // arrival counters and error word of the launch that follows
   if (i >= B * H) return;
   const int b = i / H, u = i % H;
   const float v = h0 ? h0[i] : 0.f;
   hseq0[(size_t)b * Hk + u] = f2bf(v);
   hstate[i] = v;
   if (hall0) hall0[i] = v;
+}
+
+// the backward launch's zero-initialised buffers in one pass (three to four memsets before)
+__global__ void rnn_bwd_zero_kernel(u32* __restrict__ sync, int sync_words, float* __restrict__ dh0, float* __restrict__ dc0,
+                                    long n_state, float* __restrict__ dbias_part, long n_part) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < sync_words) sync[i] = 0;
+  if (i < n_state) {
+    dh0[i] = 0.f;
+    if (dc0) dc0[i] = 0.f;
+  }
+  if (i < n_part) dbias_part[i] = 0.f;
 }
 
 __global__ void gru_bias_reduce_kernel(const float* __restrict__ part, int G, int H, int lstm, float* __restrict__ db_ih,
@@ -889,13 +903,13 @@ int rnn_fwd(int ngt, const float* xprojT, long ldx, const void* whh_bf16, const 
   const int xmap = xcd_map(G, S, cap), grid = xmap ? 8 * cdiv(G, 8) * S : G * S;
   u32* err = (u32*)sync + NG;
   u32* counters = err + 1;
-  PV_HIP(hipMemsetAsync(sync, 0, pv_gru_sync_bytes(B), st));
   if (Hk != H || Bpad != B) PV_HIP(hipMemsetAsync(hseq_bf16, 0, (size_t)(L + 1) * Bpad * Hk * 2, st));
   if (Bpad != B) {
     PV_HIP(hipMemsetAsync(hall, 0, (size_t)Bpad * H * sizeof(float), st));      // slot 0 rows >= B are read as states
     if (ngt == 4) PV_HIP(hipMemsetAsync(call, 0, (size_t)Bpad * H * sizeof(float), st));
   }
-  hipLaunchKernelGGL(gru_pack_h0_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, h0, B, H, Hk, (bf16_t*)hseq_bf16, hn, hall);
+  hipLaunchKernelGGL(gru_pack_h0_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, h0, B, H, Hk, (bf16_t*)hseq_bf16, hn, hall,
+                     (u32*)sync, (int)(pv_gru_sync_bytes(B) / sizeof(u32)));
   PV_LAUNCH_CHECK("gru_pack_h0_kernel");
   if (ngt == 4) {
     hipLaunchKernelGGL(lstm_pack_c0_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, c0, B, H, cn, call);
@@ -973,10 +987,12 @@ int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float*
   PV_REQUIRE(smem <= 160 * 1024, "pv_gru_bwd: LDS need %zu exceeds 160 KiB", smem);
   u32* err = (u32*)sync + NG;
   u32* counters = err + 1;
-  PV_HIP(hipMemsetAsync(sync, 0, pv_gru_sync_bytes(B), st));
-  PV_HIP(hipMemsetAsync(dh0, 0, (size_t)B * H * sizeof(float), st));
-  if (ngt == 4) PV_HIP(hipMemsetAsync(dc0, 0, (size_t)B * H * sizeof(float), st));
-  PV_HIP(hipMemsetAsync(dbias_part, 0, (size_t)2 * NG * 4 * H * sizeof(float), st));
+  {
+    const long n_state = (long)B * H, n_part = (long)2 * NG * 4 * H, n = n_state > n_part ? n_state : n_part;
+    hipLaunchKernelGGL(rnn_bwd_zero_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (u32*)sync,
+                       (int)(pv_gru_sync_bytes(B) / sizeof(u32)), dh0, ngt == 4 ? dc0 : nullptr, n_state, dbias_part, n_part);
+    PV_LAUNCH_CHECK("rnn_bwd_zero_kernel");
+  }
   if (K3 != ngt * H || Bpad != B) {
     if (dgi_bf16) PV_HIP(hipMemsetAsync(dgi_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
     PV_HIP(hipMemsetAsync(dgh_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
