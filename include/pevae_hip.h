@@ -283,6 +283,16 @@ int pv_dls_inputs_bwd(const float* dq, const float* dp, int B, int w, int e, flo
                       void* stream);
 /* DLS_Auto.cons_loss (:3266-3272): row L2 normalisation and the symmetric InfoNCE over a [B][B] score matrix with
  * the diagonal as targets: loss = (CE(log_softmax rows) + CE(log_softmax columns)) / 2. */
+/* DLS_Auto.cons_loss (dialog_models.py:3266-3272) for n <= 7 (v1, v2) pairs of [B, D[p]] rows at once: every pair of a
+ * training step depends only on the pyramids' activations, so the model's five calls (:3284, :3307 per level) become one
+ * launch per stage.  loss[0] = sum over pairs of (CE(log_softmax(alpha n1 n2^T, rows), diag) + CE(.., columns))/2 with
+ * n = rows / |rows|; v1 / v2 / dv1 / dv2: HOST arrays of n device pointers; ws: pv_cons_loss_ws_floats floats, kept by
+ * the caller from the forward to the backward call (it holds the normalised rows, scores and log-sum-exps); gout [1]. */
+size_t pv_cons_loss_ws_floats(const int* D, int n, int B);
+int pv_cons_loss_fwd(const float* const* v1, const float* const* v2, const int* D, int n, int B, float alpha, float* ws,
+                     float* loss, void* stream);
+int pv_cons_loss_bwd(const float* gout, const int* D, int n, int B, float* ws, float* const* dv1, float* const* dv2,
+                     void* stream);
 int pv_l2norm_rows_fwd(const float* x, int rows, int D, float* a, float* nrm, void* stream);
 int pv_l2norm_rows_bwd(const float* a, const float* nrm, const float* da, int rows, int D, float* dx, void* stream);
 int pv_infonce_fwd(const float* S, int B, float* lse_r, float* lse_c, float* loss, void* stream);

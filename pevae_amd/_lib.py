@@ -85,6 +85,9 @@ SIGNATURES = {
     "pv_spectral_norm_reduce": (i32, [vp, vp, vp, i32, i32, vp, i32, vp, vp]),
     "pv_linear_f32_fused": (i32, [vp, lng, lng, vp, lng, lng, vp, vp, lng, i32, i32, i32, f32, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
     "pv_spectral_norm_bwd": (i32, [vp, vp, vp, lng, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "pv_cons_loss_ws_floats": (sz, [vp, i32, i32]),
+    "pv_cons_loss_fwd": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp]),
+    "pv_cons_loss_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
     "pv_l2norm_rows_fwd": (i32, [vp, i32, i32, vp, vp, vp]),
     "pv_l2norm_rows_bwd": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "pv_infonce_fwd": (i32, [vp, i32, vp, vp, vp, vp]),

@@ -3,6 +3,7 @@
 // correction, row L2 normalisation and the symmetric InfoNCE loss of DLS_Auto.cons_loss (:3266-3272).
 // All of these are tiny (batch x <=1536) and latency bound: one wave per row, fixed-order reductions.
 #include "common.h"
+#include "linear_group.h"
 #include "../../include/pevae_hip.h"
 
 namespace {
@@ -455,9 +456,171 @@ __global__ void infonce_bwd_kernel(const float* __restrict__ S, const float* __r
   dS[k] = g[0] / (2.f * B) * (expf(s - lse_r[i]) + expf(s - lse_c[j]) - (i == j ? 2.f : 0.f));
 }
 
+// ---- DLS_Auto.cons_loss for several (v1, v2) pairs at once (dialog_models.py:3266-3272, called once per level :3307
+// and once on the outputs :3284): every pair of a step depends only on the pyramids' activations, so the 5 pairs of the
+// Yelp model are one launch per stage (normalise, scores, log-sum-exps, loss | dS, dn, dv) instead of 5 x 10 launches.
+constexpr int CONS_MAX = 7;                    // 2 * CONS_MAX weight... items must fit the grouped linear launch (15)
+struct ConsGroup {
+  const float* x[2 * CONS_MAX];                // v1_p at 2p, v2_p at 2p + 1
+  float* a[2 * CONS_MAX];                      // normalised rows [B][D]
+  float* aT[2 * CONS_MAX];                     // ... and their transposes [D][B] (the grouped GEMM wants K-major operands)
+  float* nrm[2 * CONS_MAX];
+  float* S[CONS_MAX];                          // [B][B] scores
+  float* lse_r[CONS_MAX];
+  float* lse_c[CONS_MAX];
+  float* dS[CONS_MAX];
+  float* dST[CONS_MAX];                        // dS^T
+  float* da[2 * CONS_MAX];                     // gradient of the normalised rows
+  float* dx[2 * CONS_MAX];                     // outputs of the backward pass
+  int D[CONS_MAX];
+  int n, B;
+};
+
+__global__ __launch_bounds__(256) void cons_l2norm_fwd_kernel(ConsGroup g, float alpha, float* __restrict__ alpha_dev) {
+  const int m = blockIdx.y, D = g.D[m >> 1];
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && m == 0 && threadIdx.x == 0) alpha_dev[0] = alpha;
+  if (r >= g.B) return;
+  const float* x = g.x[m] + (size_t)r * D;
+  float q = 0.f;
+  for (int c = lane; c < D; c += 64) q += x[c] * x[c];
+  const float n = sqrtf(wave_sum(q));
+  for (int c = lane; c < D; c += 64) {
+    const float v = x[c] / n;
+    g.a[m][(size_t)r * D + c] = v;
+    g.aT[m][(size_t)c * g.B + r] = v;
+  }
+  if (lane == 0) g.nrm[m][r] = n;
+}
+__global__ __launch_bounds__(256) void cons_l2norm_bwd_kernel(ConsGroup g) {
+  const int m = blockIdx.y, D = g.D[m >> 1];
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= g.B) return;
+  const float* a = g.a[m] + (size_t)r * D;
+  const float* da = g.da[m] + (size_t)r * D;
+  float d = 0.f;
+  for (int c = lane; c < D; c += 64) d += a[c] * da[c];
+  d = wave_sum(d);
+  const float inv = 1.f / g.nrm[m][r];
+  for (int c = lane; c < D; c += 64) g.dx[m][(size_t)r * D + c] = (da[c] - a[c] * d) * inv;
+}
+// blockIdx.y = 2p + which (0: rows, 1: columns)
+__global__ __launch_bounds__(256) void cons_lse_kernel(ConsGroup g) {
+  const int p = blockIdx.y >> 1, which = blockIdx.y & 1, B = g.B;
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B) return;
+  const long st = which ? B : 1;
+  const float* q = g.S[p] + (which ? i : (long)i * B);
+  float m = -INFINITY;
+  for (int j = lane; j < B; j += 64) m = fmaxf(m, q[j * st]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int j = lane; j < B; j += 64) s += expf(q[j * st] - m);
+  s = wave_sum(s);
+  if (lane == 0) (which ? g.lse_c[p] : g.lse_r[p])[i] = m + logf(s);
+}
+// loss[0] = sum_p ( mean_i(lse_r - S_ii) + mean_i(lse_c - S_ii) ) / 2, pairs added in index order (one block)
+__global__ __launch_bounds__(256) void cons_loss_kernel(ConsGroup g, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float total = 0.f;
+  for (int p = 0; p < g.n; ++p) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < g.B; i += 256) s += g.lse_r[p][i] + g.lse_c[p][i] - 2.f * g.S[p][(long)i * g.B + i];
+    s = block_sum(s, red);
+    total += s / (2.f * g.B);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = total;
+}
+__global__ void cons_bwd_kernel(ConsGroup g, const float* __restrict__ gout) {
+  const int p = blockIdx.y, B = g.B;
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (long)B * B) return;
+  const int i = (int)(k / B), j = (int)(k % B);
+  const float s = g.S[p][k];
+  const float d = gout[0] / (2.f * B) * (expf(s - g.lse_r[p][i]) + expf(s - g.lse_c[p][j]) - (i == j ? 2.f : 0.f));
+  g.dS[p][k] = d;
+  g.dST[p][(long)j * B + i] = d;
+}
+
+// workspace carve-up shared by the two entry points (floats): alpha | per pair: a1 a2 nrm1 nrm2 S lse_r lse_c dS da1 da2
+size_t cons_fill(ConsGroup& g, const int* D, int n, int B, float* ws) {
+  size_t o = 4;
+  g.n = n;
+  g.B = B;
+  for (int p = 0; p < n; ++p) {
+    g.D[p] = D[p];
+    const size_t bd = (size_t)B * D[p], bb = (size_t)B * B;
+    auto take = [&](size_t k) { float* q = ws ? ws + o : nullptr; o += (k + 3) & ~(size_t)3; return q; };
+    g.a[2 * p] = take(bd); g.a[2 * p + 1] = take(bd);
+    g.aT[2 * p] = take(bd); g.aT[2 * p + 1] = take(bd);
+    g.nrm[2 * p] = take(B); g.nrm[2 * p + 1] = take(B);
+    g.S[p] = take(bb); g.lse_r[p] = take(B); g.lse_c[p] = take(B);
+    g.dS[p] = take(bb); g.dST[p] = take(bb);
+    g.da[2 * p] = take(bd); g.da[2 * p + 1] = take(bd);
+  }
+  return o;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t pv_cons_loss_ws_floats(const int* D, int n, int B) {
+  ConsGroup g;
+  if (!D || n < 1 || n > CONS_MAX || B < 1) return 0;
+  return cons_fill(g, D, n, B, nullptr);
+}
+
+int pv_cons_loss_fwd(const float* const* v1, const float* const* v2, const int* D, int n, int B, float alpha, float* ws,
+                     float* loss, void* stream) {
+  PV_REQUIRE(v1 && v2 && D && ws && loss && n >= 1 && n <= CONS_MAX && B > 0, "pv_cons_loss_fwd: bad argument (1..%d pairs)", CONS_MAX);
+  hipStream_t st = (hipStream_t)stream;
+  ConsGroup g{};
+  cons_fill(g, D, n, B, ws);
+  LinGroupItem it[CONS_MAX];
+  for (int p = 0; p < n; ++p) {
+    PV_REQUIRE(v1[p] && v2[p] && D[p] > 0, "pv_cons_loss_fwd: bad pair %d", p);
+    g.x[2 * p] = v1[p];
+    g.x[2 * p + 1] = v2[p];
+    // S = alpha a1 a2^T from the K-major copies: A(m, k) = a1T[k][m], B(k, n) = a2T[k][n]
+    it[p] = LinGroupItem{g.aT[2 * p], 1, B, g.aT[2 * p + 1], B, 1, g.S[p], B, B, B, D[p], ws, 0, nullptr, 0, nullptr, nullptr};
+  }
+  hipLaunchKernelGGL(cons_l2norm_fwd_kernel, dim3(cdiv(B, 4), 2 * n), dim3(256), 0, st, g, alpha, ws);
+  PV_LAUNCH_CHECK("cons_l2norm_fwd_kernel");
+  int rc = pv_linear_f32_group(it, n, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cons_lse_kernel, dim3(cdiv(B, 4), 2 * n), dim3(256), 0, st, g);
+  PV_LAUNCH_CHECK("cons_lse_kernel");
+  hipLaunchKernelGGL(cons_loss_kernel, dim3(1), dim3(256), 0, st, g, loss);
+  PV_LAUNCH_CHECK("cons_loss_kernel");
+  return PV_OK;
+}
+
+int pv_cons_loss_bwd(const float* gout, const int* D, int n, int B, float* ws, float* const* dv1, float* const* dv2,
+                     void* stream) {
+  PV_REQUIRE(gout && D && ws && dv1 && dv2 && n >= 1 && n <= CONS_MAX && B > 0, "pv_cons_loss_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  ConsGroup g{};
+  cons_fill(g, D, n, B, ws);
+  LinGroupItem it[2 * CONS_MAX];
+  for (int p = 0; p < n; ++p) {
+    PV_REQUIRE(dv1[p] && dv2[p], "pv_cons_loss_bwd: null output %d", p);
+    g.dx[2 * p] = dv1[p];
+    g.dx[2 * p + 1] = dv2[p];
+    // da1 = alpha dS a2 : A(m, k) = dST[k][m] ;  da2 = alpha dS^T a1 : A(m, k) = dS[k][m] ;  B operands row-major [B][D]
+    it[2 * p] = LinGroupItem{g.dST[p], 1, B, g.a[2 * p + 1], D[p], 1, g.da[2 * p], D[p], B, D[p], B, ws, 0, nullptr, 0, nullptr, nullptr};
+    it[2 * p + 1] = LinGroupItem{g.dS[p], 1, B, g.a[2 * p], D[p], 1, g.da[2 * p + 1], D[p], B, D[p], B, ws, 0, nullptr, 0, nullptr, nullptr};
+  }
+  const long nn = (long)B * B;
+  hipLaunchKernelGGL(cons_bwd_kernel, dim3((unsigned)((nn + 255) / 256), n), dim3(256), 0, st, g, gout);
+  PV_LAUNCH_CHECK("cons_bwd_kernel");
+  int rc = pv_linear_f32_group(it, 2 * n, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cons_l2norm_bwd_kernel, dim3(cdiv(B, 4), 2 * n), dim3(256), 0, st, g);
+  PV_LAUNCH_CHECK("cons_l2norm_bwd_kernel");
+  return PV_OK;
+}
 
 int pv_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta, int rows, int D, float eps,
                      float* out, float* mean, float* rstd, void* stream) {

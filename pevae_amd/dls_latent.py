@@ -153,7 +153,15 @@ class DLSAuto(nn.Module):
         cfg = self.config
         cip, ew, cw = getattr(cfg, "cip_weight", 1.0), cfg.expand_weight, cfg.converge_weight
         scaled = (lambda v: v) if cip == 1.0 else (lambda v: v * cip)     # cip_weight = 1 (the default): no launch
-        rkl = scaled(ops.cons_loss(output, rec_output))
+        batched = not restarted and not getattr(cfg, "ost", False) and all(
+            a.shape[1] % 4 == 0 for a in list(act1) + [output]) and len(self.layers) < 7
+        if batched:
+            # every cons_loss of the train branch (:3284 and :3307 per level) reads only the pyramids' activations: one
+            # batched call up front instead of one chain of ten launches per level
+            nl = len(self.layers)
+            rkl = scaled(ops.cons_loss_sum([(output, rec_output)] + [(act1[-i - 1], act2[-i - 1]) for i in range(nl)]))
+        else:
+            rkl = scaled(ops.cons_loss(output, rec_output))
         last_sample = last_t = None
         for i, (layer, dis, dis2) in enumerate(zip(self.layers, self.dis_layers, self.dis_layers2)):
             a1, a2 = act1[-i - 1], act2[-i - 1]
@@ -177,7 +185,7 @@ class DLSAuto(nn.Module):
                 # sample (:3292/:3299-3300), output (:3310) and ew * KL(t || q.detach) + cw * KL(t.detach || q) (:3305-3306)
                 last_sample, output, klw = ops.DlsLevel.apply(res[2], res[0], a2, eps, lay_out, float(ew), float(cw))
                 last_t = t_mean
-                rkl = rkl + klw + scaled(ops.cons_loss(a1, a2))                                    # :3307
+                rkl = rkl + klw if batched else rkl + klw + scaled(ops.cons_loss(a1, a2))          # :3307
             else:
                 if self.training:
                     eps = noise[i] if noise is not None else torch.rand_like(t_lv)

@@ -1443,6 +1443,47 @@ class ScaledMatmulNT(torch.autograd.Function):
         return da, db, None
 
 
+class ConsLossSum(torch.autograd.Function):
+    """sum_p cons_loss(v1_p, v2_p) for up to 7 pairs in one launch per stage (pv_cons_loss_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, *vs):
+        _need_cuda(*vs)
+        vs = [v.contiguous() for v in vs]
+        n, B = len(vs) // 2, vs[0].shape[0]
+        dev = vs[0].device
+        D = (C.c_int * n)(*[int(vs[2 * p].shape[1]) for p in range(n)])
+        for p in range(n):
+            assert vs[2 * p].shape == vs[2 * p + 1].shape and vs[2 * p].shape[0] == B and vs[2 * p].shape[1] % 4 == 0
+        ws = torch.empty(_lib.load().pv_cons_loss_ws_floats(D, n, B), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        p1 = (C.c_void_p * n)(*[vs[2 * p].data_ptr() for p in range(n)])
+        p2 = (C.c_void_p * n)(*[vs[2 * p + 1].data_ptr() for p in range(n)])
+        _lib.call("pv_cons_loss_fwd", p1, p2, D, n, B, 1.1, _p(ws), _p(loss), _stream())
+        ctx.ws, ctx.meta = ws, (n, B, D, [tuple(v.shape) for v in vs])
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        n, B, D, shapes = ctx.meta
+        dev = ctx.ws.device
+        outs = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+        d1 = (C.c_void_p * n)(*[outs[2 * p].data_ptr() for p in range(n)])
+        d2 = (C.c_void_p * n)(*[outs[2 * p + 1].data_ptr() for p in range(n)])
+        _lib.call("pv_cons_loss_bwd", _p(g.contiguous().view(1)), D, n, B, _p(ctx.ws), d1, d2, _stream())
+        return tuple(outs)
+
+
+def cons_loss_sum(pairs):
+    """Sum of DLS_Auto.cons_loss over (v1, v2) pairs; batches of up to 7 pairs share their launches."""
+    total = None
+    for i in range(0, len(pairs), 7):
+        flat = [t for pr in pairs[i:i + 7] for t in pr]
+        part = ConsLossSum.apply(*flat)
+        total = part if total is None else total + part
+    return total
+
+
 def cons_loss(v1, v2):
     """DLS_Auto.cons_loss (dialog_models.py:3266-3272) with batch_arrange = arange(B)."""
     return InfoNCE.apply(ScaledMatmulNT.apply(L2NormRows.apply(v1), L2NormRows.apply(v2), 1.1))

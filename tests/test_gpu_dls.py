@@ -182,3 +182,24 @@ def test_den_auto_golden(dev):
     z3, _ = ref(T(g["output"], "cpu"), [T(g["act1_%d" % i], "cpu") for i in range(2)],
                 [T(g["act2_%d" % i], "cpu") for i in range(2)], True)
     close(z2, z3, rtol=1e-4, atol=1e-5)
+
+
+def test_cons_loss_sum_matches_single_calls(dev):
+    """The batched cons_loss (pv_cons_loss_fwd / _bwd: all pairs of a step in one launch per stage) against the sum of
+    the single-pair path (which is golden-tested above): value and every input gradient."""
+    from pevae_amd import ops
+    gen = torch.Generator().manual_seed(31)
+    B = 48
+    dims = [8, 64, 32, 16, 12]
+    pairs_a = [(torch.randn(B, d, generator=gen).to(dev).requires_grad_(), torch.randn(B, d, generator=gen).to(dev).requires_grad_())
+               for d in dims]
+    pairs_b = [(a.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()) for a, b in pairs_a]
+    tot_a = ops.cons_loss_sum(pairs_a)
+    tot_b = sum(ops.cons_loss(a, b) for a, b in pairs_b)
+    (tot_a * 0.7).backward()
+    (tot_b * 0.7).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(tot_a.detach()), float(tot_b.detach()), rtol=1e-5, atol=1e-5)
+    for (a, b), (c, d) in zip(pairs_a, pairs_b):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), c.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(b.grad.cpu().numpy(), d.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
