@@ -159,6 +159,12 @@ int pv_transpose_to_bf16(const void* src, int src_is_f32, int R, int C, long lds
 int pv_colsum_f32(const float* X, int R, long ld, int n, float* out, int accumulate, void* stream);
 /* out2[0] = sum of x[i] over i with mask[i] != ignore (all i when mask == NULL), out2[1] = their count */
 int pv_masked_sum(const float* x, const int64_t* mask, int64_t ignore, long n, float* out2, void* stream);
+/* Its backward, dx[i] = g[0] where mask[i] != ignore (everywhere when mask == NULL), and the row scale of the vocabulary
+ * backward, gscale[t] = dnll[perm ? perm[t] : t] * (target[t] != ignore): one launch each for what was a chain of
+ * fill / compare / cast / gather / multiply kernels behind criterions.py:55-64. */
+int pv_masked_sum_bwd(const int64_t* mask, int64_t ignore, const float* g, long n, float* dx, void* stream);
+int pv_vocab_gscale(const float* dnll, const int64_t* perm, const int64_t* target, int64_t ignore, int T, float* gscale,
+                    void* stream);
 /* dense-input NLL (criterions.py:57-63 on a materialised log-prob tensor): out[t] = -logp[t][target[t]] */
 int pv_pick_nll_fwd(const float* logp, const int64_t* target, int64_t ignore, int T, int V, float* out,
                     void* stream);

@@ -67,6 +67,8 @@ SIGNATURES = {
     "pv_cast_pack_bf16": (i32, [vp, i32, i32, i32, i32, lng, lng, lng, vp, i32, vp]),
     "pv_transpose_to_bf16": (i32, [vp, i32, i32, i32, lng, vp, lng, i32, vp]),
     "pv_colsum_f32": (i32, [vp, i32, lng, i32, vp, i32, vp]),
+    "pv_masked_sum_bwd": (i32, [vp, i64, vp, lng, vp, vp]),
+    "pv_vocab_gscale": (i32, [vp, vp, vp, i64, i32, vp, vp]),
     "pv_masked_sum": (i32, [vp, vp, i64, lng, vp, vp]),
     "pv_pick_nll_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "pv_pick_nll_bwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),

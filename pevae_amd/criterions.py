@@ -13,9 +13,7 @@ from .enc2dec.decoders import DeferredLogProbs
 def _token_nll(net_output, labels, padding_idx):
     """-> (sum of token NLL, number of non-pad tokens) as device scalars."""
     if isinstance(net_output, DeferredLogProbs):
-        nll, tgt = net_output.token_nll(labels, padding_idx)
-        sums = ops.MaskedSum.apply(nll, tgt, padding_idx)
-        return sums[0], sums[1]
+        return net_output.token_nll_sums(labels, padding_idx)
     flat = net_output.reshape(-1, net_output.size(-1))
     tgt = labels.reshape(-1)
     picked = ops.GatherNLL.apply(flat, tgt, padding_idx)

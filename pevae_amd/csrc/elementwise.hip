@@ -626,6 +626,43 @@ int pv_cat_rows_bwd(const float* log_q, const float* log_p, long log_p_numel, co
   return PV_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// backward of pv_masked_sum: dx[i] = g[0] where mask[i] != ignore (everywhere without a mask), else 0
+__global__ void masked_sum_bwd_kernel(const int64_t* __restrict__ mask, int64_t ignore, const float* __restrict__ g, long n,
+                                      float* __restrict__ dx) {
+  const float gv = g[0];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = (!mask || mask[i] != ignore) ? gv : 0.f;
+}
+// row scale of the vocabulary backward: gscale[t] = dnll[perm ? perm[t] : t] * (target[t] != ignore)
+__global__ void vocab_gscale_kernel(const float* __restrict__ dnll, const int64_t* __restrict__ perm,
+                                    const int64_t* __restrict__ target, int64_t ignore, int T, float* __restrict__ gscale) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x)
+    gscale[t] = target[t] != ignore ? dnll[perm ? perm[t] : t] : 0.f;
+}
+}  // namespace
+
+extern "C" {
+
+int pv_masked_sum_bwd(const int64_t* mask, int64_t ignore, const float* g, long n, float* dx, void* stream) {
+  PV_REQUIRE(g && dx && n >= 0, "pv_masked_sum_bwd: bad argument");
+  if (n == 0) return PV_OK;
+  hipLaunchKernelGGL(masked_sum_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, mask, ignore, g, n, dx);
+  PV_LAUNCH_CHECK("masked_sum_bwd_kernel");
+  return PV_OK;
+}
+
+int pv_vocab_gscale(const float* dnll, const int64_t* perm, const int64_t* target, int64_t ignore, int T, float* gscale,
+                    void* stream) {
+  PV_REQUIRE(dnll && target && gscale && T > 0, "pv_vocab_gscale: bad argument");
+  hipLaunchKernelGGL(vocab_gscale_kernel, dim3(grid_for(T, 256)), dim3(256), 0, (hipStream_t)stream, dnll, perm, target,
+                     ignore, T, gscale);
+  PV_LAUNCH_CHECK("vocab_gscale_kernel");
+  return PV_OK;
+}
+
 int pv_masked_sum(const float* x, const int64_t* mask, int64_t ignore, long n, float* out2, void* stream) {
   PV_REQUIRE(x && out2 && n >= 0, "pv_masked_sum: bad argument");
   hipLaunchKernelGGL(masked_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, mask, ignore, n, out2);

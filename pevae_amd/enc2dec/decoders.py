@@ -95,6 +95,16 @@ class DeferredLogProbs(object):
         self._nll_cache[key] = res
         return res
 
+    def token_nll_sums(self, labels, ignore_index):
+        """(sum of the token NLL, number of non-ignored tokens) as device scalars; NLLEntropy and Perplexity of one step
+        ask for the same pair, which is reduced once."""
+        key = ("sums", labels.data_ptr(), labels._version, tuple(labels.shape), ignore_index)
+        hit = self._nll_cache.get(key)
+        if hit is None:
+            nll, tgt = self.token_nll(labels, ignore_index)
+            hit = self._nll_cache[key] = ops.MaskedSum.apply(nll, tgt, ignore_index)
+        return hit[0], hit[1]
+
     # -- dense fallback: behaves like the reference's tensor ---------------------------------------------------
     def materialize(self):
         if self._dense is None:

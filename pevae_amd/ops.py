@@ -323,10 +323,9 @@ class VocabNLL(torch.autograd.Function):
         T, H, V, Hp, ldh, inv_temp, ignore_index = ctx.dims
         dev = w_bf.device
         Tp, Vp = round_up(T, 64), round_up(V, 64)
-        dn = dnll.to(torch.float32)
-        if perm is not None:
-            dn = dn.index_select(0, perm)              # `target` is already in compact order
-        gscale = (dn * (target != ignore_index)).contiguous()
+        gscale = torch.empty(T, dtype=torch.float32, device=dev)      # `target` is already in compact order
+        _lib.call("pv_vocab_gscale", _p(dnll.to(torch.float32).contiguous()), _p(perm), _p(target), ignore_index, T, _p(gscale),
+                  _stream())
         P = workspace("vocab_P", Tp * Vp, BF16, dev)
         PT = workspace("vocab_PT", Vp * Tp, BF16, dev)
         dbp = workspace("vocab_dbias_part", (Tp // 64) * Vp, torch.float32, dev)
@@ -954,8 +953,8 @@ class MaskedSum(torch.autograd.Function):
     def backward(ctx, dout):
         (m,) = ctx.saved_tensors
         has_mask, ignore, shape = ctx.meta
-        g = dout[0]
-        dx = (m != ignore).to(torch.float32) * g if has_mask else g.expand(m.shape).clone()
+        dx = torch.empty(m.numel(), dtype=torch.float32, device=m.device)
+        _lib.call("pv_masked_sum_bwd", _p(m) if has_mask else None, ignore, _p(dout.contiguous()), m.numel(), _p(dx), _stream())
         return dx.view(shape), None, None
 
 
