@@ -626,8 +626,11 @@ class EmbeddingLookup(torch.autograd.Function):
         dw = sink if sink is not None else torch.empty((rows, D), dtype=torch.float32, device=dev)
         nbytes = _lib.load().pv_embedding_bwd_ws_bytes(max(n, 1), D)
         ws = workspace("emb_bwd", nbytes, torch.uint8, dev)
-        g = dout.contiguous().view(-1, D)
-        _lib.call("pv_embedding_bwd", _p(g), D, _p(ids_c), n, max(n, 1), max(n, 1), 0, 1, rows, D, pad,
+        if dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= D and dout.stride(0) % 4 == 0:
+            g, ldg = dout, dout.stride(0)         # a column slice of a wider gradient (torch.cat backward): no copy
+        else:
+            g, ldg = dout.contiguous().view(-1, D), D
+        _lib.call("pv_embedding_bwd", _p(g), ldg, _p(ids_c), n, max(n, 1), max(n, 1), 0, 1, rows, D, pad,
                   1 if sink is not None else 0, _p(dw), _p(ws), nbytes, _stream())
         return (None if sink is not None else dw), None, None
 
