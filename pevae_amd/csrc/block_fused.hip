@@ -674,18 +674,6 @@ struct ParamReduceGroup {
   ParamReduceArgs r[PV_BLOCK_GROUP_MAX];
 };
 
-__global__ __launch_bounds__(256) void block_param_reduce_kernel(ParamReduceGroup grp) {
-  const ParamReduceArgs& a = grp.r[blockIdx.y];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.width) return;
-  float s = 0.f;
-  for (int g = 0; g < a.nwg; ++g) s += a.ppart[(size_t)g * a.width + c];     // fixed order
-  int seg = 0;
-  while (c >= a.seg_end[seg]) ++seg;
-  float* d = a.dst[seg] + (c - (seg ? a.seg_end[seg - 1] : 0));
-  *d = a.accumulate ? *d + s : s;
-}
-
 int check_dims(int M, int Din, int mid, int Dout, const char* who) {
   PV_REQUIRE(M > 0 && Din > 0 && mid > 0 && Dout > 0, "%s: empty shape", who);
   PV_REQUIRE(Din % 16 == 0 && mid % 16 == 0 && Dout % 16 == 0, "%s: widths %d/%d/%d must be multiples of 16", who, Din, mid, Dout);
@@ -838,9 +826,14 @@ int pv_block_bwd(const pv_block_call* calls, int n, void* stream) {
   if (rc) return rc;
   hipLaunchKernelGGL(block_bwd_dx_kernel, dim3(nwg_max, n), dim3(NT), smem, st, g);
   PV_LAUNCH_CHECK("block_bwd_dx_kernel");
-  hipLaunchKernelGGL(block_param_reduce_kernel, dim3(cdiv(width_max, 256), n), dim3(256), 0, st, pr);
-  PV_LAUNCH_CHECK("block_param_reduce_kernel");
-  return pv_linear_f32_group(it, 5 * n, st);       // the 5 n weight-gradient GEMMs in one launch
+  // the 5 n weight-gradient GEMMs in one launch, the bias / LayerNorm-parameter reductions riding on it
+  ColReduceJob jobs[PV_BLOCK_GROUP_MAX];
+  for (int b = 0; b < n; ++b) {
+    const ParamReduceArgs& r = pr.r[b];
+    jobs[b].part = r.ppart; jobs[b].nrows = r.nwg; jobs[b].width = r.width; jobs[b].accumulate = r.accumulate;
+    for (int i = 0; i < 7; ++i) { jobs[b].seg_end[i] = r.seg_end[i]; jobs[b].dst[i] = r.dst[i]; }
+  }
+  return pv_linear_f32_group(it, 5 * n, st, jobs, n);
 }
 
 }  // extern "C"

@@ -247,10 +247,28 @@ struct LinGroup {
   int tile_end[GROUP_MAX];     // exclusive prefix of tile counts
   int ntn[GROUP_MAX];          // tiles along N
   int n;
+  ColReduceJob jobs[COLREDUCE_MAX];
+  int job_end[COLREDUCE_MAX];  // exclusive prefix of the riders' workgroup counts, after the GEMM tiles
+  int njobs;
 };
 
 __global__ __launch_bounds__(256) void linear_f32_group_kernel(LinGroup G) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][TK * 48];
+  const int gemm_tiles = G.tile_end[G.n - 1];
+  if ((int)blockIdx.x >= gemm_tiles) {                  // a rider: 256 columns of one column-reduce job
+    int j = 0;
+    while (j + 1 < G.njobs && (int)blockIdx.x - gemm_tiles >= G.job_end[j]) ++j;
+    const ColReduceJob& a = G.jobs[j];
+    const int c = ((int)blockIdx.x - gemm_tiles - (j ? G.job_end[j - 1] : 0)) * 256 + threadIdx.x;
+    if (c >= a.width) return;
+    float s = 0.f;
+    for (int g = 0; g < a.nrows; ++g) s += a.part[(size_t)g * a.width + c];     // fixed order
+    int seg = 0;
+    while (c >= a.seg_end[seg]) ++seg;
+    float* d = a.dst[seg] + (c - (seg ? a.seg_end[seg - 1] : 0));
+    *d = a.accumulate ? *d + s : s;
+    return;
+  }
   int i = 0;
   while (i + 1 < G.n && (int)blockIdx.x >= G.tile_end[i]) ++i;
   const int local = blockIdx.x - (i ? G.tile_end[i - 1] : 0);
@@ -284,8 +302,9 @@ int pick_mode(const float* P, long sx, long sk, long bs, int batch) {
 
 }  // namespace
 
-int pv_linear_f32_group(const LinGroupItem* it, int n, hipStream_t st) {
+int pv_linear_f32_group(const LinGroupItem* it, int n, hipStream_t st, const ColReduceJob* jobs, int njobs) {
   PV_REQUIRE(it && n > 0 && n <= GROUP_MAX, "pv_linear_f32_group: bad item count %d", n);
+  PV_REQUIRE(njobs >= 0 && njobs <= COLREDUCE_MAX && (njobs == 0 || jobs), "pv_linear_f32_group: bad rider count %d", njobs);
   LinGroup G;
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
@@ -301,7 +320,14 @@ int pv_linear_f32_group(const LinGroupItem* it, int n, hipStream_t st) {
   }
   for (int i = n; i < GROUP_MAX; ++i) { G.g[i] = G.g[0]; G.tile_end[i] = tiles; G.ntn[i] = 1; }
   G.n = n;
-  hipLaunchKernelGGL(linear_f32_group_kernel, dim3(tiles), dim3(256), 0, st, G);
+  int riders = 0;
+  for (int j = 0; j < njobs; ++j) {
+    G.jobs[j] = jobs[j];
+    riders += cdiv(jobs[j].width, 256);
+    G.job_end[j] = riders;
+  }
+  G.njobs = njobs;
+  hipLaunchKernelGGL(linear_f32_group_kernel, dim3(tiles + riders), dim3(256), 0, st, G);
   PV_LAUNCH_CHECK("linear_f32_group_kernel");
   return PV_OK;
 }

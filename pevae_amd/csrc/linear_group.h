@@ -20,4 +20,16 @@ struct LinGroupItem {
   const float* r1_v;
 };
 
-int pv_linear_f32_group(const LinGroupItem* items, int n, hipStream_t st);
+// Optional rider of a grouped launch: column sums of per-workgroup partial rows, dst_seg[c - seg_begin] (+)= sum_g
+// part[g][c] in row order (the bias / LayerNorm-parameter gradients of a fused Block), done by extra workgroups of the
+// same launch instead of a launch of their own.
+struct ColReduceJob {
+  const float* part;     // [nrows][width]
+  int nrows, width;
+  int seg_end[7];        // exclusive ends of the 7 destination segments inside a row
+  float* dst[7];
+  int accumulate;
+};
+constexpr int COLREDUCE_MAX = 3;
+
+int pv_linear_f32_group(const LinGroupItem* items, int n, hipStream_t st, const ColReduceJob* jobs = nullptr, int njobs = 0);
