@@ -12,8 +12,9 @@
 //   block_fwd_kernel   : x -> out, saving a0 = gelu(x), y1, a1, y2, a2, y3, a3, y4, o = LN(x + y4), mean, rstd
 //   block_bwd_dx_kernel: dL/dout -> dL/dx, storing dy1..dy4 for the weight gradients and, per workgroup, partial
 //                        column sums (bias / LayerNorm parameter gradients) and partial <dy, y - b> (spectral term)
-//   block_param_reduce_kernel: fixed-order sum of the per-workgroup partials into the bias / gamma / beta gradients
-//   (+ pv_linear_f32_group: the five weight-gradient GEMMs dy^T a with the spectral rank-1 epilogue, one launch)
+//   (+ pv_linear_f32_group: the five weight-gradient GEMMs dy^T a with the spectral rank-1 epilogue, one launch; the
+//    fixed-order sums of the per-workgroup partials into the bias / gamma / beta gradients ride on the same launch as
+//    ColReduceJob riders in extra workgroups)
 //
 // Arithmetic: exact fp32 (v_mfma_f32_16x16x4_f32), like the unfused path; sums run in a different order.
 #include "common.h"
