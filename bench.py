@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--graph", type=int, default=1, help="replay fwd+bwd / optimizer from HIP graphs")
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-baseline steps (about 1.7 s each on 16 threads)")
     ap.add_argument("--dropout", type=float, default=0.3)
     ap.add_argument("--latent", default="dls", choices=["gauss", "dls"],
                     help="latent stack: 'dls' = the reference's DLS pyramid (DlsRec/DlsPri/DLS_Auto), 'gauss' = flat")

@@ -311,10 +311,13 @@ class VocabNLL(torch.autograd.Function):
         ctx.hid_dtype = hid.dtype
         ctx.params = (weight, bias)
         ctx.mark_non_differentiable(lse)
+        ctx.set_materialize_grads(False)
         return nll, lse
 
     @staticmethod
     def backward(ctx, dnll, _dlse):
+        if dnll is None:
+            return (None,) * 8
         if ctx.compact:
             h_bf, w_bf, bias, target, lse, perm, count = ctx.saved_tensors
         else:
@@ -470,6 +473,7 @@ class GRULayer(torch.autograd.Function):
         ctx.has_h0 = h0 is not None
         ctx.sync = sync
         ctx.mark_non_differentiable(hseq)
+        ctx.set_materialize_grads(False)    # an unused `out` / `h_n` (and hseq) arrives as None, not as a zero-filled tensor
         return out, hn, hseq
 
     @staticmethod
@@ -552,6 +556,7 @@ class LSTMLayer(torch.autograd.Function):
         ctx.lengths = lengths
         ctx.has_state = (h0 is not None, c0 is not None)
         ctx.mark_non_differentiable(hseq)
+        ctx.set_materialize_grads(False)
         return out, hn, cn, hseq
 
     @staticmethod
