@@ -103,3 +103,88 @@ def test_step_eval_and_second_backward_accumulates(dev):
     gpu.valid_loss(gpu(feed_d, eps=eps)).backward()
     for n, p in gpu.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), 2 * g1[n].cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=n)
+
+
+def test_step_full_size_oracle_and_properties(dev):
+    """BASELINE.json configs[1] at full size (bs=256, L=50, V=20004, H=512, DLS pyramid): the composed step against the
+    CPU oracle (a few seconds on the host cores), plus properties that hold at any size."""
+    from pevae_amd import ops
+    from pevae_amd.dls_vae import PAD_ID, default_config, synthetic_batch
+    cfg = default_config(dropout=0.0, batch_size=256, latent_stack="dls")
+    gpu, ref = _pair(cfg, dev)
+    gpu.train()
+    ref.train()
+    feed = synthetic_batch(cfg, 256, 4321)
+    feed_d = {k: v.to(dev) for k, v in feed.items()}
+    H = cfg.dec_cell_size
+    gen = torch.Generator().manual_seed(11)
+    eps = [torch.rand(256, d, generator=gen) for d in (H // 16, H // 8, H // 4)]
+    eps_d = [e.to(dev) for e in eps]
+
+    from pevae_amd.optim import FlatAdam
+    opt = FlatAdam(gpu.parameters(), lr=1e-4, max_norm=5.0, guards=False)     # gradients sink into the flat buffer, as in bench.py
+
+    buffers = {n: b.clone() for n, b in gpu.named_buffers()}      # spectral-norm u vectors advance on every training forward
+
+    def run(fd):
+        with torch.no_grad():
+            for n, b in gpu.named_buffers():
+                b.copy_(buffers[n])
+        opt.zero_grad()
+        loss = gpu(fd, eps=eps_d)
+        gpu.valid_loss(loss).backward()
+        torch.cuda.synchronize()
+        ops.gru_check_all()
+        return loss, {n: p.grad.clone() for n, p in gpu.named_parameters()}
+
+    loss, grads = run(feed_d)
+
+    # (1) the oracle at full size; tolerances as in test_step_matches_oracle (bf16 MFMA operands, fp32 accumulate)
+    loss_r = ref(feed, eps=eps)
+    ref.valid_loss(loss_r).backward()
+    assert abs(float(loss.vae_nll) - float(loss_r.vae_nll)) <= 2e-2 * abs(float(loss_r.vae_nll))
+    assert abs(float(loss.vae_rkl) - float(loss_r.vae_rkl)) <= 2e-2 * abs(float(loss_r.vae_rkl)) + 1e-4
+    for n, p in ref.named_parameters():
+        g, r = grads[n].cpu(), p.grad
+        scale = float(r.abs().max()) + 1e-9
+        assert float((g - r).abs().max()) <= 8e-2 * scale, (n, float((g - r).abs().max()), scale)
+        if r.numel() >= 4096:
+            cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-20))
+            assert cos > 0.99, (n, cos)
+
+    # (2) no atomics anywhere on the path: a second run reproduces every bit
+    loss2, grads2 = run(feed_d)
+    assert float(loss.vae_nll) == float(loss2.vae_nll) and float(loss.vae_rkl) == float(loss2.vae_rkl)
+    for n in grads:
+        assert torch.equal(grads[n], grads2[n]), n
+
+    # (3) softmax rows sum to one: the vocabulary bias gradient sums to zero over V
+    db = grads["x_decoder.project.bias"].double()
+    assert abs(float(db.sum())) <= 1e-3 * float(db.abs().sum())
+
+    # (4) rows nobody looked up carry exactly zero gradient (sorted segmented sum, no scatter over the table);
+    #     padding_idx row of the word table: nn.Embedding(padding_idx=0)
+    gw = grads["x_embedding.weight"]
+    used = torch.zeros(cfg.vocab_size, dtype=torch.bool, device=dev)
+    used[feed_d["sentence_embeddings"].reshape(-1)] = True
+    used[feed_d["input_ids"].reshape(-1)] = True
+    used[PAD_ID] = False
+    assert not gw[~used].any() and gw[used].abs().sum(1).gt(0).float().mean() > 0.99
+    for tab, key in (("user_embedding.weight", "user_ids"), ("item_embedding.weight", "item_ids")):
+        hit = torch.zeros(grads[tab].shape[0], dtype=torch.bool, device=dev)
+        hit[feed_d[key]] = True
+        assert not grads[tab][~hit].any(), tab
+
+    # (5) ignored targets: decoder inputs behind the last live target cannot move the loss or the vocabulary gradients'
+    #     live rows (NLLLoss(ignore_index=0), criterions.py:38-41) -- bit for bit, since the live rows are compacted
+    #     in the same order
+    fd = dict(feed_d)
+    ids = feed_d["input_ids"].clone()
+    live = feed_d["ans_ids"] != PAD_ID
+    last = (live.long() * torch.arange(ids.shape[1], device=dev)).max(1).values
+    behind = torch.arange(ids.shape[1], device=dev).unsqueeze(0) > last.unsqueeze(1)
+    ids[behind] = 7
+    fd["input_ids"] = ids
+    loss3, grads3 = run(fd)
+    assert float(loss3.vae_nll) == float(loss.vae_nll)
+    assert torch.equal(grads3["x_decoder.project.weight"], grads["x_decoder.project.weight"])
