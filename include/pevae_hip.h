@@ -95,6 +95,15 @@ int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const
 size_t pv_vocab_argmax_ws_bytes(int T, int V);
 int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H, float inv_temp,
                     int mask_col, void* workspace, int64_t* ids, float* logp, void* stream);
+/* No counterpart in the reference: pv_vocab_argmax for callers that cannot allocate or pass a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  The per-slab partials live in a device array
+ * built into the library (one copy per GPU, pv_vocab_argmax_noalloc_max_bytes() = 4 MiB, held until the process ends);
+ * no hipMalloc / hipFree / allocating call is made.  Returns PV_ERR_LIMIT (-3) when ceil(V/64) * round_up(T,64) * 16
+ * bytes exceed that size.  All calls on one GPU share the array: calls that overlap on one GPU (two streams) race.  The
+ * first call on a device looks the array's address up (hipGetSymbolAddress): make it outside stream capture. */
+int pv_vocab_argmax_noalloc(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H,
+                            float inv_temp, int mask_col, int64_t* ids, float* logp, void* stream);
+size_t pv_vocab_argmax_noalloc_max_bytes(void);
 /* Backward of the dense path: P = (dlogp - exp(logp) * rowsum(dlogp)) * inv_temp as bf16 [T][ldp] (+ dbias). */
 int pv_logsoftmax_bwd_bf16(const float* logp, const float* dlogp, int T, int V, float inv_temp, void* P, int ldp,
                            float* dbias, void* stream);

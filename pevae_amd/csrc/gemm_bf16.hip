@@ -19,6 +19,7 @@
 //   EpiLogProb   : dense log-softmax rows (API-compat path for callers that want [B,L,V])
 #include "common.h"
 #include "../../include/pevae_hip.h"
+#include <mutex>
 
 namespace {
 
@@ -749,6 +750,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// ---- scratch of pv_vocab_argmax_noalloc: one array per GPU, held until the process ends ----------------------------
+constexpr size_t ARGMAX_SCRATCH_BYTES = 4u << 20;      // e.g. 256 rows x 65 536 symbols, or 1 024 rows x 16 384
+static __device__ __align__(256) unsigned char scratch[ARGMAX_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+static void* scratch_dev_ptr[MAX_DEVICES];             // device address of `scratch` on each GPU (0 = not looked up yet)
+static std::mutex scratch_mutex;
+
+int argmax_scratch_for_current_device(void** out) {
+  int dev = 0;
+  PV_HIP(hipGetDevice(&dev));
+  PV_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "pv_vocab_argmax_noalloc: device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lock(scratch_mutex);
+  if (!scratch_dev_ptr[dev]) {
+    void* p = nullptr;
+    PV_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));       // with `dev` current: that GPU's copy
+    PV_REQUIRE(p && ((uintptr_t)p & 255) == 0, "pv_vocab_argmax_noalloc: bad scratch address %p", p);
+    scratch_dev_ptr[dev] = p;
+  }
+  *out = scratch_dev_ptr[dev];
+  return PV_OK;
+}
+
 int persistent_grid() {
   static int grid = 0;
   if (!grid) {
@@ -985,6 +1008,30 @@ int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float*
   PV_LAUNCH_CHECK("vocab_argmax_reduce_kernel");
   return PV_OK;
 }
+
+/* The same greedy step for callers that cannot allocate (HIP graph capture, tight serving loops): the per-slab partials
+ * live in a file-scope device array instead of a caller workspace.  Each GPU holds its own copy of that array at its own
+ * address, looked up once per device with hipGetSymbolAddress (the array's NAME is only a host-side stand-in, never a
+ * device address); every call on a GPU shares it, so calls that overlap on one GPU race.  Nothing has to start at zero:
+ * the GEMM epilogue writes every (slab, row) record the reduce kernel reads. */
+int pv_vocab_argmax_noalloc(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H,
+                            float inv_temp, int mask_col, int64_t* ids, float* logp, void* stream) {
+  int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_argmax_noalloc");
+  if (rc) return rc;
+  PV_REQUIRE(bias && ids && logp, "pv_vocab_argmax_noalloc: null argument");
+  const size_t need = pv_vocab_argmax_ws_bytes(T, V);
+  if (need > ARGMAX_SCRATCH_BYTES) {
+    pv_set_error("pv_vocab_argmax_noalloc: ceil(V/64) * round_up(T,64) * 16 = %zu bytes exceeds the built-in scratch of "
+                 "%zu bytes (T=%d, V=%d); use pv_vocab_argmax with a workspace", need, (size_t)ARGMAX_SCRATCH_BYTES, T, V);
+    return PV_ERR_LIMIT;
+  }
+  void* ws = nullptr;
+  rc = argmax_scratch_for_current_device(&ws);
+  if (rc) return rc;
+  return pv_vocab_argmax(h, ldh, W, ldw, bias, T, V, H, inv_temp, mask_col, ws, ids, logp, stream);
+}
+
+size_t pv_vocab_argmax_noalloc_max_bytes(void) { return ARGMAX_SCRATCH_BYTES; }
 
 int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const float* bias,
                            const float* lse, int T, int V, int H, float inv_temp, float* out, void* stream) {
