@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 1
+#define PV_ABI_VERSION 2
 
 const char* pv_last_error(void);
 int pv_abi_version(void);
@@ -326,13 +326,33 @@ int pv_softmax_rows_bwd(const float* y, const float* dy, int rows, int n, float*
 /* op 0: tanh(a); 1: b*(1-a^2) (a = tanh output); 2: gelu(a) (erf form, dialog_models.py:266-269); 3: b*gelu'(a) */
 int pv_unary_f32(const float* a, const float* b, long n, int op, float* out, void* stream);
 
+/* ---- dropout (nn.Dropout of encoders.py:54 and decoders.py:175,189) -------------------------------------------------
+ * y = x * keep / (1 - p) over a strided fp32 view [n0][n1][C] (element (i0, i1, c) at src[i0*s0 + i1*s1 + c*sc]).  keep
+ * comes from `mask` (uint8, 1 = keep) when given, else from Philox4x32-10 keyed by (seed, step) of `rng_state`
+ * (pv_rng_state_bytes() of device memory: {uint64 seed; uint64 step}), the call-site id `site` and the element's LOGICAL
+ * index i0*m0 + i1*m1 + c -- the same call on the upstream gradient is the backward pass (decisions are regenerated, no
+ * mask is stored), and any layout of the same logical tensor sees the same decisions.  pv_rng_advance: step += 1 (one
+ * thread; once per training step, so a replayed HIP graph draws fresh masks).  pv_dropout_pack_bf16 writes the result as
+ * the zero-padded bf16 GEMM operand rows i0*n1p + i1 of ldd elements (decoder states -> vocabulary projection). */
+size_t pv_rng_state_bytes(void);
+int pv_rng_advance(void* state, void* stream);
+int pv_dropout_f32(const float* src, int n0, int n1, int C, long s0, long s1, long sc, long m0, long m1, float p,
+                   const void* mask, const void* rng_state, int site, float* dst, long d0, long d1, void* stream);
+int pv_dropout_pack_bf16(const float* src, int n0, int n1, int n1p, int C, long s0, long s1, long sc, long m0, long m1,
+                         float p, const void* mask, const void* rng_state, int site, void* dst, int ldd, void* stream);
+
 /* ---- clip + skip guards + Adam over one flat buffer (main_pretrain.py:207-225,268-269;
  * dialog_models.py:122-131) ------------------------------------------------------------------------------------ */
+/* state: pv_optim_state_bytes() of device memory, zeroed once; its first 48 bytes are {float avg_norm; int have_avg,
+ * jump_cnt, batch_cnt, adam_step; float last_norm, clip_coef; int skip; float lr_eff, bc1, bc2; int skipped_total}.
+ * grad_scale: the gradient is grad_scale * grads (data parallel: grads = SUM over ranks, grad_scale = 1/world; norm,
+ * clip and update use the scaled values without another pass).  weight_decay: decoupled decay of torch.optim.AdamW
+ * (the freeze-phase optimizer, dialog_models.py:834: p *= 1 - lr * wd before the update); 0 = torch.optim.Adam. */
 size_t pv_optim_state_bytes(void);
 int pv_grad_guard(const float* grads, long n, void* state, float max_norm, float lr, int warmup_steps, float beta1,
-                  float beta2, int guards, void* stream);
+                  float beta2, int guards, float grad_scale, void* stream);
 int pv_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, const void* state,
-                 float beta1, float beta2, float eps, void* stream);
+                 float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

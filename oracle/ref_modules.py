@@ -80,6 +80,20 @@ def lstm_cell(x_t, h, c, w_ih, w_hh, b_ih, b_hh):
     return o * torch.tanh(c2), c2
 
 
+class MaskedDropout(nn.Module):
+    """nn.Dropout (encoders.py:54, decoders.py:175,189) with the keep mask supplied instead of drawn: y = x * keep / (1 - p)
+    in training mode.  Parity tests give the same mask to the HIP modules (pevae_amd.ops.Dropout.mask)."""
+
+    def __init__(self, mask, p):
+        super().__init__()
+        self.mask, self.p = mask, p
+
+    def forward(self, x):
+        if not self.training or self.p == 0:
+            return x
+        return x * self.mask.to(x.dtype).view(x.shape) / (1.0 - self.p)
+
+
 class RNNParams(nn.Module):
     """Parameter container with torch.nn.GRU/LSTM names (`weight_ih_l0`, `..._reverse`) and init.
 

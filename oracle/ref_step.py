@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from . import ref_modules as R
 
-PAD_ID, UNK_ID, BOS_ID, EOS_ID = 0, 1, 2, 3
+PAD_ID, UNK_ID, BOS_ID, EOS_ID = 0, 1, 4, 5      # [<pad>, <unk>, <sys>, <usr>] + words (corpora.py:649); dialog_models.py:455-456
 
 
 class RefDLSVAE(nn.Module):
@@ -19,12 +19,14 @@ class RefDLSVAE(nn.Module):
         c = self.config = config
         H, E, Z = c.dec_cell_size, c.embed_size, c.latent_size
         self.emb_size = H // 2
-        self.x_embedding = nn.Embedding(c.vocab_size, E, padding_idx=PAD_ID)
+        self.pad_id, self.unk_id = getattr(c, "pad_id", PAD_ID), getattr(c, "unk_id", UNK_ID)
+        self.go_id, self.eos_id = getattr(c, "bos_id", BOS_ID), getattr(c, "eos_id", EOS_ID)
+        self.x_embedding = nn.Embedding(c.vocab_size, E, padding_idx=self.pad_id)
         self.user_embedding = nn.Embedding(c.n_user, self.emb_size)
         self.item_embedding = nn.Embedding(c.n_item, self.emb_size)
         self.rating_embedding = nn.Embedding(5, self.emb_size)
         self.x_encoder = R.EncoderRNN(E, H, dropout_p=c.dropout, rnn_cell=c.rnn_cell, variable_lengths=False)
-        self.x_decoder = R.DecoderRNN(c.vocab_size, c.max_seq_len, E, H, BOS_ID, EOS_ID, UNK_ID,
+        self.x_decoder = R.DecoderRNN(c.vocab_size, c.max_seq_len, E, H, self.go_id, self.eos_id, self.unk_id,
                                       n_layers=c.num_layer, rnn_cell=c.rnn_cell, input_dropout_p=c.dropout,
                                       dropout_p=c.dropout, use_attention=c.use_attention, attn_mode=c.attn_type,
                                       attn_size=H, use_gpu=False, embedding=self.x_embedding)
@@ -33,7 +35,7 @@ class RefDLSVAE(nn.Module):
             self.rec_encoder = R.DlsPyramid(H, H // 16, c)
             self.pri_encoder = R.DlsPyramid(H, H // 16, c, wrap=True)
             self.sup_decoder = R.DLSAuto(H // 32, H // 8, c)
-            self.dls_connector = nn.Sequential(R.Block(H // 4, H // 2, H // 2), R.Block(H // 2, H, H))
+            self.x_init_connector = nn.Sequential(R.Block(H // 4, H // 2, H // 2), R.Block(H // 2, H, H))
         self.prior_fc = nn.Linear(3 * self.emb_size, H)
         if self.latent_stack == "gauss":
             self.rec_head = R.Hidden2Gaussian(H, Z)
@@ -41,8 +43,8 @@ class RefDLSVAE(nn.Module):
             self.x_init_connector = R.LinearConnector(Z, H, c.rnn_cell == "lstm")
         if c.do_pred:
             self.dnn = nn.Sequential(nn.Linear(2 * self.emb_size, H), nn.Linear(H, 1))
-        self.nll_loss = R.NLLEntropy(PAD_ID, c)
-        self.ppl = R.Perplexity(PAD_ID, c)
+        self.nll_loss = R.NLLEntropy(self.pad_id, c)
+        self.ppl = R.Perplexity(self.pad_id, c)
         self.kl_loss = R.NormKLLoss(unit_average=False)
 
     def use_aten_rnn(self, on=True):
@@ -73,7 +75,7 @@ class RefDLSVAE(nn.Module):
             z, rkl = self.sup_decoder(z_pri, z_rec, rec_state, pri_state, getattr(self, "restarted", False), noise=eps)
             if not self.training:
                 rkl = None
-            dec_init = self.dls_connector(z).unsqueeze(0)
+            dec_init = self.x_init_connector(z).unsqueeze(0)
         else:
             mu_q, lv_q = self.rec_head(h)
             mu_p, lv_p = self.pri_head(prior_h)

@@ -101,9 +101,13 @@ SIGNATURES = {
     "pv_softmax_rows": (i32, [vp, i32, i32, vp, vp]),
     "pv_softmax_rows_bwd": (i32, [vp, vp, i32, i32, vp, vp]),
     "pv_unary_f32": (i32, [vp, vp, lng, i32, vp, vp]),
+    "pv_rng_state_bytes": (sz, []),
+    "pv_rng_advance": (i32, [vp, vp]),
+    "pv_dropout_f32": (i32, [vp, i32, i32, i32, lng, lng, lng, lng, lng, f32, vp, vp, i32, vp, lng, lng, vp]),
+    "pv_dropout_pack_bf16": (i32, [vp, i32, i32, i32, i32, lng, lng, lng, lng, lng, f32, vp, vp, i32, vp, i32, vp]),
     "pv_optim_state_bytes": (sz, []),
-    "pv_grad_guard": (i32, [vp, lng, vp, f32, f32, i32, f32, f32, i32, vp]),
-    "pv_adam_step": (i32, [vp, vp, vp, vp, lng, vp, f32, f32, f32, vp]),
+    "pv_grad_guard": (i32, [vp, lng, vp, f32, f32, i32, f32, f32, i32, f32, vp]),
+    "pv_adam_step": (i32, [vp, vp, vp, vp, lng, vp, f32, f32, f32, f32, vp]),
 }
 
 _lib = None
@@ -127,7 +131,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.pv_abi_version() != 1:
+    if lib.pv_abi_version() != 2:
         raise ImportError("pevae_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = lib
     return lib

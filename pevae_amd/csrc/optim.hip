@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 
 __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ partial, int npart, OptState* st,
                                                      float max_norm, float lr, int warmup, float beta1, float beta2,
-                                                     int guards) {
+                                                     int guards, float grad_scale) {
   __shared__ float red[256];
   float s = 0.f;
   for (int i = threadIdx.x; i < npart; i += 256) s += partial[i];
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ pa
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
-  const float norm = sqrtf(red[0]);
+  // grad_scale: the buffer holds grad_scale^-1 times the gradient (a data-parallel SUM over `world` ranks with
+  // grad_scale = 1/world): norm, clip and update all see the scaled gradient without a pass over the buffer
+  const float norm = sqrtf(red[0]) * grad_scale;
   OptState o = *st;
   o.last_norm = norm;
   o.skip = 0;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ pa
     o.skipped_total += 1;
   } else {
     const float coef = max_norm / (norm + 1e-6f);          // torch clip_grad_norm_
-    o.clip_coef = max_norm > 0.f ? fminf(coef, 1.f) : 1.f;
+    o.clip_coef = (max_norm > 0.f ? fminf(coef, 1.f) : 1.f) * grad_scale;
     // LambdaLR: the k-th optimizer.step() (k = 0,1,..) runs with lr * min(1, k / warmup)
     const int k = o.adam_step;
     o.lr_eff = (warmup > 0 && k < warmup) ? lr * (float)k / fmaxf(1.f, (float)warmup) : lr;
@@ -104,9 +106,10 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ pa
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n,
                                                     const OptState* __restrict__ st, float beta1, float beta2,
-                                                    float eps) {
+                                                    float eps, float weight_decay) {
   if (st->skip) return;
   const float coef = st->clip_coef, step_size = st->lr_eff / st->bc1, rbc2 = rsqrtf(st->bc2);
+  const float decay = 1.f - st->lr_eff * weight_decay;      // torch.optim.AdamW: p *= 1 - lr * wd before the update
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256l + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 pv = ((float4*)p)[i], mv = ((float4*)m)[i], vv = ((float4*)v)[i];
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       const float gr = gg[k] * coef;
       mm[k] = beta1 * mm[k] + (1.f - beta1) * gr;
       vx[k] = beta2 * vx[k] + (1.f - beta2) * gr * gr;
-      pp[k] -= step_size * mm[k] / (sqrtf(vx[k]) * rbc2 + eps);
+      pp[k] = pp[k] * decay - step_size * mm[k] / (sqrtf(vx[k]) * rbc2 + eps);
     }
     ((float4*)p)[i] = pv;
     ((float4*)m)[i] = mv;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       const float gr = g[i] * coef;
       m[i] = beta1 * m[i] + (1.f - beta1) * gr;
       v[i] = beta2 * v[i] + (1.f - beta2) * gr * gr;
-      p[i] -= step_size * m[i] / (sqrtf(v[i]) * rbc2 + eps);
+      p[i] = p[i] * decay - step_size * m[i] / (sqrtf(v[i]) * rbc2 + eps);
     }
 }
 
@@ -142,7 +145,7 @@ extern "C" {
 size_t pv_optim_state_bytes(void) { return sizeof(OptState) + NPART * sizeof(float); }
 
 int pv_grad_guard(const float* grads, long n, void* state, float max_norm, float lr, int warmup_steps, float beta1,
-                  float beta2, int guards, void* stream) {
+                  float beta2, int guards, float grad_scale, void* stream) {
   PV_REQUIRE(grads && state && n > 0, "pv_grad_guard: bad argument");
   PV_REQUIRE(((uintptr_t)grads & 15) == 0, "pv_grad_guard: flat gradient buffer must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -152,20 +155,20 @@ int pv_grad_guard(const float* grads, long n, void* state, float max_norm, float
   hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, n, partial);
   PV_LAUNCH_CHECK("sumsq_kernel");
   hipLaunchKernelGGL(guard_kernel, dim3(1), dim3(256), 0, st, partial, nb, (OptState*)state, max_norm, lr,
-                     warmup_steps, beta1, beta2, guards);
+                     warmup_steps, beta1, beta2, guards, grad_scale);
   PV_LAUNCH_CHECK("guard_kernel");
   return PV_OK;
 }
 
 int pv_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, const void* state,
-                 float beta1, float beta2, float eps, void* stream) {
+                 float beta1, float beta2, float eps, float weight_decay, void* stream) {
   PV_REQUIRE(params && grads && exp_avg && exp_avg_sq && state && n > 0, "pv_adam_step: bad argument");
   PV_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
              "pv_adam_step: flat buffers must be 16-byte aligned");
   long blocks = (n / 4 + 255) / 256;
   const int nb = (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
-                     (const OptState*)state, beta1, beta2, eps);
+                     (const OptState*)state, beta1, beta2, eps, weight_decay);
   PV_LAUNCH_CHECK("adam_kernel");
   return PV_OK;
 }

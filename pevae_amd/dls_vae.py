@@ -25,7 +25,12 @@ from .enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
 from .enc2dec.encoders import EncoderRNN
 from .utils import Pack
 
-PAD_ID, UNK_ID, BOS_ID, EOS_ID = 0, 1, 2, 3      # vocab = [<pad>, <unk>, <s>, </s>] + words (corpora.py:624-651)
+# vocab = [<pad>, <unk>, <sys>, <usr>] + words by frequency (corpora.py:649).  <s> and </s> open and close every
+# sentence (corpora.py:620), so on a real corpus they are the two most frequent words: ids 4 and 5.  The model takes
+# them from the vocabulary, as FS_VAE.__init__ does (dialog_models.py:455-456: go_id = rev_vocab[BOS], eos_id =
+# rev_vocab[EOS]); these are the defaults for synthetic data, which has no vocabulary.
+PAD_ID, UNK_ID, SYS_ID, USR_ID, BOS_ID, EOS_ID = 0, 1, 2, 3, 4, 5
+N_SPECIAL = 6                                    # synthetic word ids start here
 
 
 def default_config(**kw):
@@ -33,10 +38,21 @@ def default_config(**kw):
                     n_item=20000, latent_size=64, dropout=0.3, rnn_cell="gru", num_layer=1, use_attention=False,
                     attn_type="cat", do_pred=False, beam_size=10, batch_size=256, init_lr=1e-4, grad_clip=5.0,
                     warmup_steps=0, use_gpu=True, latent_stack="gauss", expand_weight=0.5, converge_weight=0.1,
-                    cip_weight=1.0, ost=False)
+                    cip_weight=1.0, ost=False, pad_id=PAD_ID, unk_id=UNK_ID, bos_id=BOS_ID, eos_id=EOS_ID,
+                    use_mutual=False, use_feature=False, n_feature=0, den_weight=1.0)
     for k, v in kw.items():
         setattr(cfg, k, v)
     return cfg
+
+
+def config_from_vocab(config, rev_vocab):
+    """Special-symbol ids and vocabulary size from a corpus vocabulary (dialog_models.py:451-457: vocab_size =
+    len(vocab), go_id = rev_vocab[BOS], eos_id = rev_vocab[EOS], unk via corpora.py:651)."""
+    from .dataset.data_loaders import BOS, EOS, PAD, UNK
+    config.vocab_size = len(rev_vocab)
+    config.pad_id, config.unk_id = rev_vocab[PAD], rev_vocab[UNK]
+    config.bos_id, config.eos_id = rev_vocab[BOS], rev_vocab[EOS]
+    return config
 
 
 class DLSVAE(nn.Module):
@@ -45,12 +61,14 @@ class DLSVAE(nn.Module):
         c = self.config = config
         H, E, Z = c.dec_cell_size, c.embed_size, c.latent_size
         self.emb_size = H // 2
-        self.x_embedding = nn.Embedding(c.vocab_size, E, padding_idx=PAD_ID)            # dialog_models.py:468
+        self.pad_id, self.unk_id = getattr(c, "pad_id", PAD_ID), getattr(c, "unk_id", UNK_ID)
+        self.go_id, self.eos_id = getattr(c, "bos_id", BOS_ID), getattr(c, "eos_id", EOS_ID)      # :455-456
+        self.x_embedding = nn.Embedding(c.vocab_size, E, padding_idx=self.pad_id)       # dialog_models.py:468
         self.user_embedding = nn.Embedding(c.n_user, self.emb_size)                      # :473
         self.item_embedding = nn.Embedding(c.n_item, self.emb_size)                      # :475
         self.rating_embedding = nn.Embedding(5, self.emb_size)                           # :502
         self.x_encoder = EncoderRNN(E, H, dropout_p=c.dropout, rnn_cell=c.rnn_cell, variable_lengths=False)  # :530
-        self.x_decoder = DecoderRNN(c.vocab_size, c.max_seq_len, E, H, BOS_ID, EOS_ID, UNK_ID,
+        self.x_decoder = DecoderRNN(c.vocab_size, c.max_seq_len, E, H, self.go_id, self.eos_id, self.unk_id,
                                     n_layers=c.num_layer, rnn_cell=c.rnn_cell, input_dropout_p=c.dropout,
                                     dropout_p=c.dropout, use_attention=c.use_attention, attn_mode=c.attn_type,
                                     attn_size=H, use_gpu=c.use_gpu, embedding=self.x_embedding)               # :560-570
@@ -59,7 +77,7 @@ class DLSVAE(nn.Module):
             self.rec_encoder = L.DlsRec(H, H // 16, c)
             self.pri_encoder = L.DlsPri(H, H // 16, c)
             self.sup_decoder = L.DLSAuto(H // 32, H // 8, c)
-            self.dls_connector = nn.Sequential(L.Block(H // 4, H // 2, H // 2), L.Block(H // 2, H, H))
+            self.x_init_connector = nn.Sequential(L.Block(H // 4, H // 2, H // 2), L.Block(H // 2, H, H))
         self.prior_fc = nn.Linear(3 * self.emb_size, H)
         if self.latent_stack == "gauss":
             self.rec_head = nn_lib.Hidden2Gaussian(H, Z)
@@ -67,8 +85,8 @@ class DLSVAE(nn.Module):
             self.x_init_connector = nn_lib.LinearConnector(Z, H, c.rnn_cell == "lstm")  # :626
         if c.do_pred:                                                                    # `self.dnn`, used at :815, never
             self.dnn = nn.Sequential(nn.Linear(2 * self.emb_size, H), nn.Linear(H, 1))  # defined by the reference
-        self.nll_loss = criterions.NLLEntropy(PAD_ID, c)                                 # :634
-        self.ppl = criterions.Perplexity(PAD_ID, c)                                      # :637
+        self.nll_loss = criterions.NLLEntropy(self.pad_id, c)                            # :634
+        self.ppl = criterions.Perplexity(self.pad_id, c)                                 # :637
         self.kl_loss = criterions.NormKLLoss(unit_average=False)
         self.backLoss = True
 
@@ -89,10 +107,12 @@ class DLSVAE(nn.Module):
         self.valid_loss(loss, batch_cnt, step=step).backward()
 
     def forward(self, data_feed, mode=TEACH_FORCE, gen_type="greedy", eps=None):
+        if self.training and self.config.dropout > 0:
+            ops.rng_advance(self.x_embedding.weight.device)      # new dropout masks every step, also under graph replay
         user = ops.embedding(self.user_embedding.weight, data_feed["user_ids"])          # :758
         item = ops.embedding(self.item_embedding.weight, data_feed["item_ids"])          # :759
         rating = ops.embedding(self.rating_embedding.weight, data_feed["ratings"].ge(3).long())   # :760
-        words = ops.embedding(self.x_embedding.weight, data_feed["sentence_embeddings"], PAD_ID)
+        words = ops.embedding(self.x_embedding.weight, data_feed["sentence_embeddings"], self.pad_id)
         enc_outs, enc_last = self.x_encoder(words)                                        # :765
         h = enc_last.transpose(0, 1).contiguous().squeeze(1)                              # :766
         prior_h = ops.tanh(ops.linear(torch.cat([user, item, rating], -1), self.prior_fc.weight, self.prior_fc.bias))
@@ -107,7 +127,7 @@ class DLSVAE(nn.Module):
                                       getattr(self, "restarted", False), noise=eps)        # :3535
             if not self.training:
                 rkl = None                                                                 # :3571
-            dec_init = self.dls_connector(z).unsqueeze(0)                                  # :3473
+            dec_init = self.x_init_connector(z).unsqueeze(0)                                  # :3473
         else:
             mu_q, lv_q = self.rec_head(h)
             mu_p, lv_p = self.pri_head(prior_h)
@@ -143,17 +163,18 @@ class DLSVAE(nn.Module):
 
 def synthetic_batch(config, batch_size, seed, device="cpu"):
     """Synthetic batch in the format of YELPDataLoader.batcher.__call__ (data_loaders.py:704-715):
-    BOS, len-2 Zipf-distributed word ids in [4, V), EOS, PAD to L; ans_ids = input_ids shifted left."""
+    BOS, len-2 Zipf-distributed word ids in [6, V), EOS, PAD to L; ans_ids = input_ids shifted left.  BOS / EOS are
+    config.bos_id / config.eos_id (4 / 5 by default: where a real corpus puts them, see the top of this file)."""
     g = torch.Generator().manual_seed(seed)
     B, L, V = batch_size, config.max_seq_len, config.vocab_size
     lens = torch.randint(min(8, L), L + 1, (B,), generator=g)
-    ranks = torch.arange(1, V - 3, dtype=torch.float64)
+    ranks = torch.arange(1, V - N_SPECIAL + 1, dtype=torch.float64)
     probs = (1.0 / ranks ** 1.1)
-    words = torch.multinomial(probs / probs.sum(), B * L, replacement=True, generator=g).view(B, L) + 4
+    words = torch.multinomial(probs / probs.sum(), B * L, replacement=True, generator=g).view(B, L) + N_SPECIAL
     pos = torch.arange(L).unsqueeze(0)
     ids = torch.where(pos < lens.unsqueeze(1), words, torch.zeros_like(words))
-    ids[:, 0] = BOS_ID
-    ids[torch.arange(B), lens - 1] = EOS_ID
+    ids[:, 0] = getattr(config, "bos_id", BOS_ID)
+    ids[torch.arange(B), lens - 1] = getattr(config, "eos_id", EOS_ID)
     ans = torch.cat([ids[:, 1:], torch.zeros(B, 1, dtype=torch.long)], 1)
     user = torch.randint(0, config.n_user, (B,), generator=g)
     item = torch.randint(0, config.n_item, (B,), generator=g)

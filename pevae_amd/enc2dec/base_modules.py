@@ -19,6 +19,7 @@ class RNNWeights(nn.Module):
         super().__init__()
         self.cell, self.input_size, self.hidden_size = cell, input_size, hidden_size
         self.num_layers, self.bidirectional, self.dropout = num_layers, bidirectional, float(dropout)
+        self.between_layers = ops.Dropout(self.dropout) if self.dropout > 0 and num_layers > 1 else None
         ngate = 3 if cell == "gru" else 4
         ndir = 2 if bidirectional else 1
         bound = 1.0 / math.sqrt(hidden_size)
@@ -81,8 +82,8 @@ class RNNWeights(nn.Module):
                 finals.append(hn)
                 hseq = hs if ndir == 1 else None
             x = outs[0] if ndir == 1 else torch.cat(outs, dim=-1)
-            if self.dropout > 0 and self.training and layer < self.num_layers - 1:
-                x = F.dropout(x, self.dropout, True)
+            if self.between_layers is not None and self.training and layer < self.num_layers - 1:
+                x = self.between_layers(x)
                 hseq = None
         if lstm:
             return x, (torch.stack(finals, dim=0), torch.stack(cfinals, dim=0)), hseq
@@ -112,7 +113,7 @@ class BaseRNN(nn.Module):
         self.hidden_size = hidden_size
         self.n_layers = n_layers
         self.input_dropout_p = input_dropout_p
-        self.input_dropout = nn.Dropout(p=input_dropout_p)
+        self.input_dropout = ops.Dropout(p=input_dropout_p)
         cell = rnn_cell.lower()
         if cell not in ("lstm", "gru"):
             raise ValueError("Unsupported RNN Cell: {0}".format(rnn_cell))          # base_modules.py:39

@@ -64,9 +64,11 @@ class Attention(nn.Module):
 class DeferredLogProbs(object):
     """Lazy [B,L,V] log-softmax of (hid W^T + b) / temperature."""
 
-    def __init__(self, hid, weight, bias, inv_temp, hid_bf16=None, layout=None):
+    def __init__(self, hid, weight, bias, inv_temp, hid_bf16=None, layout=None, drop=None):
+        # drop = (p, site, mask): the decoder's output dropout (decoders.py:189) has NOT been applied to `hid` yet; the
+        # fused path folds it into the bf16 operand pack, the dense path applies it first
         self.hid, self.weight, self.bias, self.inv_temp = hid, weight, bias, inv_temp
-        self.hid_bf16, self.layout = hid_bf16, layout
+        self.hid_bf16, self.layout, self.drop = hid_bf16, layout, drop
         self._dense = None
         self._nll_cache = {}
 
@@ -78,7 +80,7 @@ class DeferredLogProbs(object):
         if hit is not None:
             return hit
         B, L, H = self.hid.shape
-        if self.hid_bf16 is not None:
+        if self.hid_bf16 is not None or (self.drop is not None and self.layout is not None):
             Lh, Bh, Bpad = self.layout
             tgt = labels.reshape(B, L).t()
             if Bpad != B:
@@ -86,7 +88,11 @@ class DeferredLogProbs(object):
                 tgt = torch.cat([tgt, pad], dim=1)
             tgt = tgt.contiguous().view(-1)
             nll, _ = ops.VocabNLL.apply(self.hid, self.weight, self.bias, tgt, self.inv_temp, ignore_index,
-                                        self.hid_bf16, self.layout)
+                                        self.hid_bf16, self.layout, self.drop)
+        elif self.drop is not None:
+            tgt = labels.reshape(-1)
+            nll, _ = ops.VocabNLL.apply(self.hid, self.weight, self.bias, tgt, self.inv_temp, ignore_index, None, None,
+                                        self.drop)
         else:
             tgt = labels.reshape(-1)
             nll, _ = ops.VocabNLL.apply(self.hid.reshape(B * L, H), self.weight, self.bias, tgt, self.inv_temp,
@@ -109,7 +115,8 @@ class DeferredLogProbs(object):
     def materialize(self):
         if self._dense is None:
             B, L, H = self.hid.shape
-            flat = ops.VocabLogProbDense.apply(self.hid.reshape(B * L, H), self.weight, self.bias, self.inv_temp)
+            hid = self.hid if self.drop is None else ops.DropoutFn.apply(self.hid, *self.drop)
+            flat = ops.VocabLogProbDense.apply(hid.reshape(B * L, H), self.weight, self.bias, self.inv_temp)
             self._dense = flat.view(B, L, -1)
         return self._dense
 
@@ -171,7 +178,7 @@ class DecoderRNN(BaseRNN):
         self.tie_output_embed = tie_output_embed
         if not tie_output_embed:
             self.project = nn.Linear(self.hidden_size, self.output_size)
-        self.output_dropout = nn.Dropout(p=input_dropout_p)            # decoders.py:166
+        self.output_dropout = ops.Dropout(p=input_dropout_p)           # decoders.py:166
         for para in self.parameters():                                   # decoders.py:167-168 (incl. shared embedding)
             nn.init.uniform_(para.data, -init_range, init_range)
 
@@ -181,8 +188,10 @@ class DecoderRNN(BaseRNN):
             return w, torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
         return self.project.weight, self.project.bias
 
-    def _hidden_states(self, input_var, hidden, encoder_outputs, latent_variable):
-        """decoders.py:171-189: embedding -> dropout -> [cat latent] -> RNN -> [attention] -> dropout."""
+    def _hidden_states(self, input_var, hidden, encoder_outputs, latent_variable, defer_output_dropout=False):
+        """decoders.py:171-189: embedding -> dropout -> [cat latent] -> RNN -> [attention] -> dropout.
+        defer_output_dropout: return the states BEFORE the output dropout plus the (p, site, mask) it must still get (the
+        teacher-forced path folds it into the vocabulary operand pack); the 4th result is then (hseq, drop)."""
         embedded = ops.embedding(self.embedding.weight, input_var, self.embedding.padding_idx)
         embedded = self.input_dropout(embedded)
         if latent_variable is not None:
@@ -193,9 +202,13 @@ class DecoderRNN(BaseRNN):
         if self.use_attention and encoder_outputs is not None:
             output, attn = self.attention(output, encoder_outputs)
             hseq = None
-        if self.training and self.output_dropout.p > 0:
+        dropping = self.training and self.output_dropout.p > 0
+        if defer_output_dropout:
+            drop = (self.output_dropout.p, self.output_dropout.next_site(), self.output_dropout.mask) if dropping else None
+            return output, hidden, attn, (None if dropping else hseq, drop)
+        if dropping:
             hseq = None
-        output = self.output_dropout(output.contiguous())
+        output = self.output_dropout(output)
         return output, hidden, attn, hseq
 
     def forward_step(self, input_var, hidden, encoder_outputs, latent_variable=None):
@@ -242,15 +255,18 @@ class DecoderRNN(BaseRNN):
         lengths = np.array([self.max_length] * batch_size * beam_size)
 
         if mode == TEACH_FORCE:
-            output, decoder_hidden, attn, hseq = self._hidden_states(decoder_input, decoder_hidden, attn_context,
-                                                                     latent_variable)
+            output, decoder_hidden, attn, (hseq, drop) = self._hidden_states(decoder_input, decoder_hidden, attn_context,
+                                                                             latent_variable, defer_output_dropout=True)
             w, b = self._out_weights()
             B, L, H = output.shape
             hid_bf16 = layout = None
             if hseq is not None:
                 Hk, K3, Bpad, NG = ops.gru_geometry(B, H)
                 hid_bf16, layout = hseq[Bpad:], (L, B, Bpad)
-            decoder_outputs = DeferredLogProbs(output, w, b, 1.0 / self.softmax_temperature, hid_bf16, layout)
+            elif drop is not None and not (self.use_attention and attn_context is not None):
+                # the states are a strided view of the recurrence's time-major buffer: pack them time-major as well
+                layout = (L, B, ops.gru_geometry(B, H)[2])
+            decoder_outputs = DeferredLogProbs(output, w, b, 1.0 / self.softmax_temperature, hid_bf16, layout, drop)
         else:
             step_outputs, cum_sum = [], None
             fused = getattr(self, "fused_greedy", False) and gen_type == 'greedy'

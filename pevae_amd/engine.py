@@ -6,7 +6,9 @@ Kept from the reference: the epoch / batch iteration over a feed with epoch_init
 and the two skip rules (:207-225; evaluated on the device inside FlatAdam, same arithmetic), the freeze phase (:227-266:
 reload the best checkpoint, freeze embedding / encoder / decoder / init connector, fresh optimizer), evaluation every
 `ckpt_step` batches with plateau decay `lr *= lr_decay_rate` when the validation loss did not improve by 1 % (:343-348),
-patience bookkeeping and best-checkpoint save (:354-366), LossManager's report format (:21-73).
+patience bookkeeping and best-checkpoint save (:354-366), LossManager's report format (:21-73), the skip bookkeeping of
+:213-225 (a skipped step adds nothing to train_loss, does not advance batch_cnt and triggers no report, evaluation or
+freeze switch -- see train()), AdamW for the freeze phase (dialog_models.py:834).
 Changed: LossManager keeps the per-batch losses on the device and reads them back once per report instead of one
 `.item()` (a host sync) per loss per batch; TensorBoard, generation previews and the text metrics (:264-265, :319-338,
 :401-1286) are out of scope."""
@@ -94,36 +96,90 @@ def validate(model, valid_feed, config, batch_cnt=None):                # main_p
         logger.info(losses.pprint(valid_feed.name))
         logger.info("Total valid loss {}".format(valid_loss))
         res = losses.return_dict()
+    _check_recurrence()
     return valid_loss, res
 
 
 FROZEN_IN_PHASE_2 = ("x_embedding", "x_encoder", "x_decoder", "x_init_connector")    # main_pretrain.py:238-247
 
 
-def make_optimizer(model, config):
+def make_optimizer(model, config, phase2=False):
+    """model.get_optimizer (dialog_models.py:122-131: Adam + constant-with-warmup) or, for the freeze phase,
+    model.get_freeze_optimizer (:834: torch.optim.AdamW with its default decoupled weight decay 0.01)."""
     return FlatAdam([p for p in model.parameters() if p.requires_grad], lr=config.init_lr, max_norm=config.grad_clip,
-                    warmup_steps=getattr(config, "warmup_steps", 0))
+                    warmup_steps=getattr(config, "warmup_steps", 0), weight_decay=0.01 if phase2 else 0.0)
 
 
-def train(model, train_feed, valid_feed, config, max_evals=None, checkpoint=None):
+def _check_recurrence():
+    """A timed-out wait inside a persistent GRU / LSTM launch is reported through an error word only; read the words of
+    the recent launches at every evaluation so that a run cannot continue on garbage states (one small read-back)."""
+    if torch.cuda.is_available():
+        from . import ops
+        ops.gru_check_all()
+
+
+def train(model, train_feed, valid_feed, config, max_evals=None, checkpoint=None, optimizer_factory=None, trace=None):
     """Runs until the reference's stop rule (done_epoch > 100, :184; five evaluations after the freeze phase add 100,
     :333-334) or `max_evals` evaluations.  Returns the history of (batch_cnt, valid_loss, lr) per evaluation.
     config fields used (the reference's names): init_lr, grad_clip, batch_size, teach_force_bound, freeze_step,
-    ckpt_step, print_step, lr_decay_rate, improve_threshold, patient_increase, exp_name."""
+    ckpt_step, print_step, lr_decay_rate, improve_threshold, patient_increase, exp_name.
+
+    Skipped steps (:213-222 `continue`): the decision is taken on the device inside optimizer.step(); the host needs it
+    for the same bookkeeping as the reference -- a skipped step adds nothing to train_loss and does not advance
+    batch_cnt, so it triggers no report, evaluation or freeze switch.  Each step's flag comes back through an 8-byte
+    asynchronous copy (FlatAdam.skip_flag_async); steps whose flag has not been read are `pending`.  The host waits for
+    the flags only when one of the pending steps could reach a print / evaluation / freeze boundary, which keeps the
+    reference's exact sequence without a host sync per step (the reference has three).
+    optimizer_factory(model, config, phase2) and `trace` (a list that receives ("step", n, skipped) / ("eval", batch_cnt,
+    valid_loss, lr) / ("freeze", n) events) exist for the CPU test against oracle/ref_engine.py."""
+    factory = optimizer_factory or make_optimizer
     patience = 2
     valid_loss_threshold = np.inf
     best_valid_loss = np.inf
     learning_rate = config.init_lr
     batch_cnt = 0
-    optimizer = make_optimizer(model, config)
+    optimizer = factory(model, config, False)
     best_model_name = checkpoint or os.path.join("./runs/", "model_" + getattr(config, "exp_name", "pevae") + ".pt")
     os.makedirs(os.path.dirname(os.path.abspath(best_model_name)), exist_ok=True)
-    done_epoch, final_epoch, evals = 0, 0, 0
+    done_epoch, final_epoch, evals, nstep = 0, 0, 0, 0
     history = []
     train_loss = LossManager()
     model.train()
     model.restarted = getattr(model, "restarted", False)
     freeze_step = getattr(config, "freeze_step", None)
+    pending = []                                      # [(loss pack, SkipFlag, step number)] in step order
+
+    def note(*ev):
+        if trace is not None:
+            trace.append(ev)
+
+    def boundary_within(lo, hi):
+        """Could batch_cnt, now `lo`, reach a print / evaluation / freeze boundary while growing to at most `hi`?"""
+        if hi <= lo:
+            return False
+        for step_ in (config.print_step, config.ckpt_step):
+            if hi // step_ != lo // step_:
+                return True
+        return freeze_step is not None and not model.restarted and hi >= freeze_step
+
+    def settle(block):
+        """Fold the steps whose skip flag has arrived (all of them when block) into batch_cnt / train_loss."""
+        nonlocal batch_cnt
+        last_applied = None
+        while pending and (block or pending[0][1].ready()):
+            loss, flag, n = pending.pop(0)
+            skipped = flag.skipped()
+            note("step", n, skipped)
+            last_applied = not skipped
+            if skipped:
+                logger.info("step %d skipped by the gradient-norm guard" % n)
+                continue
+            if trace is not None:
+                trace.append(("lr", n, flag.lr()))
+            train_loss.add_loss(loss)
+            batch_cnt += 1
+        return last_applied
+
     logger.info("**** Training Begins ****")
     while done_epoch <= 100 and (max_evals is None or evals < max_evals):
         train_feed.epoch_init(config, shuffle=True)
@@ -132,31 +188,43 @@ def train(model, train_feed, valid_feed, config, max_evals=None, checkpoint=None
             if batch is None:
                 break
             optimizer.zero_grad()
-            model.steps = batch_cnt
+            model.steps = batch_cnt + len(pending)
             mode = TEACH_FORCE if done_epoch < config.teach_force_bound else GEN
             loss = model(batch, mode=mode)
             model.backward(batch_cnt, loss, step=batch_cnt)
-            if freeze_step is not None and batch_cnt >= freeze_step and not model.restarted:
-                # :227-266 second phase: best weights back, sentence side frozen, fresh optimizer and counters
-                logger.info("Switch to another train!")
-                best_valid_loss = np.inf
-                if os.path.exists(best_model_name):
-                    model.load_state_dict(torch.load(best_model_name, weights_only=True), strict=False)
-                    logger.info("Model {}: Load Done!".format(best_model_name))
-                model.restarted = True
-                for name in FROZEN_IN_PHASE_2:
-                    mod = getattr(model, name, None)
-                    if mod is not None:
+            nstep += 1
+            if freeze_step is not None and not model.restarted and batch_cnt + len(pending) >= freeze_step:
+                settle(True)
+                if batch_cnt >= freeze_step:
+                    # :207-266: the guards come first -- a skipped step `continue`s before the switch is looked at
+                    optimizer.guard()
+                    flag = optimizer.skip_flag_async()
+                    if flag.skipped():
+                        note("step", nstep, True)
+                        continue
+                    logger.info("Switch to another train!")
+                    note("freeze", nstep)
+                    best_valid_loss = np.inf
+                    if os.path.exists(best_model_name):
+                        model.load_state_dict(torch.load(best_model_name, weights_only=True), strict=False)
+                        logger.info("Model {}: Load Done!".format(best_model_name))
+                    model.restarted = True
+                    for name in FROZEN_IN_PHASE_2:
+                        mod = getattr(model, name, None)
+                        if mod is None:                  # a renamed module would silently keep training
+                            raise AttributeError("engine.train: the model has no %r to freeze (main_pretrain.py:238-247)" % name)
                         for p in mod.parameters():
                             p.requires_grad = False
                             p.grad = None
-                optimizer = make_optimizer(model, config)
-                learning_rate = config.init_lr
-                batch_cnt = 0
-                continue
+                    optimizer = factory(model, config, True)             # :257 get_freeze_optimizer (AdamW)
+                    learning_rate = config.init_lr
+                    batch_cnt = 0
+                    continue
             optimizer.step()                       # clip, skip rules and Adam on the device (:207-225, :268-269)
-            train_loss.add_loss(loss)
-            batch_cnt += 1
+            pending.append((loss, optimizer.skip_flag_async(), nstep))
+            applied = settle(boundary_within(batch_cnt, batch_cnt + len(pending)))
+            if pending or not applied:             # no boundary in reach, or this step was skipped (`continue`, :216 / :222)
+                continue
             if batch_cnt % config.print_step == 0:
                 logger.info(train_loss.pprint("Train", window=config.print_step,
                                               prefix="{}/{}".format(batch_cnt % (config.ckpt_step + 1), config.ckpt_step)))
@@ -166,6 +234,7 @@ def train(model, train_feed, valid_feed, config, max_evals=None, checkpoint=None
                 logger.info(train_loss.pprint("Train"))
                 done_epoch += 1
                 evals += 1
+                _check_recurrence()
                 valid_loss, _ = validate(model, valid_feed, config, batch_cnt)
                 if model.restarted:
                     final_epoch += 1
@@ -181,7 +250,9 @@ def train(model, train_feed, valid_feed, config, max_evals=None, checkpoint=None
                         torch.save(model.state_dict(), best_model_name)
                     best_valid_loss = valid_loss
                 history.append((batch_cnt, valid_loss, learning_rate))
+                note("eval", batch_cnt, valid_loss, learning_rate)
                 model.train()
                 train_loss.clear()
                 logger.info("\n**** Epoch {} ****".format(done_epoch))
+    settle(True)
     return history

@@ -243,6 +243,97 @@ def masked_sum(x, mask=None, ignore=0):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# dropout (nn.Dropout of encoders.py:54, decoders.py:175,189) on our own counter-based generator
+# ------------------------------------------------------------------------------------------------------------
+
+_RNG = {}
+
+
+def rng_state(device):
+    """{uint64 seed, uint64 step} in device memory (csrc/dropout.hip); seeded from torch.initial_seed() on first use."""
+    st = _RNG.get(device)
+    if st is None:
+        import struct
+        raw = struct.pack("QQ", torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0)
+        st = _RNG[device] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    return st
+
+
+def rng_seed(seed, device):
+    import struct
+    rng_state(device).copy_(torch.frombuffer(bytearray(struct.pack("QQ", seed & 0xFFFFFFFFFFFFFFFF, 0)), dtype=torch.uint8))
+
+
+def rng_advance(device):
+    """step += 1 on the device: once per training step (DLSVAE.forward), so that a replayed HIP graph draws new masks."""
+    _lib.call("pv_rng_advance", _p(rng_state(device)), _stream())
+
+
+def _drop_call(x3, out3, p, site, mask, midx):
+    n0, n1, Cc = x3.shape
+    _lib.call("pv_dropout_f32", _p(x3), n0, n1, Cc, x3.stride(0), x3.stride(1), x3.stride(2), midx[0], midx[1], float(p),
+              _p(mask), _p(rng_state(x3.device)), int(site), _p(out3), out3.stride(0), out3.stride(1), _stream())
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = x * keep / (1 - p); keep from `mask` (uint8, same shape as x) or regenerated from (seed, step, site, index) in
+    both passes -- no mask is stored."""
+
+    @staticmethod
+    def forward(ctx, x, p, site, mask):
+        _need_cuda(x, mask)
+        xc = x.contiguous()
+        Cc = xc.shape[-1]
+        x3 = xc.view(1, -1, Cc)
+        out = torch.empty_like(xc)
+        if mask is not None:
+            mask = mask.to(torch.uint8).contiguous()
+            assert mask.numel() == xc.numel()
+        _drop_call(x3, out.view(1, -1, Cc), p, site, mask, (0, Cc))
+        ctx.p, ctx.site, ctx.mask = p, site, mask
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dyc = dy.contiguous()
+        Cc = dyc.shape[-1]
+        dx = torch.empty_like(dyc)
+        _drop_call(dyc.view(1, -1, Cc), dx.view(1, -1, Cc), ctx.p, ctx.site, ctx.mask, (0, Cc))
+        return dx, None, None, None
+
+
+_SITE = [0]
+
+
+class Dropout(torch.nn.Module):
+    """torch.nn.Dropout's interface on the kernels above.  `mask` (uint8 / bool tensor of the input's shape, 1 = keep)
+    overrides the generator: parity tests hand the same mask to the oracle.  Every forward call draws under its own
+    site id (instance id x 4096 + call number), so a module called once per decoded token does not repeat its mask."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        if p < 0 or p >= 1:
+            if p == 1:
+                raise ValueError("pevae_amd Dropout: p = 1 is not supported (every element dropped)")
+            raise ValueError("dropout probability has to be between 0 and 1, but got {}".format(p))
+        self.p = float(p)
+        _SITE[0] += 1
+        self.site_base, self.calls, self.mask = _SITE[0] * 4096, 0, None
+
+    def next_site(self):
+        self.calls = (self.calls + 1) % 4096
+        return self.site_base + self.calls
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        return DropoutFn.apply(x, self.p, self.next_site(), self.mask)
+
+    def extra_repr(self):
+        return "p={}".format(self.p)
+
+
+# ------------------------------------------------------------------------------------------------------------
 # fused vocabulary projection + log-softmax + NLL
 # ------------------------------------------------------------------------------------------------------------
 
@@ -272,11 +363,31 @@ class VocabNLL(torch.autograd.Function):
     memory (static launch geometry, graph-capturable).  PEVAE_VOCAB_DENSE=1 computes every row like the reference."""
 
     @staticmethod
-    def forward(ctx, hid, weight, bias, target, inv_temp, ignore_index, hid_bf16, layout):
+    def forward(ctx, hid, weight, bias, target, inv_temp, ignore_index, hid_bf16, layout, drop=None):
         # hid: fp32 [T,H] -- or, with `hid_bf16` ([L*Bpad, ld] time-major bf16 rows from the GRU kernel) and
         # layout=(L,B,Bpad), the batch-first [B,L,H] tensor the gradient is returned for.  `target` follows
         # the row order of the bf16 operand.
+        # drop = (p, site, mask): decoders.py:189 output dropout folded into the operand pack -- hid [B,L,H] fp32 (any
+        # strides) is dropped, scaled and written as the bf16 operand in one pass (time-major rows with `layout`, else
+        # batch-major rows b*L + t); the backward pass applies the same keep decisions to dH.
         _need_cuda(hid, weight, bias, target)
+        ctx.drop = None
+        if drop is not None:
+            p_, site_, mask_ = drop
+            Bh, Lh, Hh = hid.shape
+            Hp_ = round_up(Hh, 64)
+            if mask_ is not None:
+                mask_ = mask_.to(torch.uint8).contiguous()
+                assert mask_.numel() == Bh * Lh * Hh
+            if layout is not None:
+                L_, B_, Bpad_ = layout
+                n0, n1, n1p, s0, s1, m0, m1 = L_, B_, Bpad_, hid.stride(1), hid.stride(0), Hh, Lh * Hh
+            else:
+                n0, n1, n1p, s0, s1, m0, m1 = Bh, Lh, Lh, hid.stride(0), hid.stride(1), Lh * Hh, Hh
+            hid_bf16 = torch.empty((n0 * n1p, Hp_), dtype=BF16, device=hid.device)
+            _lib.call("pv_dropout_pack_bf16", _p(hid), n0, n1, n1p, Hh, s0, s1, hid.stride(2), m0, m1, float(p_), _p(mask_),
+                      _p(rng_state(hid.device)), int(site_), _p(hid_bf16), Hp_, _stream())
+            ctx.drop = (float(p_), int(site_), mask_, (n0, n1, n1p, m0, m1))
         T, H, V, Hp, h_bf, ldh, w_bf = _vocab_operands(hid if hid_bf16 is None else hid_bf16[:, :weight.shape[1]], weight)
         dev = weight.device
         ctx.layout = layout
@@ -317,7 +428,7 @@ class VocabNLL(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dnll, _dlse):
         if dnll is None:
-            return (None,) * 8
+            return (None,) * 9
         if ctx.compact:
             h_bf, w_bf, bias, target, lse, perm, count = ctx.saved_tensors
         else:
@@ -342,10 +453,16 @@ class VocabNLL(torch.autograd.Function):
             dH_c = dH
             dH = torch.empty((T, H), dtype=torch.float32, device=dev)
             _lib.call("pv_scatter_rows_f32", _p(dH_c), H, _p(perm), _p(count), T, H, _p(dH), H, _stream())
+        if ctx.drop is not None:                       # dL/d(undropped states) = dH * keep / (1 - p), in place
+            p_, site_, mask_, (n0, n1, n1p, m0, m1) = ctx.drop
+            _lib.call("pv_dropout_f32", _p(dH), n0, n1, H, n1p * H, H, 1, m0, m1, p_, _p(mask_), _p(rng_state(dev)), site_,
+                      _p(dH), n1p * H, H, _stream())
+            if ctx.layout is None:
+                dH = dH.view(n0, n1, H)
         if ctx.layout is not None:
             L, B, Bpad = ctx.layout
             dH = dH.view(L, Bpad, H)[:, :B].transpose(0, 1)
-        return dH, dW, dbias, None, None, None, None, None
+        return dH, dW, dbias, None, None, None, None, None, None
 
 
 def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, dw_sink=None, live=None):
@@ -418,7 +535,11 @@ class VocabLogProbDense(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------
 
 GRU_MAX_WGS = 0     # 0 = one workgroup per CU of the current device
-LAST_GRU_SYNC = []  # (sync buffer, NG, tag) of recent launches, for gru_check_all() in tests / smoke
+import collections
+
+# (sync buffer, NG, tag) of the most recent launches, for gru_check_all() (tests, smoke, bench, engine evaluations):
+# a bounded ring -- the oldest entry is dropped, so later launches stay observable and at most 64 sync buffers are held
+LAST_GRU_SYNC = collections.deque(maxlen=64)
 
 
 def gru_check_all():
@@ -466,8 +587,7 @@ class GRULayer(torch.autograd.Function):
         out = hall[1:, :B].transpose(0, 1)          # [B,L,H] view of the fp32 states: no second copy is written
         if save:
             ctx.save_for_backward(x_bf, hseq, gsave, hall, w_ih, w_hh)
-        if len(LAST_GRU_SYNC) < 64:
-            LAST_GRU_SYNC.append((sync, NG, "pv_gru_fwd"))
+        LAST_GRU_SYNC.append((sync, NG, "pv_gru_fwd"))
         ctx.dims = (B, L, E, H, Hk, K3, Bpad, NG, Ep)
         ctx.params = (w_ih, w_hh)
         ctx.has_h0 = h0 is not None
@@ -496,8 +616,7 @@ class GRULayer(torch.autograd.Function):
             _lib.call("pv_gru_bwd", _p(dout), 0 if dout is None else dout.stride(0),
                       0 if dout is None else dout.stride(1), _p(dhn_c), _p(gsave), _p(hall), _p(whhT), L, B, H, 0,
                       _p(dgi), _p(dgh), _p(dh0), _p(dbp), _p(db_ih), _p(db_hh), _p(sync), GRU_MAX_WGS, _stream())
-        if len(LAST_GRU_SYNC) < 64:
-            LAST_GRU_SYNC.append((sync, NG, "pv_gru_bwd"))
+        LAST_GRU_SYNC.append((sync, NG, "pv_gru_bwd"))
         Tt = L * Bpad
         Tp = round_up(Tt, 64)
         # dx = dgi W_ih  (time-major rows), then back to [B,L,E]
@@ -549,8 +668,7 @@ class LSTMLayer(torch.autograd.Function):
         out = hall[1:, :B].transpose(0, 1)
         if save:
             ctx.save_for_backward(x_bf, hseq, gsave, hall, call, w_ih, w_hh)
-        if len(LAST_GRU_SYNC) < 64:
-            LAST_GRU_SYNC.append((sync, NG, "pv_lstm_fwd"))
+        LAST_GRU_SYNC.append((sync, NG, "pv_lstm_fwd"))
         ctx.dims = (B, L, E, H, Hk, K4, Bpad, NG, Ep)
         ctx.params = (w_ih, w_hh)
         ctx.lengths = lengths
@@ -581,8 +699,7 @@ class LSTMLayer(torch.autograd.Function):
                       0 if dout is None else dout.stride(1), _p(dhn_c), _p(dcn_c), _p(gsave), _p(hall), _p(call),
                       _p(whhT), L, B, H, 0, _p(dg), _p(dh0), _p(dc0), _p(dbp), _p(db_ih), _p(db_hh), _p(ctx.lengths),
                       _p(sync), GRU_MAX_WGS, _stream())
-        if len(LAST_GRU_SYNC) < 64:
-            LAST_GRU_SYNC.append((sync, NG, "pv_lstm_bwd"))
+        LAST_GRU_SYNC.append((sync, NG, "pv_lstm_bwd"))
         Tt = L * Bpad
         Tp = round_up(Tt, 64)
         wihT = transpose_to_bf16(w_ih.contiguous(), 4 * H, E, E, K4)

@@ -9,15 +9,39 @@ from . import _lib
 from .ops import _p, _stream
 
 
+class SkipFlag(object):
+    def __init__(self, buf, ev):
+        self.buf, self.ev, self._val = buf, ev, None
+
+    def ready(self):
+        return self._val is not None or self.ev.query()
+
+    def _read(self):
+        if self._val is None:
+            self.ev.synchronize()
+            self._val = (int(self.buf[0]), struct.unpack("f", struct.pack("i", int(self.buf[1])))[0])
+        return self._val
+
+    def skipped(self):
+        return self._read()[0] != 0
+
+    def lr(self):
+        return self._read()[1]
+
+
 class FlatAdam(object):
     """Re-homes every parameter (and its .grad) as a view into flat fp32 buffers, then steps them with
     pv_grad_guard + pv_adam_step.  torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay.
 
     lr schedule: transformers.get_constant_schedule_with_warmup -- the k-th applied step (k = 0, 1, ...) runs
     at lr * min(1, k / warmup_steps).  `guards=True` adds the reference's skip rules (non-finite norm, up to 5
-    in a row; norm > 3x its running mean)."""
+    in a row; norm > 3x its running mean).  `weight_decay` > 0 makes it torch.optim.AdamW (decoupled decay; the
+    reference's freeze-phase optimizer, dialog_models.py:834, uses AdamW's default 0.01).  `grad_scale`: the flat
+    gradient holds a sum over `1 / grad_scale` data-parallel ranks (dp.FlatGradReducer); the scale is applied inside
+    the guard / Adam kernels."""
 
-    def __init__(self, params, lr, max_norm, warmup_steps=0, betas=(0.9, 0.999), eps=1e-8, guards=True):
+    def __init__(self, params, lr, max_norm, warmup_steps=0, betas=(0.9, 0.999), eps=1e-8, guards=True,
+                 weight_decay=0.0, grad_scale=1.0):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdam: no trainable parameters")
@@ -25,6 +49,8 @@ class FlatAdam(object):
         if dev.type != "cuda":
             raise RuntimeError("FlatAdam needs parameters on an MI355X device; there is no CPU fallback")
         self.lr, self.max_norm, self.warmup, self.betas, self.eps, self.guards = lr, max_norm, warmup_steps, betas, eps, guards
+        self.weight_decay, self.grad_scale = float(weight_decay), float(grad_scale)
+        self._flag_ring, self._flag_slot = [], 0
         offs, n = [], 0
         for p in self.params:
             offs.append(n)
@@ -54,12 +80,32 @@ class FlatAdam(object):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
 
-    def step(self):
-        st = _stream()
+    def guard(self):
+        """Clip norm + the skip rules of main_pretrain.py:207-225 on the device (decision and coefficients into `state`)."""
         _lib.call("pv_grad_guard", _p(self.flat_g), self.n, _p(self.state), self.max_norm, self.lr, self.warmup,
-                  self.betas[0], self.betas[1], 1 if self.guards else 0, st)
+                  self.betas[0], self.betas[1], 1 if self.guards else 0, self.grad_scale, _stream())
+
+    def apply(self):
+        """optimizer.step() + scheduler.step() (:268-269) unless the guard dropped this step."""
         _lib.call("pv_adam_step", _p(self.flat_p), _p(self.flat_g), _p(self.exp_avg), _p(self.exp_avg_sq), self.n,
-                  _p(self.state), self.betas[0], self.betas[1], self.eps, st)
+                  _p(self.state), self.betas[0], self.betas[1], self.eps, self.weight_decay, _stream())
+
+    def step(self):
+        self.guard()
+        self.apply()
+
+    def skip_flag_async(self):
+        """Non-blocking read-back of this step's skip decision (main_pretrain.py:213-222 does `continue` on it): an
+        8-byte copy {skip, lr_eff} into one of 8 page-locked slots, ordered behind the step on the current stream.
+        -> handle with .ready() (poll), .skipped() (waits for the copy) and .lr()."""
+        if len(self._flag_ring) < 8:
+            self._flag_ring.append((torch.empty(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event()))
+        buf, ev = self._flag_ring[self._flag_slot % len(self._flag_ring)]
+        self._flag_slot += 1
+        ev.synchronize()                                      # the slot's previous copy (8 steps ago) has landed
+        buf.copy_(self.state[28:36].view(torch.int32), non_blocking=True)
+        ev.record()
+        return SkipFlag(buf, ev)
 
     def state_dict_host(self):
         """Copy the device-side guard state to the host (synchronises; logging / tests only)."""

@@ -33,7 +33,7 @@ def test_ctypes_table_matches_header():
     for name, args in decl.items():
         assert len(args) == len(_lib.SIGNATURES[name][1]), name
     lib = _lib.load()
-    assert lib.pv_abi_version() == 1
+    assert lib.pv_abi_version() == 2
 
 
 def test_argument_validation_needs_no_gpu():

@@ -63,3 +63,96 @@ def test_train_validate_freeze_phase(dev, tmp_path):
     sd = torch.load(ckpt, weights_only=True)
     assert torch.equal(model.x_embedding.weight.detach().cpu(), sd["x_embedding.weight"].cpu())
     assert all(h[2] <= cfg.init_lr for h in hist)
+
+
+def test_engine_skip_sequence_matches_reference_on_the_device(dev, tmp_path):
+    """The real FlatAdam (guards and Adam on the device, skip flags read back asynchronously) under engine.train against
+    the reference's control flow (oracle/ref_engine.py <- main_pretrain.py:148-371): the gradient norm of every step is
+    scripted through the loss scale (spikes, a run of non-finite steps), the validation losses are scripted, and the
+    sequence of skipped / applied steps, evaluations, learning rates and the freeze switch must agree."""
+    from argparse import Namespace
+    from pevae_amd import engine
+    from pevae_amd.utils import Pack
+    from oracle.ref_engine import ref_train_trace
+    from test_engine_loop import Feed, script
+
+    N = 1024
+    norms, valid = script(7, 120)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for name in engine.FROZEN_IN_PHASE_2:
+                setattr(self, name, torch.nn.Linear(2, 2))
+            self.w = torch.nn.Parameter(torch.zeros(N))
+            self.n_step, self.n_eval, self.restarted = 0, 0, False
+
+        def forward(self, batch, mode=None):
+            if not self.training:
+                return Pack(vae_nll=torch.tensor(valid[self.n_eval], device=dev))
+            scale = float(norms[self.n_step]) / float(np.sqrt(N))         # |grad| = scale * sqrt(N)
+            self.n_step += 1
+            return Pack(vae_nll=(self.w * scale).sum())
+
+        def backward(self, batch_cnt, loss, step=None):
+            loss.vae_nll.backward()
+
+    cfg = Namespace(init_lr=1e-3, grad_clip=5.0, batch_size=4, teach_force_bound=1000, freeze_step=20, ckpt_step=8,
+                    print_step=5, lr_decay_rate=0.8, improve_threshold=0.996, patient_increase=2.0, exp_name="t",
+                    warmup_steps=6)
+    # what the device computes as the norm: sqrt(sum of N squares of a float32 scale), not the scripted value itself
+    dev_norms = [float(np.sqrt(np.float32(N)) * np.float32(float(n) / float(np.sqrt(N)))) for n in norms]
+    want, want_lr = ref_train_trace(dev_norms, valid, cfg, batches_per_epoch=13, max_evals=9)
+    model = M().to(dev)
+    trace = []
+    engine.train(model, Feed("train", 13), Feed("valid", 2, model), cfg, max_evals=9,
+                 checkpoint=os.path.join(str(tmp_path), "m.pt"), trace=trace)
+    got = [e for e in trace if e[0] != "lr"]
+    got_lr = [e[2] for e in trace if e[0] == "lr"]
+    last = max(i for i, e in enumerate(want) if e[0] == "eval")
+    assert got[:last + 1] == [tuple(e) for e in want[:last + 1]]
+    np.testing.assert_allclose(got_lr[:len(want_lr)], want_lr[:len(got_lr)], rtol=1e-6)
+    assert sum(1 for e in got if e[0] == "step" and e[2]) >= 2 and any(e[0] == "freeze" for e in got)
+
+
+def test_freeze_phase_with_the_dls_stack_and_gen_ids(dev, tmp_path):
+    """latent_stack='dls' through the freeze switch (its Block -> Block connector is `x_init_connector`, as in
+    dialog_models.py:3410, and is frozen with the sentence side), and free-running decoding on the real data path: the
+    decoder starts from rev_vocab['<s>'] and lengths stop at rev_vocab['</s>'] (dialog_models.py:455-456)."""
+    from pevae_amd import engine
+    from pevae_amd.dataset import YELPDataLoader, build_vocab, BOS, EOS
+    from pevae_amd.dls_vae import DLSVAE, config_from_vocab, default_config
+    from pevae_amd.enc2dec.decoders import GEN
+    train_rows, valid_rows = _rows(96, 3, 40, 8), _rows(32, 4, 40, 8)
+    vocab, rev, _ = build_vocab((train_rows, valid_rows), 100)
+    cfg = default_config(embed_size=32, dec_cell_size=64, max_seq_len=12, n_user=30, n_item=20,
+                         latent_size=16, dropout=0.0, batch_size=32, init_lr=3e-3, grad_clip=5.0, seed=0,
+                         teach_force_bound=1000, freeze_step=4, ckpt_step=3, print_step=3, lr_decay_rate=0.8,
+                         improve_threshold=0.996, patient_increase=2.0, exp_name="t2", fix_batch=False, latent_stack="dls")
+    config_from_vocab(cfg, rev)
+    assert (cfg.bos_id, cfg.eos_id) == (rev[BOS], rev[EOS]) and {cfg.bos_id, cfg.eos_id} == {4, 5}
+    torch.manual_seed(0)
+    model = DLSVAE(cfg).to(dev)
+    assert "x_init_connector.0.c1.weight_orig" in model.state_dict()
+    tf = YELPDataLoader("train", train_rows, cfg).attach(rev, dev)
+    vf = YELPDataLoader("valid", valid_rows, cfg).attach(rev, dev)
+    hist = engine.train(model, tf, vf, cfg, max_evals=3, checkpoint=os.path.join(str(tmp_path), "b.pt"))
+    assert len(hist) == 3 and model.restarted
+    frozen = [p for n in engine.FROZEN_IN_PHASE_2 for p in getattr(model, n).parameters()]
+    assert frozen and all(not p.requires_grad for p in frozen)
+    assert any(p.requires_grad for p in model.sup_decoder.parameters())
+    # GEN on a real batch: first decoder input and the EOS the length logic looks for
+    model.eval()
+    seen = []
+    orig = model.x_decoder._hidden_states
+    model.x_decoder._hidden_states = lambda inp, *a, **k: (seen.append(inp.clone()), orig(inp, *a, **k))[1]
+    batch = tf.batcher(rev, cfg.max_seq_len, dev)(train_rows[:8])
+    with torch.no_grad():
+        model.backLoss = False
+        ret, _ = model(batch, mode=GEN)
+        model.backLoss = True
+    assert seen and bool((seen[0] == rev[BOS]).all())
+    seq = torch.cat(ret["sequence"], 1).cpu()
+    for b, ln in enumerate(ret["length"]):
+        eos_at = (seq[b] == rev[EOS]).nonzero()
+        assert ln == (int(eos_at[0]) + 1 if len(eos_at) else seq.shape[1])

@@ -311,6 +311,84 @@ def test_adam_clip_guard_matches_torch(dev):
             np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=2e-6)
 
 
+def test_adamw_and_grad_scale_match_torch(dev):
+    """The freeze-phase optimizer (dialog_models.py:834: torch.optim.AdamW, default weight decay 0.01) and the
+    data-parallel 1/world fold: FlatAdam(weight_decay=0.01, grad_scale=1/4) fed 4x the gradient vs AdamW fed the gradient."""
+    from pevae_amd.optim import FlatAdam
+    torch.manual_seed(12)
+    shapes = [(40, 9), (77,)]
+    ps = [torch.randn(*s) for s in shapes]
+    ref = [p.clone().requires_grad_() for p in ps]
+    opt = torch.optim.AdamW(ref, lr=3e-2)
+    mine = [torch.nn.Parameter(p.clone().to(dev)) for p in ps]
+    fa = FlatAdam(mine, lr=3e-2, max_norm=2.0, guards=False, weight_decay=0.01, grad_scale=0.25)
+    for step in range(5):
+        grads = [torch.randn(*s) * (2.0 if step % 2 else 0.1) for s in shapes]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        norm = torch.nn.utils.clip_grad_norm_(ref, 2.0, 2)
+        opt.step()
+        fa.zero_grad()
+        for p, g in zip(mine, grads):
+            p.grad.copy_((4.0 * g).to(dev))
+        fa.step()
+        assert abs(fa.state_dict_host()["last_norm"] - float(norm)) < 1e-4 * float(norm)
+        for a, b in zip(mine, ref):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_dropout_mask_and_generator(dev):
+    """ops.Dropout (encoders.py:54, decoders.py:175,189): with a supplied mask it is exactly x * keep / (1 - p) in both
+    passes; with the generator the keep rate is 1 - p, the backward pass regenerates the forward's decisions, a new step
+    (pv_rng_advance) or a new call draws a new mask, and the bf16 operand pack sees the same decisions as the fp32 form."""
+    from pevae_amd import _lib, ops
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(6, 11, 37, generator=gen)
+    keep = torch.rand(6, 11, 37, generator=gen) >= 0.3
+    drop = ops.Dropout(0.3).train()
+    drop.mask = keep.to(dev)
+    xd = x.to(dev).requires_grad_()
+    y = drop(xd)
+    w = torch.randn(6, 11, 37, generator=gen)
+    (y * w.to(dev)).sum().backward()
+    np.testing.assert_array_equal(y.detach().cpu().numpy(),
+                                  torch.where(keep, x * (1.0 / (1.0 - np.float32(0.3))), torch.zeros(())).numpy())
+    np.testing.assert_array_equal(xd.grad.cpu().numpy(),
+                                  torch.where(keep, w * (1.0 / (1.0 - np.float32(0.3))), torch.zeros(())).numpy())
+    drop.eval()
+    assert drop(xd) is xd
+    # generator mode
+    ops.rng_seed(123, dev)
+    drop = ops.Dropout(0.3).train()
+    big = torch.ones(64, 50, 512, device=dev, requires_grad=True)
+    y1 = drop(big)
+    y1.sum().backward()
+    kept = y1 != 0
+    assert abs(float(kept.float().mean()) - 0.7) < 2e-3
+    assert torch.equal(big.grad != 0, kept)                       # backward regenerated the same decisions
+    assert float(y1.max()) == pytest.approx(1.0 / 0.7, rel=1e-6)
+    y2 = drop(big)                                                # next call of the same module: another site
+    assert 0.4 < float(((y2 != 0) == kept).float().mean()) < 0.7  # independent masks agree on ~0.58 of the elements
+    site = drop.site_base + 77
+    a = ops.DropoutFn.apply(big, 0.3, site, None)
+    b = ops.DropoutFn.apply(big, 0.3, site, None)
+    assert torch.equal(a, b)                                      # same (seed, step, site): same mask
+    ops.rng_advance(dev)
+    c = ops.DropoutFn.apply(big, 0.3, site, None)
+    assert not torch.equal(a, c)                                  # new step: new mask
+    # bf16 pack of a strided [B, L, H] view, time-major rows, against the fp32 form of the same logical tensor
+    B, L, H, Bpad, Hp = 5, 7, 40, 32, 64
+    src = torch.randn(L, Bpad, H, device=dev)                     # time-major storage, as the recurrence leaves it
+    view = src[:, :B].transpose(0, 1)                             # the batch-first module output
+    ref = ops.DropoutFn.apply(view, 0.3, site, None)              # logical (b, t, c) indexing
+    out = torch.empty(L * Bpad, Hp, dtype=torch.bfloat16, device=dev)
+    _lib.call("pv_dropout_pack_bf16", view.data_ptr(), L, B, Bpad, H, view.stride(1), view.stride(0), view.stride(2), H, L * H,
+              0.3, None, ops.rng_state(dev).data_ptr(), site, out.data_ptr(), Hp, torch.cuda.current_stream().cuda_stream)
+    got = out.view(L, Bpad, Hp)
+    assert torch.equal(got[:, :B, :H].transpose(0, 1).float(), ref.to(torch.bfloat16).float())
+    assert not got[:, B:].any() and not got[:, :, H:].any()       # padding rows / columns are zero
+
+
 def test_guard_skips_nonfinite_and_spikes(dev):
     from pevae_amd.optim import FlatAdam
     p = torch.nn.Parameter(torch.ones(64, device=dev))

@@ -25,16 +25,34 @@ def _pair(cfg, dev):
     return gpu.to(dev), ref
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(use_attention=True), dict(do_pred=True), dict(latent_stack="dls")])
+def share_dropout_masks(gpu, ref, cfg, B, dev, seed=17):
+    """The decoder's two dropouts (decoders.py:175 on the embedded inputs, :189 on the states; the encoder's input dropout
+    has p = 0, dialog_models.py:530-534) draw the SAME supplied keep masks on both sides."""
+    import oracle.ref_modules as R
+    if cfg.dropout <= 0:
+        return
+    gen = torch.Generator().manual_seed(seed)
+    L, E, H = cfg.max_seq_len, cfg.embed_size, cfg.dec_cell_size
+    for name, shape in (("input_dropout", (B, L, E)), ("output_dropout", (B, L, H))):
+        keep = torch.rand(shape, generator=gen) >= cfg.dropout
+        getattr(gpu.x_decoder, name).mask = keep.to(dev)
+        setattr(ref.x_decoder, name, R.MaskedDropout(keep, cfg.dropout))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(use_attention=True), dict(do_pred=True), dict(latent_stack="dls"),
+                                dict(dropout=0.3), dict(dropout=0.3, use_attention=True),
+                                dict(dropout=0.3, latent_stack="dls")])
 def test_step_matches_oracle(dev, kw):
     from pevae_amd import ops
     from pevae_amd.dls_vae import default_config, synthetic_batch
     from pevae_amd.optim import FlatAdam
+    kw = dict(dict(dropout=0.0), **kw)
     cfg = default_config(vocab_size=517, embed_size=20, dec_cell_size=64, max_seq_len=11, n_user=40, n_item=30,
-                         latent_size=16, dropout=0.0, batch_size=24, **kw)
+                         latent_size=16, batch_size=24, **kw)
     gpu, ref = _pair(cfg, dev)
     gpu.train()
     ref.train()
+    share_dropout_masks(gpu, ref, cfg, 24, dev)     # p = 0.3: the bench's arithmetic, with the masks fed to the oracle
     feed = synthetic_batch(cfg, 24, 99)
     feed_d = {k: v.to(dev) for k, v in feed.items()}
     gen = torch.Generator().manual_seed(3)
