@@ -4,9 +4,11 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = zero_grad + forward + backward + (gradient all-reduce) + clip/guards + Adam on ONE synthetic batch
-that is already resident in HBM.  Forward+backward and the optimizer tail are replayed from HIP graphs; the
-RCCL gradient all-reduce runs eagerly between them.  Rank 0 prints ONE JSON line with the whole-job rate, the
+A step = zero_grad + forward + backward + (gradient exchange) + clip/guards + Adam on one of NB (default 4) synthetic
+batches that are already resident in HBM (two small device-to-device copies select the batch of a step).  The step is
+replayed from HIP graphs: [zero_grad, forward, vocabulary backward] -> [rest of the backward] -> [guards + Adam].  With
+more than one rank the all-reduce of the vocabulary projection's gradient (a third of the dense bytes) starts after
+the first graph and travels over xGMI while the second one runs; everything else is exchanged after it.  Rank 0 prints ONE JSON line with the whole-job rate, the
 roofline of the dominant kernel group (vocabulary projection + softmax + NLL, forward and backward; HIP-event
 timed in an instrumented eager pass right after the timed region) and the CPU baseline (the oracle's composed
 step on stock ATen fp32 kernels, rank 0 only, bounded sample).
@@ -28,16 +30,21 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X bf16 MFMA, dense (MI355X_MICROARCH
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="yelp", choices=["yelp", "movie", "book", "mutual"],
+                    help="BASELINE.json configs: yelp = configs[1]; movie = configs[2] (8k x 8k tables, decoder attention); "
+                         "book = configs[3] (200k users, 100k items); mutual = configs[4] (--use_mutual + --do_pred)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps cycle through")
+    ap.add_argument("--overlap", type=int, default=1, help="N > 1: start the vocabulary gradient's all-reduce before the rest of the backward pass")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--graph", type=int, default=1, help="replay fwd+bwd / optimizer from HIP graphs")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-baseline steps (about 1.7 s each on 16 threads)")
     ap.add_argument("--dropout", type=float, default=0.3)
-    ap.add_argument("--latent", default="dls", choices=["gauss", "dls"],
+    ap.add_argument("--latent", default=None, choices=["gauss", "dls"],
                     help="latent stack: 'dls' = the reference's DLS pyramid (DlsRec/DlsPri/DLS_Auto), 'gauss' = flat")
-    ap.add_argument("--attention", type=int, default=0, help="decoder attention over encoder states (configs[2])")
+    ap.add_argument("--attention", type=int, default=None, help="decoder attention over encoder states (configs[2])")
     ap.add_argument("--vocab-dense", type=int, default=0,
                     help="1 = run the vocabulary GEMMs over the padding rows too (no ignored-token compaction)")
     ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for per-kernel times")
@@ -87,37 +94,85 @@ def main():
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
 
-    cfg = default_config(dropout=args.dropout, batch_size=args.batch, latent_stack=args.latent,
-                         use_attention=bool(args.attention))
+    shape = {"yelp": dict(n_user=30000, n_item=20000), "movie": dict(n_user=8000, n_item=8000, use_attention=True,
+                                                                       latent_stack="gauss"),
+             "book": dict(n_user=200000, n_item=100000), "mutual": dict(use_mutual=True, do_pred=True)}[args.config]
+    if args.latent is not None:
+        shape["latent_stack"] = args.latent
+    if args.attention is not None:
+        shape["use_attention"] = bool(args.attention)
+    cfg = default_config(**dict(dict(dropout=args.dropout, batch_size=args.batch, latent_stack="dls"), **shape))
     torch.manual_seed(0)                                    # identical initial weights on every rank
     model = DLSVAE(cfg).to(dev)
     model.train()
-    opt = FlatAdam(model.parameters(), lr=cfg.init_lr, max_norm=cfg.grad_clip, warmup_steps=cfg.warmup_steps)
+    model.split_backward = True
+    # the flat gradient holds the SUM over ranks; 1/world is applied inside the guard / Adam kernels
+    opt = FlatAdam(model.parameters(), lr=cfg.init_lr, max_norm=cfg.grad_clip, warmup_steps=cfg.warmup_steps,
+                   grad_scale=1.0 / world)
     dp.broadcast_parameters(opt.flat_p)
-    feed = synthetic_batch(cfg, args.batch, 1234 + rank, dev)
-    # user / item tables: only the looked-up rows carry gradient, so they are exchanged as (ids, rows), not all-reduced
+    # NB resident batches; the step reads `feed`, whose tensors are views into two static buffers (int64 / fp32)
+    batches = [synthetic_batch(cfg, args.batch, 1234 + rank + 1000 * i, dev) for i in range(max(1, args.batches))]
+    ikeys = [k for k, v in batches[0].items() if v.dtype == torch.int64]
+    fkeys = [k for k, v in batches[0].items() if v.dtype != torch.int64]
+    pack = lambda b, keys, dt: torch.cat([b[k].reshape(-1).to(dt) for k in keys])
+    all_i = torch.stack([pack(b, ikeys, torch.int64) for b in batches])
+    all_f = torch.stack([pack(b, fkeys, torch.float32) for b in batches])
+    cur_i, cur_f = all_i[0].clone(), all_f[0].clone()
+    feed, at = {}, 0
+    for k in ikeys:
+        n = batches[0][k].numel()
+        feed[k] = cur_i[at:at + n].view(batches[0][k].shape)
+        at += n
+    at = 0
+    for k in fkeys:
+        n = batches[0][k].numel()
+        feed[k] = cur_f[at:at + n].view(batches[0][k].shape)
+        at += n
+
+    def select(i):
+        cur_i.copy_(all_i[i % len(batches)])
+        cur_f.copy_(all_f[i % len(batches)])
+
+    # user / item tables: only the looked-up rows carry gradient, so they are exchanged as (ids, rows), not all-reduced;
+    # the vocabulary projection's gradient is final after the first backward kernels: its all-reduce starts early
+    dec = model.x_decoder
+    early = [opt.param_range(dec.project.weight), opt.param_range(dec.project.bias)] if args.overlap else []
+    early = [(min(a for a, _ in early), max(b for _, b in early))] if early else []
     reducer = dp.FlatGradReducer(opt.flat_g, world, sparse_tables=[opt.table_range(model.user_embedding.weight),
-                                                                  opt.table_range(model.item_embedding.weight)])
+                                                                  opt.table_range(model.item_embedding.weight)],
+                                 average=False, early_ranges=early)
     tables = sorted([(opt.table_range(model.user_embedding.weight)[0], "user_ids"),
                      (opt.table_range(model.item_embedding.weight)[0], "item_ids")])
     sparse_ids = [feed[k] for _, k in tables]
     n_params = sum(p.numel() for p in model.parameters())
+    state = {}
 
-    def fwd_bwd():
+    def part_a():                                   # zero_grad, forward, vocabulary backward
         opt.zero_grad()
-        loss = model(feed)
-        model.valid_loss(loss).backward()
+        state["loss"] = loss = model(feed)
+        model.backward_vocab(loss)
         return loss
 
-    def eager_step():
-        loss = fwd_bwd()
-        reducer.reduce(sparse_ids)
+    def part_b():                                   # the rest of the backward pass
+        model.backward_rest(state["loss"])
+
+    def fwd_bwd():
+        loss = part_a()
+        part_b()
+        return loss
+
+    def eager_step(i=0):
+        select(i)
+        loss = part_a()
+        reducer.start()
+        part_b()
+        reducer.finish(sparse_ids)
         opt.step()
         return loss
 
     # warm-up (eager, on a side stream as torch's graph-capture rules ask): allocates every workspace
-    for _ in range(max(3, args.warmup if not args.graph else 3)):
-        eager_step()
+    for i in range(max(3, args.warmup if not args.graph else 3)):
+        eager_step(i)
     torch.cuda.synchronize()
     ops.gru_check_all()
 
@@ -126,21 +181,27 @@ def main():
         # no autograd graph from the warm-up may stay alive (its AccumulateGrad nodes are tied to the warm-up stream)
         # and capture runs on the SAME side stream as the warm-up
         import gc
+        state.clear()
         gc.collect()
-        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, stream=side):
-            static_loss = fwd_bwd()
-        with torch.cuda.graph(g2, pool=g1.pool(), stream=side):
+        ga, gb, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, stream=side):
+            static_loss = part_a()
+        with torch.cuda.graph(gb, pool=ga.pool(), stream=side):
+            part_b()
+        with torch.cuda.graph(g2, pool=ga.pool(), stream=side):
             opt.step()
         ops.LAST_GRU_SYNC.clear()
 
-        def step():
-            g1.replay()
-            reducer.reduce(sparse_ids)
+        def step(i=0):
+            select(i)
+            ga.replay()
+            reducer.start()
+            gb.replay()
+            reducer.finish(sparse_ids)
             g2.replay()
             return static_loss
     for i in range(args.warmup):
-        step()
+        step(i)
         if rank == 0 and os.environ.get("PEVAE_BENCH_DEBUG"):
             st = opt.state_dict_host()
             bad = [n for n, p in model.named_parameters() if not torch.isfinite(p.grad).all()]
@@ -154,10 +215,11 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for i in range(args.steps):
+        loss = step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    ops.gru_check_all()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -176,10 +238,12 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
     final_nll = float(loss.vae_nll.detach())
+    skipped = opt.state_dict_host()["skipped_total"]
 
     # ---- instrumented eager pass: HIP events on the launch stream around the dominant kernels ---------------
     roof, kern_ms = None, {}
     if rank == 0:
+        select(0)
         ops.TIMERS = {}
         for _ in range(args.profile_steps):
             fwd_bwd()
@@ -192,18 +256,21 @@ def main():
         T, H, V = args.batch * cfg.max_seq_len, cfg.dec_cell_size, cfg.vocab_size
         # Only target rows that are not padding reach the vocabulary GEMMs (their NLL and gradients are exactly zero in
         # the reference too: NLLEntropy ignore_index, criterions.py), so only those rows are credited as work.
-        T_live = int((feed["ans_ids"] != 0).sum()) if ops.SKIP_IGNORED_TOKENS else T
+        select(0)
+        torch.cuda.synchronize()
+        T_live = int((feed["ans_ids"] != 0).sum()) if ops.SKIP_IGNORED_TOKENS else T     # the profiled pass runs batch 0
         alg_flop = 6.0 * T_live * H * V                  # fwd + dH + dW; the backward's logit recompute is NOT credited
-        vocab_ms = sum(kern_ms[k]["ms_per_step"] for k in ("vocab_fwd", "vocab_bwd_prob", "vocab_dH", "vocab_dW"))
+        vocab_tags = [k for k in kern_ms if k.startswith("vocab_")]
+        vocab_ms = sum(kern_ms[k]["ms_per_step"] for k in vocab_tags)
         ach = alg_flop / (vocab_ms * 1e-3) / 1e12
         traffic = None          # HBM bytes per step of the group, from the committed rocprofv3 --pmc passes (this script
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")     # cannot run the profiler on itself)
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # cannot run the profiler on itself)
         if os.path.exists(pmc):
             with open(pmc) as fh:
                 traffic = json.load(fh).get("vocab_group_hbm_bytes_per_step")
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
-                    traffic_source="profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per step)",
+                    traffic_source="profiles/r02_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per step)",
                     kernel="gemm_nt_kernel<EpiSoftmax|EpiProb|EpiStore> (vocab projection+softmax+NLL fwd+bwd group)",
                     algorithmic_gflop_per_step=round(alg_flop / 1e9, 1), group_ms_per_step=round(vocab_ms, 4),
                     token_rows=T, token_rows_computed=T_live,
@@ -216,13 +283,19 @@ def main():
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "DLS_VAE Yelp-shape bs=256/GPU bf16 (configs[1]): embed=100 dec_cell=512 L=50 "
-                                   "V=20004 NU=30000 NI=20000 Z=64, dropout=%.1f, Adam lr=1e-4 clip=5, latent stack '%s'%s"
-                                   % (args.dropout, args.latent, ", decoder attention" if args.attention else ""),
+            "config": {"workload": "DLS_VAE %s-shape bs=%d/GPU bf16 (configs[%d]): embed=100 dec_cell=512 L=50 "
+                                   "V=20004 NU=%d NI=%d Z=64, dropout=%.1f, Adam lr=1e-4 clip=5, latent stack '%s'%s%s%s"
+                                   % (args.config, args.batch, {"yelp": 1, "movie": 2, "book": 3, "mutual": 4}[args.config],
+                                      cfg.n_user, cfg.n_item, args.dropout, cfg.latent_stack,
+                                      ", decoder attention" if cfg.use_attention else "",
+                                      ", DEM mutual-information stack (use_mutual)" if cfg.use_mutual else "",
+                                      ", rating head (do_pred)" if cfg.do_pred else ""),
+                       "resident_batches": len(batches), "skipped_steps": skipped,
+                       "dp_overlap": bool(args.overlap) and world > 1,
                        "global_batch": args.batch * world, "seq_len": cfg.max_seq_len, "params": n_params,
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph),
                        "padding_rows_skipped": bool(ops.SKIP_IGNORED_TOKENS),
-                       "live_target_fraction": round(float((feed["ans_ids"] != 0).float().mean()), 4)},
+                       "live_target_fraction": round(float(sum((b["ans_ids"] != 0).float().mean() for b in batches)) / len(batches), 4)},
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kern_ms, "final_vae_nll": round(final_nll, 4),
         }
         print(json.dumps(out))

@@ -85,6 +85,35 @@ int pv_vocab_gather(const void* h, int ldh, const int64_t* target, const int64_t
                     int64_t* target_c, void* stream);
 int pv_scatter_rows_f32(const float* src, long lds, const int64_t* perm, const int* count, int T, int cols, float* dst,
                         long ldd, void* stream);
+/* ---- the same group with NOTHING of size [T][V] in HBM, forward and backward (H = 512; pv_vocab_fused_supported) ------
+ * Two flash-attention-shaped kernels (csrc/vocab_fused.hip), each two chained MFMA products per 32 x 32 block with the
+ * probabilities handed from the first product's accumulator to the second's operand in registers:
+ *   pv_vocab_fused_fwd : S^T = W h^T -> online softmax -> O^T += W^T P^T.  Emits lse[t], nll[t] (0 for ignored rows) AND
+ *                        U[t][:] = sum_v softmax[t,v] W[v] - W[target[t]] (fp32 [T][512]), the gradient of nll[t] with
+ *                        respect to the SCALED logits' input h[t] / inv_temp: dH[t] = dL/dnll[t] * inv_temp * U[t], an
+ *                        elementwise pass in backward (pv_scatter_rows_scaled_f32) instead of a GEMM over a stored P.
+ *   pv_vocab_fused_dw  : S = h W^T -> P = gscale (softmax - onehot) -> Z += P^T h.  Emits dW (+= when accumulate) and dbias;
+ *                        gscale[t] = dL/dnll[t] (0 for ignored rows; pv_vocab_gscale), lse from the forward call.
+ * Rows are the compact order of pv_vocab_compact (live rows first; live_rows = its count, NULL = all T rows);
+ * target32: the targets as int32 (pv_vocab_gather32).  Replaces decoders.py:191-193 + criterions.py:55-64 and their
+ * backward.  workspace: pv_vocab_fused_{fwd,dw}_ws_bytes -- per-workgroup partial results of the stream-K split, folded
+ * in a fixed order by a second kernel (bitwise reproducible, no atomics). */
+int pv_vocab_fused_supported(int H);
+size_t pv_vocab_fused_fwd_ws_bytes(int T, int V);
+int pv_vocab_fused_fwd(const void* h, int ldh, const void* W, int ldw, const float* bias, const int* target32, int T, int V,
+                       int H, float inv_temp, int64_t ignore_index, void* workspace, float* lse, float* nll, float* U,
+                       const int* live_rows, void* stream);
+size_t pv_vocab_fused_dw_ws_bytes(int V);
+int pv_vocab_fused_dw(const void* h, int ldh, const void* W, int ldw, const float* bias, const int* target32, const float* lse,
+                      const float* gscale, int T, int V, int H, float inv_temp, void* workspace, float* dW, int lddw,
+                      int accumulate, float* dbias, const int* live_rows, void* stream);
+/* pv_vocab_gather with the targets also as int32; perm == NULL: identity order (h_c / target_c may be NULL). */
+int pv_vocab_gather32(const void* h, int ldh, const int64_t* target, const int64_t* perm, int T, int H, void* h_c, int ldc,
+                      int64_t* target_c, int* target32, void* stream);
+/* dst[perm[new]][:] = new < *count ? src[new][:] * scale[new] * factor : 0 (perm / count NULL: identity / all rows);
+ * cols % 4 == 0 */
+int pv_scatter_rows_scaled_f32(const float* src, const float* scale, float factor, const int64_t* perm, const int* count, int T,
+                               int cols, float* dst, long ldd, void* stream);
 /* Dense [T][V] fp32 log-probs for callers that need the reference's DecoderRNN return value as a tensor
  * (decoders.py:193,292); needs lse from pv_vocab_nll_fwd. */
 int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const float* bias, const float* lse,

@@ -422,6 +422,254 @@ def gen_den_auto():
     save("den_auto", **arrs, **{"p." + k: v for k, v in pre.items()}, **post, **grads(m))
 
 
+class _CpuCurrentDevice:
+    """DLS_Auto.__init__ places its (unused here) Normal priors with `.to(torch.cuda.current_device())`
+    (dialog_models.py:3198,3203); returning 'cpu' for the duration of the constructor lets the class be built without a GPU."""
+
+    def __enter__(self):
+        self._orig = torch.cuda.current_device
+        torch.cuda.current_device = lambda: "cpu"
+
+    def __exit__(self, *exc):
+        torch.cuda.current_device = self._orig
+
+
+def _dls_cfg(B):
+    # cip_weight / gir_weight are read by DLS_Auto.forward (:3287, :3311) but defined by no parser (SURVEY section 0).
+    # gir_weight = 0 switches the density-estimate regulariser off in value and gradient: the HIP path leaves that
+    # term out (it raises in the reference as written: torch.log of the Python int n_batch = -1, :3169, :3235).
+    return types.SimpleNamespace(batch_size=B, expand_weight=0.5, converge_weight=0.1, cip_weight=1.0, gir_weight=0.0,
+                                 ost=False)
+
+
+def _redraw_uniform(seed, shapes):
+    torch.manual_seed(seed)
+    return [torch.rand(*s) for s in shapes]
+
+
+def gen_dls_auto():
+    """DLS_Auto.forward (dialog_models.py:3274-3352) from the reference class itself, all three branches.  Deviations
+    needed to run it, both outside the arithmetic the HIP path reproduces: the constructor runs with
+    torch.cuda.current_device patched to 'cpu' (_CpuCurrentDevice), and n_batch (:3169, the int -1) is set to
+    tensor(B) so that density_estimate's torch.log (:3235) has a tensor argument; with gir_weight = 0 that term then
+    contributes exactly 0.  The uniform draws of dis_reparameterization (:3207) come from the seeded CPU generator and are
+    re-drawn in the same order and stored."""
+    from models import dialog_models as dm
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_modules as R
+    B, d0, dmax = 10, 4, 16
+    for tag, restarted, training in (("train", False, True), ("restarted_train", True, True), ("restarted_eval", True, False)):
+        cfg = _dls_cfg(B)
+        torch.manual_seed(81)
+        with _CpuCurrentDevice():
+            m = dm.DLS_Auto(d0, dmax, cfg)
+        m.n_batch = torch.tensor(float(B))
+        m.train(training)
+        pre = {k: npy(v).copy() for k, v in m.state_dict().items() if k != "batch_arrange"}
+        widths = [2 * d0 * 2 ** i for i in range(3)]                       # act[-1], act[-2], act[-3]
+        output = torch.randn(B, d0, requires_grad=True)
+        rec_output = torch.randn(B, d0, requires_grad=True)
+        act1 = [torch.randn(B, w, requires_grad=True) for w in reversed(widths)]
+        act2 = [torch.randn(B, w, requires_grad=True) for w in reversed(widths)]
+        torch.manual_seed(82)
+        z, rkl = m(output, rec_output, act1, act2, restarted)
+        (z.sum() * 0.1 + rkl).backward()
+        noise = _redraw_uniform(82, [(B, w) for w in widths])
+        o = R.DLSAuto(d0, dmax, cfg)
+        o.load_state_dict({k: torch.from_numpy(v) for k, v in pre.items()})
+        o.train(training)
+        z2, rkl2 = o(output.detach(), rec_output.detach(), [a.detach() for a in act1], [a.detach() for a in act2],
+                     restarted, noise=noise)
+        assert torch.allclose(z2, z, rtol=1e-4, atol=2e-5) and abs(float(rkl2) - float(rkl)) <= 1e-5 * abs(float(rkl)), \
+            (tag, float((z2 - z).abs().max()), float(rkl2), float(rkl))
+        arrs = dict(output=output, rec_output=rec_output, z=z, rkl=rkl, d_output=output.grad, d_rec_output=rec_output.grad,
+                    restarted=np.array(restarted), training=np.array(training))
+        for i in range(3):
+            arrs.update({"act1_%d" % i: act1[i], "act2_%d" % i: act2[i], "noise_%d" % i: noise[i]})
+            for nm, a in (("d_act1_%d" % i, act1[i]), ("d_act2_%d" % i, act2[i])):
+                if a.grad is not None:
+                    arrs[nm] = a.grad
+        post = {k: v for k, v in sd(m, "post.").items() if k.endswith("weight_u") or k.endswith("weight_v")}
+        save("dls_auto_" + tag, **arrs, **{"p." + k: v for k, v in pre.items()}, **post,
+             **{k: v for k, v in grads(m).items() if "batch_arrange" not in k})
+
+
+def gen_composed_step(encoders, decoders, nn_lib, criterions):
+    """The composed DLS_VAE training step of pevae_amd/dls_vae.py built from the REFERENCE's own classes (SURVEY 3.2 /
+    8c): nn.Embedding tables (dialog_models.py:468-502), EncoderRNN (:530), DecoderRNN sharing the word embedding
+    (:560-570), NLLEntropy / Perplexity (:634-637) and, per latent stack,
+      'gauss': Hidden2Gaussian heads, z = mu + exp(logvar) * eps (:191-203), NormKLLoss, LinearConnector (:626);
+      'dls'  : DlsRec / DlsPri / DLS_Auto / x_init_connector = Block -> Block (:3401-3417, :3529-3538).
+    Data flow of FS_VAE.forward (:755-818), loss = vae_nll + vae_rkl (:3451-3465).  What is NOT the reference's: the
+    composition itself (its DLS_VAE cannot be constructed), prior_fc + tanh as the condition encoder.
+    Parameters are stored under the state_dict keys of pevae_amd.dls_vae.DLSVAE."""
+    from models import dialog_models as dm
+    V, E, H, L, B, Z, NU, NI = 97, 12, 32, 7, 6, 8, 11, 9
+    for stack in ("gauss", "dls"):
+        torch.manual_seed(91)
+        cfg = _dls_cfg(B)
+        x_embedding = torch.nn.Embedding(V, E, padding_idx=0)
+        user_embedding, item_embedding = torch.nn.Embedding(NU, H // 2), torch.nn.Embedding(NI, H // 2)
+        rating_embedding = torch.nn.Embedding(5, H // 2)
+        x_encoder = encoders.EncoderRNN(E, H, dropout_p=0.0, rnn_cell="gru", variable_lengths=False)
+        x_decoder = make_decoder(decoders, vocab_size=V, max_len=L, input_size=E, hidden_size=H, sos_id=4, eos_id=5,
+                                 unk_id=1, n_layers=1, rnn_cell="gru", input_dropout_p=0.0, dropout_p=0.0,
+                                 use_attention=False, use_gpu=False, embedding=x_embedding)
+        prior_fc = torch.nn.Linear(3 * (H // 2), H)
+        mods = dict(x_embedding=x_embedding, user_embedding=user_embedding, item_embedding=item_embedding,
+                    rating_embedding=rating_embedding, x_encoder=x_encoder, x_decoder=x_decoder, prior_fc=prior_fc)
+        if stack == "gauss":
+            mods.update(rec_head=nn_lib.Hidden2Gaussian(H, Z), pri_head=nn_lib.Hidden2Gaussian(H, Z),
+                        x_init_connector=nn_lib.LinearConnector(Z, H, False))
+        else:
+            with _CpuCurrentDevice():
+                sup = dm.DLS_Auto(H // 32, H // 8, cfg)
+            sup.n_batch = torch.tensor(float(B))
+            mods.update(rec_encoder=dm.DlsRec(H, H // 16, cfg), pri_encoder=dm.DlsPri(H, H // 16, cfg), sup_decoder=sup,
+                        x_init_connector=torch.nn.Sequential(dm.Block(H // 4, H // 2, H // 2), dm.Block(H // 2, H, H)))
+        model = torch.nn.ModuleDict(mods)
+        model.train()
+        nll_loss, ppl = criterions.NLLEntropy(0, None), criterions.Perplexity(0, None)
+        kl_loss = criterions.NormKLLoss(unit_average=False)
+        pre = {k: npy(v).copy() for k, v in model.state_dict().items() if "batch_arrange" not in k}
+        # batch in the format of YELPDataLoader.batcher (data_loaders.py:704-715)
+        lens = torch.randint(3, L + 1, (B,))
+        ids = torch.randint(6, V, (B, L))
+        ids = torch.where(torch.arange(L).unsqueeze(0) < lens.unsqueeze(1), ids, torch.zeros_like(ids))
+        ids[:, 0] = 4
+        ids[torch.arange(B), lens - 1] = 5
+        ans = torch.cat([ids[:, 1:], torch.zeros(B, 1, dtype=torch.long)], 1)
+        user, item = torch.randint(0, NU, (B,)), torch.randint(0, NI, (B,))
+        ratings = torch.randint(0, 5, (B,)).float()
+        # -- the step ------------------------------------------------------------------------------------------
+        u, it = user_embedding(user), item_embedding(item)                                  # :758-759
+        r = rating_embedding(ratings.ge(3).int())                                           # :760
+        enc_outs, enc_last = x_encoder(x_embedding(ids))                                    # :765
+        h = enc_last.transpose(0, 1).contiguous().squeeze(1)                                # :766
+        prior_h = torch.tanh(prior_fc(torch.cat([u, it, r], -1)))
+        if stack == "gauss":
+            mu_q, lv_q = mods["rec_head"](h)
+            mu_p, lv_p = mods["pri_head"](prior_h)
+            eps = torch.randn(B, Z)
+            z = eps * torch.exp(lv_q) + mu_q                                                # :191-203
+            rkl = kl_loss(mu_q, lv_q, mu_p, lv_p)
+            dec_init = mods["x_init_connector"](z)                                          # :711
+            noise = {"eps": eps}
+        else:
+            z_pri, pri_state = mods["pri_encoder"](prior_h.unsqueeze(1))                    # :3529 (output[:, 0])
+            z_rec, rec_state = mods["rec_encoder"](h.unsqueeze(1))                          # :3530
+            torch.manual_seed(92)
+            z, rkl = mods["sup_decoder"](z_pri, z_rec, rec_state, pri_state, False)         # :3535
+            draws = _redraw_uniform(92, [(B, H // 16), (B, H // 8), (B, H // 4)])
+            noise = {"eps_%d" % i: d for i, d in enumerate(draws)}
+            dec_init = mods["x_init_connector"](z).unsqueeze(0)                             # :3473
+        logp, _, _ = x_decoder(B, ids, dec_init, mode=decoders.TEACH_FORCE)                 # :712
+        vae_nll, vae_ppl = nll_loss(logp, ans), ppl(logp, ans)                              # :790-791
+        (vae_nll + rkl).backward()                                                          # :3451-3465
+        g = {"g." + k: npy(p.grad) for k, p in model.named_parameters() if p.grad is not None and "batch_arrange" not in k}
+        post = {"post." + k: npy(v).copy() for k, v in model.state_dict().items()
+                if k.endswith("weight_u") or k.endswith("weight_v")}
+        save("composed_step_" + stack, input_ids=ids, ans_ids=ans, user_ids=user, item_ids=item, ratings=ratings,
+             vae_nll=vae_nll, vae_ppl=vae_ppl, vae_rkl=rkl, dims=np.array([V, E, H, L, B, Z, NU, NI]),
+             **noise, **{"p." + k: v for k, v in pre.items()}, **post, **g)
+
+
+def gen_yelp_data_path():
+    """Real data path of the step from the reference's own code: yelp._process_reivews (corpora.py:609-622),
+    yelp._build_vocab (:624-651) and YELPDataLoader.batcher (data_loaders.py:636-715).  The `yelp` class cannot be
+    constructed (it unpickles corpus files that do not ship), so its two methods are called on a stand-in object that
+    carries the attributes they read; the tokenizer is nltk.RegexpTokenizer(r'\\w+|<sil>|[^\\w\\s]+').tokenize in the
+    reference (utils.py:241-242) -- nltk is absent here, and with gaps=False that class is re.findall of the same pattern,
+    which is what the stand-in uses.  Output: tests/golden/yelp_data_path.json (raw reviews, processed rows, vocabulary,
+    collated batches as lists)."""
+    import json
+    import random
+    import re
+    from models.dataset import corpora, data_loaders
+    rnd = random.Random(5)
+    pool = ["good", "food", "the", "service", "was", "great", "slow", "place", "pizza", "love", "it's", "not", "bad", "!", ",",
+            "very", "tasty", "staff", "friendly", "never", "again", "<sil>", "5-star", "wait...", "ok"]
+    def review():
+        return " ".join(rnd.choice(pool) for _ in range(rnd.randint(1, 14)))
+    raw = {name: [(rnd.randrange(40), rnd.randrange(25), rnd.randrange(7), review(), "unused", rnd.randint(1, 5))
+                  for _ in range(n)] for name, n in (("train", 40), ("valid", 12), ("test", 9), ("pretrain", 7))}
+    obj = types.SimpleNamespace(tokenize=re.compile(r"\w+|<sil>|[^\w\s]+").findall)
+    torch.manual_seed(101)
+    rows = {name: corpora.yelp._process_reivews(obj, data) for name, data in raw.items()}
+    obj.train_corpus, obj.valid_corpus, obj.test_corpus, obj.pretrain_corpus = (rows[k] for k in ("train", "valid", "test", "pretrain"))
+    corpora.yelp._build_vocab(obj, 30)                      # cut-off below the raw vocabulary size: OOV words exist
+    batches = []
+    for max_seq_len, sel in ((8, range(0, 10)), (8, range(10, 13)), (16, range(20, 27)), (5, range(30, 40))):
+        b = data_loaders.YELPDataLoader.batcher(obj.rev_vocab, max_seq_len, "cpu")([rows["train"][i] for i in sel])
+        batches.append(dict(max_seq_len=max_seq_len, rows=list(sel), out={k: v.tolist() for k, v in b.items()}))
+    out = dict(raw={k: [list(r) for r in v] for k, v in raw.items()},
+               rows={k: [list(r) for r in v] for k, v in rows.items()},
+               max_vocab_cnt=30, vocab=obj.vocab, unk_id=obj.unk_id, batches=batches)
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "yelp_data_path.json"), "w") as fh:
+        json.dump(out, fh)
+    print("wrote yelp_data_path.json:", len(obj.vocab), "vocabulary entries,", len(batches), "batches")
+
+
+def gen_decoder_sample_beam(decoders):
+    """Free-running `sample` and `beam` decoding (decoders.py:255-270, :294-328).
+    sample: the reference run as is (seeded).  torch.multinomial(probs, 1) on the CPU draws q ~ Exp(1) per entry and returns
+    argmax(probs / q); the same stream is re-drawn here (one [B, V] exponential_ per token, in order), checked to give
+    the reference's symbols, and stored -- the HIP path and the oracle take it as input.
+    beam: the reference's own forward() RAISES on this torch at the back-tracking step (torch.cat of 0-d tensors,
+    :318-322; and top_id.div at :267 is a true division since torch 1.5).  The golden therefore drives the reference's own
+    forward_step (:171-194) per token and restates decode()'s beam branch (:257-270) and the back-tracking (:307-328) with
+    floor division -- the deviation DESIGN.md section 1 lists.  As in the reference, the decoder state is NOT re-ordered by
+    the back pointers and lengths are taken over all B * beam raw symbol rows."""
+    V, L, E, H, B, beam = 37, 7, 12, 16, 4, 3
+    torch.manual_seed(23)
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = make_decoder(decoders, vocab_size=V, max_len=L, input_size=E, hidden_size=H, sos_id=1, eos_id=2, unk_id=3,
+                       rnn_cell="gru", use_gpu=False, embedding=emb)
+    dec.eval()
+    with torch.no_grad():
+        dec.project.bias[2] += 1.0                  # EOS reachable
+    ids = torch.randint(4, V, (B, L))
+    h0 = torch.randn(1, B, H) * 0.5
+    # ---- sample ----------------------------------------------------------------------------------------------------
+    torch.manual_seed(24)
+    with torch.no_grad():
+        logp, hid, ret = dec(B, ids, h0, mode=decoders.GEN, gen_type="sample")
+    seq = torch.cat(ret["sequence"], dim=1)
+    torch.manual_seed(24)
+    qs = torch.stack([torch.empty(B, V).exponential_() for _ in range(L)])
+    again = torch.stack([(torch.exp(logp[:, t]) / qs[t]).argmax(-1) for t in range(L)], 1)
+    assert torch.equal(again, seq), "torch.multinomial's CPU stream is not exp-trick argmax on this torch build"
+    save("decoder_gen_sample", ids=ids, h0=h0, logp=logp, hid=hid, seq=seq, length=np.array(ret["length"]), q=qs, **sd(dec))
+    # ---- beam ------------------------------------------------------------------------------------------------------
+    with torch.no_grad():
+        inp = torch.full((B * beam, 1), 1, dtype=torch.long)                   # :216-219 sos_id
+        hidden = dec.repeat_state(h0, B, beam)                                 # :225-227
+        outs, symbols_all, back_all, cum = [], [], [], None
+        lengths = np.array([L] * B * beam)
+        for di in range(L):
+            step_out, hidden, _ = dec.forward_step(inp, hidden, None)
+            outs.append(step_out)
+            sl = step_out.squeeze(1)
+            score = sl.view(B, -1)[:, 0:V] if di == 0 else (cum + sl).view(B, -1)
+            top_v, top_id = score.topk(beam)
+            back_all.append(torch.div(top_id, V, rounding_mode="floor").view(-1, 1))
+            sym = top_id.fmod(V).view(-1, 1)
+            cum = top_v.view(-1, 1)
+            symbols_all.append(sym)
+            eos = sym.eq(2).view(-1).numpy()
+            lengths[((lengths > di) & eos) != 0] = len(symbols_all)          # :276-280
+            inp = sym
+        best = cum.view(-1, beam).topk(1)[1].view(-1)
+        final = []
+        for sym, bp in zip(symbols_all[::-1], back_all[::-1]):
+            final.append(sym.view(-1, beam)[torch.arange(B), best].unsqueeze(1))
+            best = bp.view(-1, beam)[torch.arange(B), best]
+        final = final[::-1]
+    save("decoder_gen_beam", ids=ids, h0=h0, logp=torch.cat(outs, 1), hid=hidden, seq=torch.cat(final, 1),
+         raw_symbols=torch.cat(symbols_all, 1), length=lengths, beam=np.array(beam), **sd(dec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -433,7 +681,9 @@ def main():
                 encoder_lstm_varlen=lambda: gen_encoder_lstm_varlen(encoders), decoder=lambda: gen_decoder(decoders),
                 attention=lambda: gen_attention(decoders), connectors=lambda: gen_connectors(nn_lib),
                 criterions=lambda: gen_criterions(criterions),
-                dialog=lambda: gen_dialog_pieces(utils), den=gen_den_auto)
+                dialog=lambda: gen_dialog_pieces(utils), den=gen_den_auto, dls_auto=gen_dls_auto, yelp=gen_yelp_data_path,
+                sample_beam=lambda: gen_decoder_sample_beam(decoders),
+                composed=lambda: gen_composed_step(encoders, decoders, nn_lib, criterions))
     for k, fn in todo.items():
         if not args.only or k in args.only.split(","):
             fn()

@@ -398,7 +398,9 @@ class DecoderRNN(BaseRNN):
                 if gen_type == "greedy":
                     sym = sl.topk(1)[1]
                 elif gen_type == "sample":
-                    sym = self.multinomial_sampling(torch.exp(sl))
+                    noise = getattr(self, "sample_noise", None)     # Exp(1) draws [L, B, V] of torch.multinomial's sampler
+                    sym = (self.multinomial_sampling(torch.exp(sl)) if noise is None
+                           else (torch.exp(sl) / noise[di]).argmax(-1, keepdim=True))
                 elif gen_type == "beam":                                       # decoders.py:257-270
                     if di == 0:
                         score = sl.view(batch_size, -1)[:, :self.output_size]

@@ -26,16 +26,26 @@ class RefDLSVAE(nn.Module):
         self.item_embedding = nn.Embedding(c.n_item, self.emb_size)
         self.rating_embedding = nn.Embedding(5, self.emb_size)
         self.x_encoder = R.EncoderRNN(E, H, dropout_p=c.dropout, rnn_cell=c.rnn_cell, variable_lengths=False)
-        self.x_decoder = R.DecoderRNN(c.vocab_size, c.max_seq_len, E, H, self.go_id, self.eos_id, self.unk_id,
+        self.use_feature = bool(getattr(c, "use_feature", False))
+        if self.use_feature:                                                             # :488, :762-763
+            self.feature_embedding = nn.Embedding(c.n_feature, self.emb_size)
+        self.x_decoder = R.DecoderRNN(c.vocab_size, c.max_seq_len, E + (self.emb_size if self.use_feature else 0), H,
+                                      self.go_id, self.eos_id, self.unk_id,
                                       n_layers=c.num_layer, rnn_cell=c.rnn_cell, input_dropout_p=c.dropout,
                                       dropout_p=c.dropout, use_attention=c.use_attention, attn_mode=c.attn_type,
                                       attn_size=H, use_gpu=False, embedding=self.x_embedding)
         self.latent_stack = getattr(c, "latent_stack", "gauss")
+        self.use_mutual = bool(getattr(c, "use_mutual", False)) and self.latent_stack == "dls"
         if self.latent_stack == "dls":                                                   # dialog_models.py:3401-3417
             self.rec_encoder = R.DlsPyramid(H, H // 16, c)
             self.pri_encoder = R.DlsPyramid(H, H // 16, c, wrap=True)
-            self.sup_decoder = R.DLSAuto(H // 32, H // 8, c)
-            self.x_init_connector = nn.Sequential(R.Block(H // 4, H // 2, H // 2), R.Block(H // 2, H, H))
+            if self.use_mutual:                                                          # DeN_VAE, :2917-2931
+                self.sup_decoder = R.DeNAuto(H // 32, H // 16, c)
+                self.x_init_connector = nn.Sequential(R.Block(H // 8, H // 4, H // 4), R.Block(H // 4, H // 2, H // 2),
+                                                      R.Block(H // 2, H, H))
+            else:
+                self.sup_decoder = R.DLSAuto(H // 32, H // 8, c)
+                self.x_init_connector = nn.Sequential(R.Block(H // 4, H // 2, H // 2), R.Block(H // 2, H, H))
         self.prior_fc = nn.Linear(3 * self.emb_size, H)
         if self.latent_stack == "gauss":
             self.rec_head = R.Hidden2Gaussian(H, Z)
@@ -72,7 +82,11 @@ class RefDLSVAE(nn.Module):
         if self.latent_stack == "dls":
             z_pri, pri_state = self.pri_encoder(prior_h)
             z_rec, rec_state = self.rec_encoder(h)
-            z, rkl = self.sup_decoder(z_pri, z_rec, rec_state, pri_state, getattr(self, "restarted", False), noise=eps)
+            if self.use_mutual:                                                            # :3089
+                noise, gumbels = eps if isinstance(eps, tuple) else (eps, None)
+                z, rkl = self.sup_decoder(z_pri, rec_state, pri_state, getattr(self, "restarted", False), noise, gumbels)
+            else:
+                z, rkl = self.sup_decoder(z_pri, z_rec, rec_state, pri_state, getattr(self, "restarted", False), noise=eps)
             if not self.training:
                 rkl = None
             dec_init = self.x_init_connector(z).unsqueeze(0)
@@ -88,8 +102,9 @@ class RefDLSVAE(nn.Module):
                 z, rkl = mu_p, None
             dec_init = self.x_init_connector(z)
         ctx = enc_outs if self.config.use_attention else None
+        feature = self.feature_embedding(feed["feature_ids"]) if self.use_feature else None
         dec_outs, _, _ = self.x_decoder(B, feed["input_ids"], dec_init, mode=mode, gen_type=gen_type,
-                                        beam_size=self.config.beam_size, attn_context=ctx)
+                                        beam_size=self.config.beam_size, attn_context=ctx, latent_variable=feature)
         pack = R.Pack(vae_zkl=None, vae_nll=self.nll_loss(dec_outs, feed["ans_ids"]),
                       vae_PPL=self.ppl(dec_outs, feed["ans_ids"]), vae_rnll=None, vae_rkl=rkl)
         if self.config.do_pred:

@@ -473,11 +473,12 @@ struct ConsGroup {
   float* da[2 * CONS_MAX];                     // gradient of the normalised rows
   float* dx[2 * CONS_MAX];                     // outputs of the backward pass
   int D[CONS_MAX];
-  int n, B;
-};
+  int Dp[CONS_MAX];                            // leading dimension of a / da: round_up(D, 4)
+  int n, B, Bp;                                // Bp = round_up(B, 4): leading dimension of aT, S, dS, dST (any batch size
+};                                             // and width keeps every grouped-GEMM operand row 16-byte aligned)
 
 __global__ __launch_bounds__(256) void cons_l2norm_fwd_kernel(ConsGroup g, float alpha, float* __restrict__ alpha_dev) {
-  const int m = blockIdx.y, D = g.D[m >> 1];
+  const int m = blockIdx.y, D = g.D[m >> 1], Dp = g.Dp[m >> 1];
   const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blockIdx.x == 0 && m == 0 && threadIdx.x == 0) alpha_dev[0] = alpha;
   if (r >= g.B) return;
@@ -487,17 +488,17 @@ __global__ __launch_bounds__(256) void cons_l2norm_fwd_kernel(ConsGroup g, float
   const float n = sqrtf(wave_sum(q));
   for (int c = lane; c < D; c += 64) {
     const float v = x[c] / n;
-    g.a[m][(size_t)r * D + c] = v;
-    g.aT[m][(size_t)c * g.B + r] = v;
+    g.a[m][(size_t)r * Dp + c] = v;
+    g.aT[m][(size_t)c * g.Bp + r] = v;
   }
   if (lane == 0) g.nrm[m][r] = n;
 }
 __global__ __launch_bounds__(256) void cons_l2norm_bwd_kernel(ConsGroup g) {
-  const int m = blockIdx.y, D = g.D[m >> 1];
+  const int m = blockIdx.y, D = g.D[m >> 1], Dp = g.Dp[m >> 1];
   const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= g.B) return;
-  const float* a = g.a[m] + (size_t)r * D;
-  const float* da = g.da[m] + (size_t)r * D;
+  const float* a = g.a[m] + (size_t)r * Dp;
+  const float* da = g.da[m] + (size_t)r * Dp;
   float d = 0.f;
   for (int c = lane; c < D; c += 64) d += a[c] * da[c];
   d = wave_sum(d);
@@ -509,8 +510,8 @@ __global__ __launch_bounds__(256) void cons_lse_kernel(ConsGroup g) {
   const int p = blockIdx.y >> 1, which = blockIdx.y & 1, B = g.B;
   const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= B) return;
-  const long st = which ? B : 1;
-  const float* q = g.S[p] + (which ? i : (long)i * B);
+  const long st = which ? g.Bp : 1;
+  const float* q = g.S[p] + (which ? i : (long)i * g.Bp);
   float m = -INFINITY;
   for (int j = lane; j < B; j += 64) m = fmaxf(m, q[j * st]);
   m = wave_max(m);
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256) void cons_loss_kernel(ConsGroup g, float* __re
   float total = 0.f;
   for (int p = 0; p < g.n; ++p) {
     float s = 0.f;
-    for (int i = threadIdx.x; i < g.B; i += 256) s += g.lse_r[p][i] + g.lse_c[p][i] - 2.f * g.S[p][(long)i * g.B + i];
+    for (int i = threadIdx.x; i < g.B; i += 256) s += g.lse_r[p][i] + g.lse_c[p][i] - 2.f * g.S[p][(long)i * g.Bp + i];
     s = block_sum(s, red);
     total += s / (2.f * g.B);
     __syncthreads();
@@ -537,10 +538,10 @@ __global__ void cons_bwd_kernel(ConsGroup g, const float* __restrict__ gout) {
   const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= (long)B * B) return;
   const int i = (int)(k / B), j = (int)(k % B);
-  const float s = g.S[p][k];
+  const float s = g.S[p][(long)i * g.Bp + j];
   const float d = gout[0] / (2.f * B) * (expf(s - g.lse_r[p][i]) + expf(s - g.lse_c[p][j]) - (i == j ? 2.f : 0.f));
-  g.dS[p][k] = d;
-  g.dST[p][(long)j * B + i] = d;
+  g.dS[p][(long)i * g.Bp + j] = d;
+  g.dST[p][(long)j * g.Bp + i] = d;
 }
 
 // workspace carve-up shared by the two entry points (floats): alpha | per pair: a1 a2 nrm1 nrm2 S lse_r lse_c dS da1 da2
@@ -548,9 +549,11 @@ size_t cons_fill(ConsGroup& g, const int* D, int n, int B, float* ws) {
   size_t o = 4;
   g.n = n;
   g.B = B;
+  g.Bp = (B + 3) & ~3;
   for (int p = 0; p < n; ++p) {
     g.D[p] = D[p];
-    const size_t bd = (size_t)B * D[p], bb = (size_t)B * B;
+    g.Dp[p] = (D[p] + 3) & ~3;
+    const size_t bd = (size_t)g.Bp * g.Dp[p], bb = (size_t)B * g.Bp;
     auto take = [&](size_t k) { float* q = ws ? ws + o : nullptr; o += (k + 3) & ~(size_t)3; return q; };
     g.a[2 * p] = take(bd); g.a[2 * p + 1] = take(bd);
     g.aT[2 * p] = take(bd); g.aT[2 * p + 1] = take(bd);
@@ -584,7 +587,7 @@ int pv_cons_loss_fwd(const float* const* v1, const float* const* v2, const int* 
     g.x[2 * p] = v1[p];
     g.x[2 * p + 1] = v2[p];
     // S = alpha a1 a2^T from the K-major copies: A(m, k) = a1T[k][m], B(k, n) = a2T[k][n]
-    it[p] = LinGroupItem{g.aT[2 * p], 1, B, g.aT[2 * p + 1], B, 1, g.S[p], B, B, B, D[p], ws, 0, nullptr, 0, nullptr, nullptr};
+    it[p] = LinGroupItem{g.aT[2 * p], 1, g.Bp, g.aT[2 * p + 1], g.Bp, 1, g.S[p], g.Bp, B, B, D[p], ws, 0, nullptr, 0, nullptr, nullptr};
   }
   hipLaunchKernelGGL(cons_l2norm_fwd_kernel, dim3(cdiv(B, 4), 2 * n), dim3(256), 0, st, g, alpha, ws);
   PV_LAUNCH_CHECK("cons_l2norm_fwd_kernel");
@@ -609,8 +612,8 @@ int pv_cons_loss_bwd(const float* gout, const int* D, int n, int B, float* ws, f
     g.dx[2 * p] = dv1[p];
     g.dx[2 * p + 1] = dv2[p];
     // da1 = alpha dS a2 : A(m, k) = dST[k][m] ;  da2 = alpha dS^T a1 : A(m, k) = dS[k][m] ;  B operands row-major [B][D]
-    it[2 * p] = LinGroupItem{g.dST[p], 1, B, g.a[2 * p + 1], D[p], 1, g.da[2 * p], D[p], B, D[p], B, ws, 0, nullptr, 0, nullptr, nullptr};
-    it[2 * p + 1] = LinGroupItem{g.dS[p], 1, B, g.a[2 * p], D[p], 1, g.da[2 * p + 1], D[p], B, D[p], B, ws, 0, nullptr, 0, nullptr, nullptr};
+    it[2 * p] = LinGroupItem{g.dST[p], 1, g.Bp, g.a[2 * p + 1], g.Dp[p], 1, g.da[2 * p], g.Dp[p], B, D[p], B, ws, 0, nullptr, 0, nullptr, nullptr};
+    it[2 * p + 1] = LinGroupItem{g.dS[p], 1, g.Bp, g.a[2 * p], g.Dp[p], 1, g.da[2 * p + 1], g.Dp[p], B, D[p], B, ws, 0, nullptr, 0, nullptr, nullptr};
   }
   const long nn = (long)B * B;
   hipLaunchKernelGGL(cons_bwd_kernel, dim3((unsigned)((nn + 255) / 256), n), dim3(256), 0, st, g, gout);

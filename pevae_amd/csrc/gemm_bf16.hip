@@ -932,6 +932,37 @@ int pv_vocab_gather(const void* h, int ldh, const int64_t* target, const int64_t
   return PV_OK;
 }
 
+// the same gather with the targets also as int32 (what the fused vocabulary kernels stage through LDS); perm == NULL:
+// identity order (h_c may then be NULL: only the int32 targets are produced)
+__global__ void vocab_gather32_kernel(const bf16_t* __restrict__ h, int ldh, const int64_t* __restrict__ target,
+                                      const int64_t* __restrict__ perm, int T, int chunks, bf16_t* __restrict__ hc, int ldc,
+                                      int64_t* __restrict__ target_c, int* __restrict__ target32) {
+  const long n = (long)T * chunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / chunks), ch = (int)(i % chunks);
+    const long src = perm ? perm[row] : row;
+    if (hc) *(uint4*)(hc + (size_t)row * ldc + ch * 8) = *(const uint4*)(h + (size_t)src * ldh + ch * 8);
+    if (ch == 0) {
+      const int64_t t = target[src];
+      if (target_c) target_c[row] = t;
+      target32[row] = (t < -2147483647 || t > 2147483647) ? -2147483647 : (int)t;
+    }
+  }
+}
+
+extern "C" int pv_vocab_gather32(const void* h, int ldh, const int64_t* target, const int64_t* perm, int T, int H, void* h_c,
+                                 int ldc, int64_t* target_c, int* target32, void* stream) {
+  PV_REQUIRE(target && target32 && T > 0 && H > 0 && H % 8 == 0, "pv_vocab_gather32: bad argument");
+  PV_REQUIRE(!h_c || (h && ldh % 8 == 0 && ldc % 8 == 0 && ldh >= H && ldc >= H && ((uintptr_t)h & 15) == 0 &&
+                      ((uintptr_t)h_c & 15) == 0), "pv_vocab_gather32: rows must be 16-byte aligned, leading dimensions multiples of 8");
+  const long n = (long)T * (H / 8);
+  const long gx = (n + 255) / 256;
+  hipLaunchKernelGGL(vocab_gather32_kernel, dim3((unsigned)(gx > 4096 ? 4096 : gx)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)h, ldh, target, perm, T, H / 8, (bf16_t*)h_c, ldc, target_c, target32);
+  PV_LAUNCH_CHECK("vocab_gather32_kernel");
+  return PV_OK;
+}
+
 int pv_scatter_rows_f32(const float* src, long lds, const int64_t* perm, const int* count, int T, int cols, float* dst,
                         long ldd, void* stream) {
   PV_REQUIRE(src && perm && count && dst && T > 0 && cols > 0 && lds >= cols && ldd >= cols, "pv_scatter_rows_f32: bad argument");

@@ -11,6 +11,7 @@ worker; here a batch is collated into a few numpy arrays, staged in reused page-
 asynchronous H2D copies on the consumer's stream, so the copy of batch k+1 overlaps step k.  A row is the corpus tuple
 (user, item, feature, tokens, rating in 1..5, rd) of corpora.py:609-622.  The corpus pickles themselves are not part of
 the path (none ship with the reference)."""
+import re
 from collections import Counter
 
 import numpy as np
@@ -18,6 +19,26 @@ import torch
 
 PAD, UNK, BOS, EOS = "<pad>", "<unk>", "<s>", "</s>"        # corpora.py:533-536
 SYS, USR = "<sys>", "<usr>"                                  # corpora.py:24-25
+
+
+_CHAT_TOKEN = re.compile(r"\w+|<sil>|[^\w\s]+")
+
+
+def chat_tokenize(text):
+    """utils.get_chat_tokenize (utils.py:241-242): nltk.RegexpTokenizer(r'\\w+|<sil>|[^\\w\\s]+').tokenize, which with
+    gaps=False is re.findall of that pattern (nltk itself is not needed)."""
+    return _CHAT_TOKEN.findall(text)
+
+
+def process_reviews(data, tokenize=chat_tokenize, rd=None):
+    """yelp._process_reivews (corpora.py:609-622): raw review tuples (user, item, feature, text, ..., rating) -> corpus
+    rows (user, item, feature, [BOS] + tokens + [EOS], rating, rd).  rd is the per-sample N(0,1) draw the reference
+    attaches with torch.randn(1).item() (:621); pass a sequence to fix it, default draws it the same way."""
+    res = []
+    for i, d in enumerate(data):
+        sentence = [BOS] + tokenize(d[3]) + [EOS]
+        res.append((d[0], d[1], d[2], sentence, d[-1], torch.randn(1).item() if rd is None else rd[i]))
+    return res
 
 
 def build_vocab(corpora, max_vocab_cnt):

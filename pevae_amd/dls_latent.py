@@ -29,13 +29,14 @@ class SNLinear(nn.Module):
         self.register_buffer("weight_v", nn.functional.normalize(torch.randn(in_f), dim=0, eps=eps))
 
         self._inv_sigma_pre = None      # set by ops.spectral_prepass for exactly one forward
+        self.clone_uv = False           # True for modules that run more than once per step (DeNAuto's discriminator)
 
     def forward(self, x, x_act=None, emit_gelu=False):
         """y = (x_act if given else x) @ (W / sigma)^T + b.  x_act = gelu(x) written by the producer of x; the gradient
         flows to x through gelu'.  emit_gelu: return (y, gelu(y)) so that the next linear gets its activation for free."""
         pre, self._inv_sigma_pre = self._inv_sigma_pre, None
         y, gy = ops.sn_linear(x, self.weight_orig, self.bias, self.weight_u, self.weight_v, self.training, self.eps,
-                              x_act=x_act, emit_gelu=emit_gelu, inv_sigma=pre)
+                              x_act=x_act, emit_gelu=emit_gelu, inv_sigma=pre, clone_uv=self.clone_uv)
         return (y, gy) if emit_gelu else y
 
 
@@ -245,6 +246,9 @@ class DeNAuto(nn.Module):
                                                nn.Sigmoid()))
             input_dim *= 2
             cnt += 1
+        for m in self.y_z_info.modules():                 # the discriminator scores positive and negative pairs: two
+            if isinstance(m, SNLinear):                   # forwards (two power iterations, as torch's hook does) per step
+                m.clone_uv = True
 
     @staticmethod
     def _kl(mu1, mu2, ls1, ls2):

@@ -68,16 +68,29 @@ class DLSVAE(nn.Module):
         self.item_embedding = nn.Embedding(c.n_item, self.emb_size)                      # :475
         self.rating_embedding = nn.Embedding(5, self.emb_size)                           # :502
         self.x_encoder = EncoderRNN(E, H, dropout_p=c.dropout, rnn_cell=c.rnn_cell, variable_lengths=False)  # :530
-        self.x_decoder = DecoderRNN(c.vocab_size, c.max_seq_len, E, H, self.go_id, self.eos_id, self.unk_id,
+        self.use_feature = bool(getattr(c, "use_feature", False))
+        if self.use_feature:                                                             # :488, :555-558, :762-763
+            self.feature_embedding = nn.Embedding(c.n_feature, self.emb_size)
+        self.x_decoder = DecoderRNN(c.vocab_size, c.max_seq_len, E + (self.emb_size if self.use_feature else 0), H,
+                                    self.go_id, self.eos_id, self.unk_id,
                                     n_layers=c.num_layer, rnn_cell=c.rnn_cell, input_dropout_p=c.dropout,
                                     dropout_p=c.dropout, use_attention=c.use_attention, attn_mode=c.attn_type,
                                     attn_size=H, use_gpu=c.use_gpu, embedding=self.x_embedding)               # :560-570
         self.latent_stack = getattr(c, "latent_stack", "gauss")
+        self.use_mutual = bool(getattr(c, "use_mutual", False)) and self.latent_stack == "dls"
         if self.latent_stack == "dls":                                                   # dialog_models.py:3401-3417
             self.rec_encoder = L.DlsRec(H, H // 16, c)
             self.pri_encoder = L.DlsPri(H, H // 16, c)
-            self.sup_decoder = L.DLSAuto(H // 32, H // 8, c)
-            self.x_init_connector = nn.Sequential(L.Block(H // 4, H // 2, H // 2), L.Block(H // 2, H, H))
+            if self.use_mutual:
+                # --use_mutual (configs[4]): the DEM mutual-information stack, wired as DeN_VAE wires DeN_Auto
+                # (dialog_models.py:2917-2931, :3089): two fusion levels with a discriminator each -> z [B, H/8], then
+                # a three-Block connector H/8 -> H/4 -> H/2 -> H
+                self.sup_decoder = L.DeNAuto(H // 32, H // 16, c)
+                self.x_init_connector = nn.Sequential(L.Block(H // 8, H // 4, H // 4), L.Block(H // 4, H // 2, H // 2),
+                                                      L.Block(H // 2, H, H))
+            else:
+                self.sup_decoder = L.DLSAuto(H // 32, H // 8, c)
+                self.x_init_connector = nn.Sequential(L.Block(H // 4, H // 2, H // 2), L.Block(H // 2, H, H))
         self.prior_fc = nn.Linear(3 * self.emb_size, H)
         if self.latent_stack == "gauss":
             self.rec_head = nn_lib.Hidden2Gaussian(H, Z)
@@ -89,6 +102,7 @@ class DLSVAE(nn.Module):
         self.ppl = criterions.Perplexity(self.pad_id, c)                                 # :637
         self.kl_loss = criterions.NormKLLoss(unit_average=False)
         self.backLoss = True
+        self.split_backward, self._cut = False, None
 
     # -- loss contract (dialog_models.py:3451-3465) ----------------------------------------------------------
     def valid_loss(self, loss, batch_cnt=None, step=None):
@@ -104,7 +118,27 @@ class DLSVAE(nn.Module):
         return total
 
     def backward(self, batch_cnt, loss, step=None):                                     # dialog_models.py:51-53
+        if self._cut is not None:
+            self.backward_vocab(loss)
+            return self.backward_rest(loss)
         self.valid_loss(loss, batch_cnt, step=step).backward()
+
+    def backward_vocab(self, loss):
+        """First part of the backward pass with split_backward: d(valid_loss)/d(vae_nll) = 1 (:3451-3465), so this is the
+        vocabulary softmax / projection backward alone; it leaves dL/d(decoder states) in the cut leaf."""
+        loss.vae_nll.backward()
+
+    def backward_rest(self, loss):
+        hid, leaf = self._cut
+        self._cut = None
+        tensors, grads = [hid], [leaf.grad]
+        if self.training and loss.vae_rkl is not None:
+            tensors.append(loss.vae_rkl)
+            grads.append(None)
+        if self.config.do_pred and loss.get("rating_mse") is not None:
+            tensors.append(loss.rating_mse)
+            grads.append(None)
+        torch.autograd.backward(tensors, grads)
 
     def forward(self, data_feed, mode=TEACH_FORCE, gen_type="greedy", eps=None):
         if self.training and self.config.dropout > 0:
@@ -123,8 +157,12 @@ class DLSVAE(nn.Module):
             ops.spectral_prepass(self._sn_modules, self.training, cache=self._sn_cache)    # all 105 power iterations, one launch
             (z_pri, pri_state), (z_rec, rec_state) = L.pyramid_pair(self.pri_encoder, prior_h,         # :3529
                                                                     self.rec_encoder, h)               # :3530
-            z, rkl = self.sup_decoder(z_pri, z_rec, rec_state, pri_state,
-                                      getattr(self, "restarted", False), noise=eps)        # :3535
+            if self.use_mutual:                                                            # :3089 (DeN_VAE)
+                noise, gumbels = eps if isinstance(eps, tuple) else (eps, None)
+                z, rkl = self.sup_decoder(z_pri, rec_state, pri_state, getattr(self, "restarted", False), noise, gumbels)
+            else:
+                z, rkl = self.sup_decoder(z_pri, z_rec, rec_state, pri_state,
+                                          getattr(self, "restarted", False), noise=eps)    # :3535
             if not self.training:
                 rkl = None                                                                 # :3571
             dec_init = self.x_init_connector(z).unsqueeze(0)                                  # :3473
@@ -140,9 +178,17 @@ class DLSVAE(nn.Module):
                 z, rkl = mu_p, None                                                        # eval: condition on the prior mean
             dec_init = self.x_init_connector(z)                                            # :711
         attn_ctx = enc_outs if self.config.use_attention else None
+        feature = (ops.embedding(self.feature_embedding.weight, data_feed["feature_ids"])
+                   if self.use_feature else None)                                          # :762-763
         dec_outs, dec_last, dec_ctx = self.x_decoder(B, data_feed["input_ids"], dec_init, mode=mode,
                                                      gen_type=gen_type, beam_size=self.config.beam_size,
-                                                     attn_context=attn_ctx)                # :712
+                                                     attn_context=attn_ctx, latent_variable=feature)   # :712
+        if self.split_backward and torch.is_grad_enabled() and hasattr(dec_outs, "token_nll"):
+            # data-parallel overlap (dp.FlatGradReducer.start / finish): cut the autograd graph at the decoder states, so
+            # that backward_vocab() yields the vocabulary projection's gradient -- a third of the dense bytes -- before
+            # the recurrences and the latent stack run backward (backward_rest)
+            leaf = dec_outs.hid.detach().requires_grad_()
+            self._cut, dec_outs.hid = (dec_outs.hid, leaf), leaf
         if not self.backLoss:                                                              # generation: :813-817
             if self.config.do_pred:
                 return dec_ctx, data_feed["ans_ids"], self._rating(user, item)
@@ -179,7 +225,8 @@ def synthetic_batch(config, batch_size, seed, device="cpu"):
     user = torch.randint(0, config.n_user, (B,), generator=g)
     item = torch.randint(0, config.n_item, (B,), generator=g)
     feed = {
-        "user_ids": user, "item_ids": item, "feature_ids": torch.zeros(B, dtype=torch.long),
+        "user_ids": user, "item_ids": item,
+        "feature_ids": torch.randint(0, max(1, getattr(config, "n_feature", 0)), (B,), generator=g),
         "sentence_embeddings": ids, "attention_masks": (ids != 0).long(),
         "ratings": torch.randint(0, 5, (B,), generator=g).float(), "input_ids": ids.clone(), "ans_ids": ans,
         "rd_ids": torch.randn(B, generator=g), "ui_ids": user + 1000000000 * item,

@@ -73,34 +73,55 @@ class FlatGradReducer(object):
     the dense part, and for `sparse_tables` -- [(offset, rows, dim)] ranges of embedding tables whose local gradient is
     non-zero only in the rows looked up this step (user / item tables: 256 of 30000 / 20000 rows) -- one all-gather of
     (ids, rows) per step instead of all-reducing the whole table (0.26 MB instead of 2 x 25 MB per rank at
-    the Yelp shape).  reduce(ids) takes the looked-up ids of each sparse table, in the same order."""
+    the Yelp shape).  reduce(ids) takes the looked-up ids of each sparse table, in the same order.
 
-    def __init__(self, flat_grad, world_size, bucket_bytes=16 << 20, group=None, sparse_tables=(), average=True):
+    Overlap with backward: `early_ranges` -- [(start, end)] stretches whose gradient is final before the rest of the
+    backward pass has run (the vocabulary projection: a third of the dense bytes, written by the first backward
+    kernels).  start() launches their all-reduces and returns at once, so they travel over xGMI while the caller runs
+    the remaining backward; finish(ids) exchanges everything else and waits for all of it.  reduce() = start + finish."""
+
+    def __init__(self, flat_grad, world_size, bucket_bytes=16 << 20, group=None, sparse_tables=(), average=True,
+                 early_ranges=()):
         # average=False leaves the SUM in the buffer: FlatAdam(grad_scale=1/world) applies the 1/world inside its guard
         # and Adam kernels, which saves a read-modify-write pass over the whole flat gradient (124 MB at the Yelp shape)
         self.flat, self.world, self.group, self.average = flat_grad, world_size, group, average
         self.tables = sorted(tuple(t) for t in sparse_tables)
         be = max(1, bucket_bytes // 4)
-        self.bounds, at = [], 0
+        early = sorted((int(a), int(b)) for a, b in early_ranges)
+        self.bounds, self.early_bounds, at = [], [], 0
         for off, rows, dim in self.tables + [(flat_grad.numel(), 0, 0)]:       # dense stretches between the tables
             if off < at:
                 raise ValueError("FlatGradReducer: sparse tables overlap")
-            self.bounds += [(at + s, at + e) for s, e in bucket_bounds(off - at, be)]
+            cuts = [at] + [x for a, b in early for x in (a, b) if at < x < off] + [off]
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                is_early = any(a <= lo and hi <= b for a, b in early)
+                (self.early_bounds if is_early else self.bounds).extend((lo + s, lo + e) for s, e in bucket_bounds(hi - lo, be))
             at = off + rows * dim
         if at > flat_grad.numel():
             raise ValueError("FlatGradReducer: sparse table beyond the buffer")
+        for a, b in early:
+            if sum(e - s for s, e in self.early_bounds if a <= s and e <= b) != b - a:
+                raise ValueError("FlatGradReducer: an early range must lie inside one dense stretch")
+        self._works = []
 
     def table_view(self, i):
         off, rows, dim = self.tables[i]
         return self.flat[off:off + rows * dim].view(rows, dim)
 
-    def reduce(self, sparse_ids=()):
+    def _all_reduce(self, bounds):
+        return [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in bounds]
+
+    def start(self):
+        """Launch the all-reduces of the early ranges (their gradient must be complete on the current stream)."""
+        if self.world > 1:
+            self._works += self._all_reduce(self.early_bounds)
+
+    def finish(self, sparse_ids=()):
         if self.world <= 1:
             return
         if len(sparse_ids) != len(self.tables):
             raise ValueError("FlatGradReducer.reduce: %d sparse tables need %d id tensors" % (len(self.tables), len(sparse_ids)))
-        works = [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for s, e in self.bounds]
+        works, self._works = self._works + self._all_reduce(self.bounds), []
         packed = [pack_sparse_rows(self.table_view(i), ids) for i, ids in enumerate(sparse_ids)]
         gathered = []
         for ids, rows in packed:                         # every rank looks up the same number of ids (its batch)
@@ -115,6 +136,10 @@ class FlatGradReducer(object):
             merge_sparse_rows(self.table_view(i), ids, ids_all, rows_all)
         if self.average:
             self.flat.mul_(1.0 / self.world)
+
+    def reduce(self, sparse_ids=()):
+        self.start()
+        self.finish(sparse_ids)
 
 
 def broadcast_parameters(flat_params, src=0, group=None):

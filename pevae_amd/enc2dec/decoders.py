@@ -300,7 +300,12 @@ class DecoderRNN(BaseRNN):
                     if gen_type == 'greedy':
                         symbols = scores.topk(1)[1]
                     elif gen_type == 'sample':
-                        symbols = self.multinomial_sampling(torch.exp(scores))
+                        # base_modules.py:54-59 torch.multinomial(probs, 1) IS argmax(probs / q), q ~ Exp(1) per entry (the
+                        # sampler torch uses for one draw per row); `sample_noise` ([L, B, V], set by parity tests)
+                        # supplies q so that the draw can be compared with the reference's
+                        noise = getattr(self, "sample_noise", None)
+                        q = noise[di] if noise is not None else torch.empty_like(scores).exponential_()
+                        symbols = (torch.exp(scores) / q).argmax(-1, keepdim=True)
                     elif gen_type == 'beam':
                         if di == 0:
                             seq_score = scores.view(batch_size, -1)[:, 0:self.output_size]

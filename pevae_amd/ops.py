@@ -351,6 +351,9 @@ def _vocab_operands(hid, weight):
 
 
 SKIP_IGNORED_TOKENS = os.environ.get("PEVAE_VOCAB_DENSE", "0") != "1"     # see VocabNLL
+# H = 512 with gradients wanted: the two flash-attention-shaped kernels of csrc/vocab_fused.hip (no [T, V] matrix in HBM in
+# either pass) instead of the four tile GEMMs with the P / P^T round trip.  PEVAE_VOCAB_FUSED=0 keeps the tile-GEMM path.
+FUSED_VOCAB = os.environ.get("PEVAE_VOCAB_FUSED", "1") != "0"
 
 
 class VocabNLL(torch.autograd.Function):
@@ -393,6 +396,9 @@ class VocabNLL(torch.autograd.Function):
         ctx.layout = layout
         target = target.contiguous()
         perm = count = None
+        ctx.fused = False
+        if FUSED_VOCAB and any(ctx.needs_input_grad[:3]) and _lib.load().pv_vocab_fused_supported(Hp):
+            return VocabNLL._forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf)
         if SKIP_IGNORED_TOKENS and ignore_index >= 0:
             perm = torch.empty(T, dtype=torch.int64, device=dev)
             count = torch.empty(1, dtype=torch.int32, device=dev)
@@ -426,9 +432,73 @@ class VocabNLL(torch.autograd.Function):
         return nll, lse
 
     @staticmethod
+    def _forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf):
+        dev = weight.device
+        perm = count = t_c = None
+        t32 = torch.empty(T, dtype=torch.int32, device=dev)
+        if SKIP_IGNORED_TOKENS and ignore_index >= 0:
+            perm = torch.empty(T, dtype=torch.int64, device=dev)
+            count = torch.empty(1, dtype=torch.int32, device=dev)
+            _lib.call("pv_vocab_compact", _p(target), T, ignore_index, _p(perm), _p(count), _stream())
+            h_c = torch.empty((T, Hp), dtype=BF16, device=dev)
+            t_c = torch.empty(T, dtype=torch.int64, device=dev)
+            _lib.call("pv_vocab_gather32", _p(h_bf), ldh, _p(target), _p(perm), T, Hp, _p(h_c), Hp, _p(t_c), _p(t32), _stream())
+            h_bf, ldh, target = h_c, Hp, t_c
+        else:
+            _lib.call("pv_vocab_gather32", None, 0, _p(target), None, T, Hp, None, 0, None, _p(t32), _stream())
+        ws = workspace("vocab_fused_fwd", _lib.load().pv_vocab_fused_fwd_ws_bytes(T, V), torch.uint8, dev)
+        lse = torch.empty(T, dtype=torch.float32, device=dev)
+        nll = torch.empty(T, dtype=torch.float32, device=dev)
+        U = torch.empty((T, Hp), dtype=torch.float32, device=dev)
+        bias_c = bias.contiguous()
+        with timed("vocab_fused_fwd"):
+            _lib.call("pv_vocab_fused_fwd", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(t32), T, V, Hp, inv_temp, ignore_index,
+                      _p(ws), _p(lse), _p(nll), _p(U), _p(count), _stream())
+        lse_c = lse
+        if perm is not None:
+            nll_c = nll
+            nll = torch.empty(T, dtype=torch.float32, device=dev)
+            lse = torch.empty(T, dtype=torch.float32, device=dev)
+            _lib.call("pv_scatter_rows_f32", _p(nll_c), 1, _p(perm), _p(count), T, 1, _p(nll), 1, _stream())
+            _lib.call("pv_scatter_rows_f32", _p(lse_c), 1, _p(perm), _p(count), T, 1, _p(lse), 1, _stream())
+        ctx.fused = True
+        ctx.fused_saved = (h_bf, w_bf, bias_c, target, t32, lse_c, perm, count, U)     # plain references: none needs grad
+        ctx.dims = (T, H, V, Hp, ldh, inv_temp, ignore_index)
+        ctx.params = (weight, bias)
+        ctx.mark_non_differentiable(lse)
+        ctx.set_materialize_grads(False)
+        return nll, lse
+
+    @staticmethod
+    def _backward_fused(ctx, dnll):
+        h_bf, w_bf, bias, target, t32, lse, perm, count, U = ctx.fused_saved
+        ctx.fused_saved = None
+        T, H, V, Hp, ldh, inv_temp, ignore_index = ctx.dims
+        dev = w_bf.device
+        gscale = torch.empty(T, dtype=torch.float32, device=dev)      # `target` is already in compact order
+        _lib.call("pv_vocab_gscale", _p(dnll.to(torch.float32).contiguous()), _p(perm), _p(target), ignore_index, T, _p(gscale),
+                  _stream())
+        dH = torch.empty((T, H), dtype=torch.float32, device=dev)
+        _lib.call("pv_scatter_rows_scaled_f32", _p(U), _p(gscale), inv_temp, _p(perm), _p(count), T, H, _p(dH), H, _stream())
+        weight, _bias = ctx.params
+        sink = grad_sink(weight, (V, H))
+        dW = sink if sink is not None else torch.empty((V, H), dtype=torch.float32, device=dev)
+        dbias = torch.empty(V, dtype=torch.float32, device=dev)
+        ws = workspace("vocab_fused_dw", _lib.load().pv_vocab_fused_dw_ws_bytes(V), torch.uint8, dev)
+        with timed("vocab_fused_dw"):
+            _lib.call("pv_vocab_fused_dw", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(t32), _p(lse), _p(gscale), T, V, Hp,
+                      inv_temp, _p(ws), _p(dW), H, 1 if sink is not None else 0, _p(dbias), _p(count), _stream())
+        return dH, (None if sink is not None else dW), dbias
+
+    @staticmethod
     def backward(ctx, dnll, _dlse):
         if dnll is None:
             return (None,) * 9
+        if ctx.fused:
+            dH, dW, dbias = VocabNLL._backward_fused(ctx, dnll)
+            T, H, V, Hp, ldh, inv_temp, ignore_index = ctx.dims
+            dev = dH.device
+            return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None)
         if ctx.compact:
             h_bf, w_bf, bias, target, lse, perm, count = ctx.saved_tensors
         else:
@@ -453,6 +523,10 @@ class VocabNLL(torch.autograd.Function):
             dH_c = dH
             dH = torch.empty((T, H), dtype=torch.float32, device=dev)
             _lib.call("pv_scatter_rows_f32", _p(dH_c), H, _p(perm), _p(count), T, H, _p(dH), H, _stream())
+        return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None)
+
+    @staticmethod
+    def _finish_dh(ctx, dH, H, dev):
         if ctx.drop is not None:                       # dL/d(undropped states) = dH * keep / (1 - p), in place
             p_, site_, mask_, (n0, n1, n1p, m0, m1) = ctx.drop
             _lib.call("pv_dropout_f32", _p(dH), n0, n1, H, n1p * H, H, 1, m0, m1, p_, _p(mask_), _p(rng_state(dev)), site_,
@@ -462,7 +536,7 @@ class VocabNLL(torch.autograd.Function):
         if ctx.layout is not None:
             L, B, Bpad = ctx.layout
             dH = dH.view(L, Bpad, H)[:, :B].transpose(0, 1)
-        return dH, dW, dbias, None, None, None, None, None, None
+        return (dH,)
 
 
 def _vocab_stage2(P, PT, h_bf, ldh, w_bf, T, H, V, Hp, Tp, Vp, dw_sink=None, live=None):
@@ -1179,7 +1253,7 @@ class SNLinearFn(torch.autograd.Function):
     .grad."""
 
     @staticmethod
-    def forward(ctx, x, x_act, weight, bias, u, v, do_iter, eps, emit_gelu, inv_sigma_pre):
+    def forward(ctx, x, x_act, weight, bias, u, v, do_iter, eps, emit_gelu, inv_sigma_pre, clone_uv=False):
         _need_cuda(x, x_act, weight, bias, u, v)
         N, K = weight.shape
         x2 = x.reshape(-1, K).contiguous()
@@ -1192,6 +1266,8 @@ class SNLinearFn(torch.autograd.Function):
             u, v = u.clone(), v.clone()          # a later forward may advance the buffers before this backward runs
         else:
             inv_sigma = inv_sigma_pre            # u / v advance once per step, before any forward of that step
+            if clone_uv:                         # ... unless this module runs again in the same step (its second forward
+                u, v = u.clone(), v.clone()      # advances the buffers in place before this call's backward has run)
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         gy = torch.empty((M, N), dtype=torch.float32, device=x.device) if emit_gelu else None
         bc = None if bias is None else bias.contiguous()
@@ -1213,7 +1289,7 @@ class SNLinearFn(torch.autograd.Function):
     def backward(ctx, dy, _dgy):
         x2, a2, w, y, bc, inv_sigma, u, v = ctx.saved_tensors
         if dy is None:
-            return (None,) * 10
+            return (None,) * 11
         M, K = x2.shape
         N = w.shape[0]
         dev = x2.device
@@ -1241,12 +1317,12 @@ class SNLinearFn(torch.autograd.Function):
             _lin_fused(dy2, 1, N, a2, K, 1, None, dw, K, N, K, M, alpha_dev=inv_sigma, accumulate=1 if sink is not None else 0,
                        r1_c=cpart, r1_u=u, r1_v=v)
             dw = None if sink is not None else dw
-        return dx, None, dw, db, None, None, None, None, None, None
+        return dx, None, dw, db, None, None, None, None, None, None, None
 
 
-def sn_linear(x, weight_orig, bias, u, v, training, eps=1e-12, x_act=None, emit_gelu=False, inv_sigma=None):
+def sn_linear(x, weight_orig, bias, u, v, training, eps=1e-12, x_act=None, emit_gelu=False, inv_sigma=None, clone_uv=False):
     """-> (y, gelu(y) or None)."""
-    return SNLinearFn.apply(x, x_act, weight_orig, bias, u, v, bool(training), eps, bool(emit_gelu), inv_sigma)
+    return SNLinearFn.apply(x, x_act, weight_orig, bias, u, v, bool(training), eps, bool(emit_gelu), inv_sigma, bool(clone_uv))
 
 
 def spectral_prepass(modules, training, eps=1e-12, cache=None):
@@ -1261,14 +1337,16 @@ def spectral_prepass(modules, training, eps=1e-12, cache=None):
         inv = torch.empty(len(modules), dtype=torch.float32, device=dev)
         rec = np.zeros((len(modules), 7), dtype=np.int64)
         sizes = [m.weight_orig.numel() for m in modules]
-        wt = torch.empty(int(np.sum(sizes)), dtype=torch.float32, device=dev)      # W^T of every weight (pv_block_fwd operands)
+        # W^T of every weight (pv_block_fwd operands), each at a 16-byte aligned offset: tiny weights of the deepest
+        # pyramid Blocks (2 x 1, 4 x 2 floats) would otherwise misalign everything behind them
+        wt = torch.empty(int(np.sum([(n + 3) // 4 * 4 for n in sizes])), dtype=torch.float32, device=dev)
         wts, off = [], 0
         for i, m in enumerate(modules):
             assert m.weight_orig.is_contiguous()
             n_out, n_in = m.weight_orig.shape
             wts.append(wt[off:off + sizes[i]].view(n_in, n_out))
             rec[i] = (ptrs[i][0], ptrs[i][1], ptrs[i][2], inv.data_ptr() + 4 * i, n_out, n_in, wts[i].data_ptr())
-            off += sizes[i]
+            off += (sizes[i] + 3) // 4 * 4
         max_out, max_in = int(rec[:, 4].max()), int(rec[:, 5].max())
         ws = None
         if max(max_out, max_in) <= 1024:
@@ -1401,8 +1479,18 @@ def _block_args(blk):
     """BlockGroupFn's per-Block arguments after x (consumes the pre-pass results of the five linears)."""
     lins = (blk.c1, blk.c2, blk.c3, blk.c4, blk.translate)
     if any(m._inv_sigma_pre is None or getattr(m, "_wt_pre", None) is None for m in lins):
-        spectral_prepass(list(lins), blk.training, lins[0].eps)
+        # a Block called twice in one step (DeNAuto's discriminator: positive and negative pairs) runs its own power
+        # iteration for the second call, as torch's spectral_norm hook does; the descriptor tables are cached on the Block,
+        # so that nothing is uploaded once the step is being captured into a HIP graph
+        # (a ring of four: the 1/sigma and W^T buffers of an earlier call of this step are saved for ITS backward pass
+        # and must not be overwritten by the next call)
+        ring = blk.__dict__.setdefault("_sn_ring", [{}, {}, {}, {}])
+        blk.__dict__["_sn_turn"] = turn = (blk.__dict__.get("_sn_turn", -1) + 1) % len(ring)
+        spectral_prepass(list(lins), blk.training, lins[0].eps, cache=ring[turn])
         us = [m.weight_u.clone() for m in lins]       # a later forward may advance the buffers before this backward runs
+        vs = [m.weight_v.clone() for m in lins]
+    elif getattr(lins[0], "clone_uv", False):
+        us = [m.weight_u.clone() for m in lins]
         vs = [m.weight_v.clone() for m in lins]
     else:
         us = [m.weight_u for m in lins]

@@ -74,6 +74,13 @@ class FlatAdam(object):
                 return (o, p.shape[0], p.shape[1])
         raise KeyError("FlatAdam.table_range: not one of this optimizer's parameters")
 
+    def param_range(self, param):
+        """(start, end) of a parameter inside the flat buffers (dp.FlatGradReducer early_ranges)."""
+        for p, o in zip(self.params, self.offsets):
+            if p is param:
+                return (o, o + p.numel())
+        raise KeyError("FlatAdam.param_range: not one of this optimizer's parameters")
+
     def zero_grad(self):
         self.flat_g.zero_()
         for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-attach the view

@@ -90,3 +90,42 @@ def test_loss_manager_report_format():
     assert lm.pprint("Train", window=1).startswith("Train vae_nll 4.000")
     lm.clear()
     assert lm.return_dict() == {}
+
+
+def _golden_data_path():
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "yelp_data_path.json")) as fh:
+        return json.load(fh)
+
+
+def test_data_path_matches_reference_code_golden():
+    """tests/golden/yelp_data_path.json was produced by the reference's OWN yelp._process_reivews / _build_vocab
+    (corpora.py:609-651) and YELPDataLoader.batcher (data_loaders.py:636-715) on synthetic reviews
+    (oracle/make_golden.py gen_yelp_data_path).  Both the product path and the oracle restatement must reproduce the
+    processed rows, the vocabulary and every collated batch exactly."""
+    from pevae_amd.dataset import process_reviews
+    g = _golden_data_path()
+    rows = {}
+    for name, raw in g["raw"].items():
+        want = g["rows"][name]
+        got = process_reviews([tuple(r) for r in raw], rd=[w[5] for w in want])
+        assert [list(r) for r in got] == want, name
+        rows[name] = got
+    order = ("train", "valid", "test", "pretrain")
+    vocab, rev, _ = build_vocab(tuple(rows[k] for k in order), g["max_vocab_cnt"])
+    assert vocab == g["vocab"] and rev["<unk>"] == g["unk_id"]
+    rv, rr = R.build_vocab(*(rows[k] for k in order), g["max_vocab_cnt"])
+    assert rv == g["vocab"] and rr == rev
+    assert any(w not in rev for r in rows["train"] for w in r[3]), "the fixture must contain out-of-vocabulary words"
+    for b in g["batches"]:
+        sel = [rows["train"][i] for i in b["rows"]]
+        got = YELPDataLoader.batcher(rev, b["max_seq_len"], "cpu")(sel)
+        ora = R.batch(sel, rev, b["max_seq_len"])
+        assert set(got) == set(b["out"]) == set(ora)
+        for k, want in b["out"].items():
+            want_t = torch.tensor(want, dtype=got[k].dtype)
+            assert torch.equal(got[k], want_t), (k, b["max_seq_len"])
+            assert torch.equal(ora[k], want_t) and ora[k].dtype == got[k].dtype, (k, b["max_seq_len"])
+    assert any(len(rows["train"][i][3]) > b["max_seq_len"] for b in g["batches"] for i in b["rows"])   # truncation exercised

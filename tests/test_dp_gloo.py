@@ -83,3 +83,46 @@ def test_sparse_table_exchange_matches_dense_average(tmp_path):
     for flat, _ in outs:
         torch.testing.assert_close(flat, want, rtol=1e-6, atol=1e-6)
     assert torch.equal(outs[0][0], outs[1][0])             # bit-identical replicas
+
+
+def _split_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from pevae_amd import dp
+    dp.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(300 + rank)
+    # layout: dense 100 | table 30 x 4 | dense 5000 with the early range [700, 3100) inside it | dense tail
+    off, n = 100, 100 + 120 + 5000
+    early = (700, 3100)
+    grad = torch.randn(n, generator=g)
+    ids = torch.randint(0, 30, (9,), generator=g)
+    t = grad[off:off + 120].view(30, 4)
+    mask = torch.zeros(30, dtype=torch.bool)
+    mask[ids] = True
+    t[~mask] = 0.0
+    flat = torch.zeros(n)
+    red = dp.FlatGradReducer(flat, world, bucket_bytes=1 << 10, sparse_tables=[(off, 30, 4)], average=False,
+                             early_ranges=[early])
+    assert sum(e - s for s, e in red.early_bounds) == early[1] - early[0]
+    # the split schedule of bench.py: the early stretch is final first and starts travelling; the rest of the "backward"
+    # fills the other stretches while it is in flight; finish() exchanges those and waits for everything
+    flat[early[0]:early[1]] = grad[early[0]:early[1]]
+    red.start()
+    keep = flat[early[0]:early[1]].clone()
+    flat[:early[0]] = grad[:early[0]]
+    flat[early[1]:] = grad[early[1]:]
+    red.finish([ids])
+    torch.save((flat, grad), os.path.join(out, "p%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_split_schedule_sum_matches_dense_and_replicas_identical(tmp_path):
+    """start() / finish() with an early range (the overlap schedule) and average=False (1/world folded into the optimizer):
+    every rank ends with the SUM over ranks, bit-identical across replicas."""
+    port = _free_port()
+    mp.spawn(_split_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "p%d.pt" % r), weights_only=True) for r in range(2)]
+    want = outs[0][1] + outs[1][1]
+    for flat, _ in outs:
+        torch.testing.assert_close(flat, want, rtol=1e-6, atol=1e-6)
+    assert torch.equal(outs[0][0], outs[1][0])

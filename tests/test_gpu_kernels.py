@@ -96,6 +96,83 @@ def test_vocab_nll_fused(dev, T, V, H, temp):
     assert float((nll.detach().cpu() - nll32).abs().max()) < 0.05
 
 
+@pytest.mark.parametrize("T,V,temp,case", [(300, 2003, 1.0, "plain"), (1000, 5000, 0.7, "plain"), (130, 1999, 1.0, "spike"),
+                                           (257, 700, 1.0, "dense"), (64, 640, 1.0, "one_live"), (96, 333, 1.0, "all_ignored")])
+def test_vocab_fused_kernels(dev, T, V, temp, case):
+    """csrc/vocab_fused.hip (H = 512: S^T = W h^T -> online softmax -> O^T += W^T P^T, and S -> P -> Z += P^T h, nothing of
+    size [T, V] in HBM) through ops.VocabNLL against the oracle on the same bf16-rounded operands: nll, lse, dH, dW, dbias.
+    Cases: ragged vocabularies / row counts (partial 32-column and 32-row items, several stream-K segments per unit), a
+    logit spike late in the vocabulary that forces the rescale branch of the online softmax (rows whose maximum grows by
+    > 20 after the first tile), no compaction (every row through the kernels), a single live row, no live row at all;
+    and a second run must reproduce every bit."""
+    from pevae_amd import _lib, ops
+    H = 512
+    assert _lib.load().pv_vocab_fused_supported(H) == 1 and ops.FUSED_VOCAB
+    g = torch.Generator().manual_seed(T + V)
+    hid = torch.randn(T, H, generator=g) * 0.5
+    W = torch.randn(V, H, generator=g) * 0.05
+    b = torch.randn(V, generator=g) * 0.1
+    tgt = torch.randint(1, V, (T,), generator=g)
+    tgt[::3] = 0
+    if case == "spike":                       # columns past the first tiles dominate some rows by ~ 60 nats
+        W[V - 40] = hid[5] * 0.5
+        W[V - 300] = hid[77] * 0.4
+        b[V - 7] = 45.0
+        tgt[5], tgt[77] = V - 40, 11
+    if case == "one_live":
+        tgt[:] = 0
+        tgt[37] = 5
+    if case == "all_ignored":
+        tgt[:] = 0
+    wtok = torch.rand(T, generator=g) + 0.5
+    hr, Wr = bf(hid).requires_grad_(), bf(W).requires_grad_()
+    br = b.clone().requires_grad_()
+    logits = (hr.double() @ Wr.double().t() + br.double()) / temp
+    logp = torch.log_softmax(logits, 1)
+    nll_ref = -(logp.gather(1, tgt.unsqueeze(1)).squeeze(1)) * (tgt != 0)
+    (nll_ref * wtok.double()).sum().backward()
+    lse_ref = torch.logsumexp(logits, 1).float().detach()
+    skip = ops.SKIP_IGNORED_TOKENS
+    ops.SKIP_IGNORED_TOKENS = case != "dense"
+    try:
+        outs = []
+        for _ in range(2):
+            hd, Wd, bd = hid.to(dev).requires_grad_(), W.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+            nll, lse = ops.VocabNLL.apply(hd, Wd, bd, tgt.to(dev), 1.0 / temp, 0, None, None)
+            (nll * wtok.to(dev)).sum().backward()
+            torch.cuda.synchronize()
+            outs.append((nll.detach().clone(), lse.clone(), hd.grad.clone(), Wd.grad.clone(), bd.grad.clone()))
+    finally:
+        ops.SKIP_IGNORED_TOKENS = skip
+    nll, lse, dh, dw, db = outs[0]
+    np.testing.assert_allclose(nll.cpu().numpy(), nll_ref.detach().float().numpy(), rtol=3e-4, atol=3e-4)
+    live = (tgt != 0) if case != "dense" else torch.ones_like(tgt, dtype=torch.bool)
+    if bool(live.any()):
+        np.testing.assert_allclose(lse.cpu()[live].numpy(), lse_ref[live].numpy(), rtol=3e-4, atol=3e-4)
+    assert float(lse.cpu()[~live].abs().max() if bool((~live).any()) else 0.0) == 0.0
+    if case == "all_ignored":
+        assert not dh.any() and not dw.any() and not db.any() and not nll.any()
+    else:
+        # probabilities are rounded to bf16 between the two products: 1e-2 of the largest entry
+        assert relerr(dh, hr.grad.float()) < 1.5e-2
+        assert relerr(dw, Wr.grad.float()) < 1.5e-2
+        assert relerr(db, br.grad.float()) < 1.5e-2
+        assert not dh.cpu()[tgt == 0].any()               # ignored rows: exactly zero gradient
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)                          # fixed-order folds, no atomics: bitwise reproducible
+    # the tile-GEMM path (P / P^T through HBM) on the same inputs agrees to the same tolerance
+    ops.FUSED_VOCAB = False
+    try:
+        hd, Wd, bd = hid.to(dev).requires_grad_(), W.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+        nll2, _ = ops.VocabNLL.apply(hd, Wd, bd, tgt.to(dev), 1.0 / temp, 0, None, None)
+        (nll2 * wtok.to(dev)).sum().backward()
+    finally:
+        ops.FUSED_VOCAB = True
+    np.testing.assert_allclose(nll.detach().cpu().numpy(), nll2.detach().cpu().numpy(), rtol=3e-4, atol=3e-4)
+    if case != "all_ignored":
+        assert relerr(dw, Wd.grad) < 2e-2 and relerr(dh, hd.grad) < 2e-2
+
+
 def gru_ref(x, h0, w_ih, w_hh, b_ih, b_hh, emulate_bf16):
     """oracle GRU (R.gru_cell arithmetic) with optional bf16 rounding of the MFMA operands (straight-through)."""
     def q(t):

@@ -347,6 +347,66 @@ def test_decoder_gen_graphed_greedy(dev):
     assert len(dec._decode_graphs) == 1
 
 
+def test_decoder_gen_sample_golden(dev):
+    """`sample` decoding (decoders.py:255-256 -> base_modules.py:54-59) against the reference's own run: the Exp(1) draws
+    behind torch.multinomial are part of the golden, so the drawn symbols can be compared token by token.  A symbol may
+    differ only where the reference's two best ratios p / q are within the bf16 noise of the log-probabilities."""
+    from pevae_amd.enc2dec import decoders as D
+    g = load_golden("decoder_gen_sample")
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb), g).to(dev)
+    dec.eval()
+    dec.sample_noise = T(g["q"], dev)
+    with torch.no_grad():
+        logp, hid, ret = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="sample")
+    seq, want = torch.cat(ret["sequence"], dim=1).cpu(), T(g["seq"])
+    score = T(g["logp"]) - torch.log(T(g["q"])).transpose(0, 1)            # log(p / q) of the reference, [B, L, V]
+    exact = 0
+    for b in range(B):
+        for t in range(L):
+            if seq[b, t] != want[b, t]:
+                top2 = score[b, t].topk(2)[0]
+                assert float(top2[0] - top2[1]) < 3e-2, (b, t)
+                break
+        else:
+            exact += 1
+            assert ret["length"][b] == int(g["length"][b])
+    assert exact >= B - 1
+    close(logp[:, 0], g["logp"][:, 0], rtol=0, atol=3e-2)
+    dec.sample_noise = None                                                 # generator mode: valid symbols, varying draws
+    with torch.no_grad():
+        a = torch.cat(dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="sample")[2]["sequence"], 1)
+        b2 = torch.cat(dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="sample")[2]["sequence"], 1)
+    assert int(a.min()) >= 0 and int(a.max()) < V and not torch.equal(a, b2)
+
+
+def test_decoder_gen_beam_golden(dev):
+    """`beam` decoding (decoders.py:257-270, :307-328) against the golden built from the reference's forward_step under its
+    beam rule (floor-division back pointers; see oracle/make_golden.py gen_decoder_sample_beam): raw beam symbols, the
+    back-tracked 1-best sequence and the lengths over all B * beam rows."""
+    from pevae_amd.enc2dec import decoders as D
+    g = load_golden("decoder_gen_beam")
+    V, L, E, H, B, beam = 37, 7, 12, 16, 4, int(g["beam"])
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb), g).to(dev)
+    dec.eval()
+    with torch.no_grad():
+        logp, hid, ret = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="beam", beam_size=beam)
+    assert logp.shape == g["logp"].shape and len(ret["length"]) == B * beam
+    close(logp[:, 0], g["logp"][:, 0], rtol=0, atol=3e-2)
+    seq, want = torch.cat(ret["sequence"], dim=1).cpu(), T(g["seq"])
+    # beams reorder on near-ties of cumulative scores; where the whole decode agrees with the reference's log-probs to
+    # bf16 noise the 1-best sequence must be the reference's
+    if float((logp.cpu() - T(g["logp"])).abs().max()) < 3e-2:
+        ref_lp = T(g["logp"])
+        margin = min(float(ref_lp[r, t].topk(beam + 1)[0][beam - 1] - ref_lp[r, t].topk(beam + 1)[0][beam])
+                     for r in range(B * beam) for t in range(L))
+        if margin > 0.1:
+            assert torch.equal(seq, want) and ret["length"] == g["length"].tolist()
+    assert seq.shape == want.shape and float((seq == want).float().mean()) >= 0.6
+
+
 def test_vocab_argmax_large(dev):
     """pv_vocab_argmax at the step's vocabulary (V = 20004, ragged last slab) against torch on the same bf16 operands."""
     from pevae_amd import ops

@@ -41,7 +41,10 @@ def share_dropout_masks(gpu, ref, cfg, B, dev, seed=17):
 
 @pytest.mark.parametrize("kw", [dict(), dict(use_attention=True), dict(do_pred=True), dict(latent_stack="dls"),
                                 dict(dropout=0.3), dict(dropout=0.3, use_attention=True),
-                                dict(dropout=0.3, latent_stack="dls")])
+                                dict(dropout=0.3, latent_stack="dls"),
+                                dict(latent_stack="dls", use_mutual=True, do_pred=True),        # configs[4] wiring
+                                dict(use_feature=True, n_feature=13),
+                                dict(latent_stack="dls", use_mutual=True, use_feature=True, n_feature=5, dropout=0.3)])
 def test_step_matches_oracle(dev, kw):
     from pevae_amd import ops
     from pevae_amd.dls_vae import default_config, synthetic_batch
@@ -56,16 +59,24 @@ def test_step_matches_oracle(dev, kw):
     feed = synthetic_batch(cfg, 24, 99)
     feed_d = {k: v.to(dev) for k, v in feed.items()}
     gen = torch.Generator().manual_seed(3)
-    if kw.get("latent_stack") == "dls":        # uniform draws of the three DLS_Auto levels (H/16, H/8, H/4 wide)
+    if kw.get("use_mutual"):                   # DeNAuto: uniform draws of its two levels + Gumbel noise of the hard negatives
+        eps = ([torch.rand(24, d, generator=gen) for d in (4, 8)],
+               [-torch.empty(24, 24).exponential_(generator=gen).log() for _ in range(2)])
+    elif kw.get("latent_stack") == "dls":      # uniform draws of the three DLS_Auto levels (H/16, H/8, H/4 wide)
         eps = [torch.rand(24, d, generator=gen) for d in (4, 8, 16)]
     else:
         eps = torch.randn(24, 16, generator=gen)
-    to_dev = lambda e: [t.to(dev) for t in e] if isinstance(e, list) else e.to(dev)
+
+    def to_dev(e):
+        if isinstance(e, (list, tuple)):
+            return type(e)(to_dev(t) for t in e)
+        return e.to(dev)
 
     opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3)
     loss_r = ref(feed, eps=eps)
     ref.valid_loss(loss_r).backward()
-    ref_grads = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    # (parameters the loss does not reach -- the last DeNAuto `layers` Block feeds nothing -- have no gradient: zeros)
+    ref_grads = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in ref.named_parameters()}
     norm_r = torch.nn.utils.clip_grad_norm_(ref.parameters(), 5.0, 2)
     opt_r.step()
 
@@ -246,3 +257,125 @@ def test_step_full_size_attention_oracle(dev):
     assert float(loss.vae_nll.detach()) == float(loss2.vae_nll.detach())
     for n in grads:
         assert torch.equal(grads[n], grads2[n]), n
+
+
+@pytest.mark.parametrize("stack", ["gauss", "dls"])
+def test_step_golden_from_reference_modules(dev, stack):
+    """pevae_amd.dls_vae.DLSVAE against the step composed from the reference's own EncoderRNN / DecoderRNN /
+    Hidden2Gaussian / LinearConnector / NLLEntropy / NormKLLoss (and DlsRec / DlsPri / DLS_Auto / Block) classes
+    (tests/golden/composed_step_*.npz, oracle/make_golden.py gen_composed_step): losses and every parameter gradient.
+    Tolerances: bf16 MFMA operands in the recurrences and the vocabulary GEMMs, fp32 accumulate."""
+    from conftest import load_golden, load_params
+    from pevae_amd import ops
+    from pevae_amd.dls_vae import DLSVAE
+    from test_oracle_golden import composed_step_inputs
+    g = load_golden("composed_step_" + stack)
+    cfg, feed, eps = composed_step_inputs(g, lambda a: torch.from_numpy(np.array(a)).to(dev))
+    m = load_params(DLSVAE(cfg), g).to(dev)
+    m.train()
+    loss = m(feed, eps=eps)
+    m.valid_loss(loss).backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    for got, key in ((loss.vae_nll, "vae_nll"), (loss.vae_PPL, "vae_ppl"), (loss.vae_rkl, "vae_rkl")):
+        assert abs(float(got.detach()) - float(g[key])) <= 2e-2 * abs(float(g[key])) + 1e-4, key
+    n = 0
+    for k, p in m.named_parameters():
+        if "g." + k in g:
+            r = torch.from_numpy(g["g." + k])
+            d = float((p.grad.cpu() - r).abs().max())
+            assert d <= 6e-2 * float(r.abs().max()) + 1e-7, (k, d, float(r.abs().max()))
+            n += 1
+    assert n == len([k for k in g if k.startswith("g.")])
+
+
+def _full_size_vs_oracle(gpu, ref, feed, feed_d, eps, eps_d, skip_cos=()):
+    from pevae_amd import ops
+    gpu.zero_grad(set_to_none=True)
+    loss = gpu(feed_d, eps=eps_d)
+    gpu.valid_loss(loss).backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    loss_r = ref(feed, eps=eps)
+    ref.valid_loss(loss_r).backward()
+    for key in ("vae_nll", "vae_rkl", "rating_mse"):
+        if loss_r.get(key) is not None:
+            a, b = float(loss[key].detach()), float(loss_r[key].detach())
+            assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, (key, a, b)
+    grads = {n: p.grad for n, p in gpu.named_parameters()}
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            assert grads[n] is None or not grads[n].any(), n
+            continue
+        g, r = grads[n].cpu(), p.grad
+        scale = float(r.abs().max()) + 1e-9
+        assert float((g - r).abs().max()) <= 8e-2 * scale + 1e-8, (n, float((g - r).abs().max()), scale)
+        if r.numel() >= 4096 and not any(s in n for s in skip_cos):
+            cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-20))
+            assert cos > 0.99, (n, cos)
+    return loss, grads
+
+
+def test_step_full_size_mutual_oracle(dev):
+    """BASELINE.json configs[4], the per-GPU shard (bs=256 of the global 2048): --use_mutual (DEM discriminator stack,
+    DeNAuto) + --do_pred rating head at full size against the oracle, with the uniform draws and the Gumbel noise of the
+    hard negatives supplied to both."""
+    from pevae_amd.dls_vae import default_config, synthetic_batch
+    cfg = default_config(dropout=0.0, batch_size=256, latent_stack="dls", use_mutual=True, do_pred=True)
+    gpu, ref = _pair(cfg, dev)
+    gpu.train()
+    ref.train()
+    feed = synthetic_batch(cfg, 256, 2048)
+    feed_d = {k: v.to(dev) for k, v in feed.items()}
+    H = cfg.dec_cell_size
+    gen = torch.Generator().manual_seed(13)
+    eps = ([torch.rand(256, d, generator=gen) for d in (H // 16, H // 8)],
+           [-torch.empty(256, 256).exponential_(generator=gen).log() for _ in range(2)])
+    eps_d = tuple([t.to(dev) for t in e] for e in eps)
+    loss, _ = _full_size_vs_oracle(gpu, ref, feed, feed_d, eps, eps_d)
+    assert loss.get("rating_mse") is not None and float(loss.vae_rkl) > 0
+
+
+def test_step_full_size_book_tables_and_sparse_exchange(dev):
+    """BASELINE.json configs[3], Amazon-Book-shape tables (200 000 users x 256, 100 000 items x 256 = 77 M of the 107 M
+    parameters): the step against the oracle, exact zeros in every row nobody looked up, and the data-parallel exchange
+    of those tables at this size -- two ranks' (ids, rows) contributions (dp.pack_sparse_rows) merged on the device
+    (dp.merge_sparse_rows, the library's sorted segmented sum) equal the dense sum of the two table gradients bit for bit
+    on both ranks."""
+    from pevae_amd import dp
+    from pevae_amd.dls_vae import default_config, synthetic_batch
+    cfg = default_config(dropout=0.0, batch_size=256, latent_stack="gauss", n_user=200000, n_item=100000)
+    gpu, ref = _pair(cfg, dev)
+    gpu.train()
+    ref.train()
+    feeds = [synthetic_batch(cfg, 256, 3000 + r) for r in range(2)]
+    eps = torch.randn(256, cfg.latent_size, generator=torch.Generator().manual_seed(5))
+    table_grads = []
+    for r, feed in enumerate(feeds):
+        feed_d = {k: v.to(dev) for k, v in feed.items()}
+        if r == 0:
+            _, grads = _full_size_vs_oracle(gpu, ref, feed, feed_d, eps, eps.to(dev))
+        else:
+            gpu.zero_grad(set_to_none=True)
+            gpu.valid_loss(gpu(feed_d, eps=eps.to(dev))).backward()
+            grads = {n: p.grad for n, p in gpu.named_parameters()}
+        per = {}
+        for tab, key in (("user_embedding.weight", "user_ids"), ("item_embedding.weight", "item_ids")):
+            gt = grads[tab]
+            hit = torch.zeros(gt.shape[0], dtype=torch.bool, device=dev)
+            hit[feed_d[key]] = True
+            assert not gt[~hit].any() and bool(gt[hit].abs().sum(1).gt(0).all()), tab
+            per[tab] = (gt.clone(), feed_d[key])
+        table_grads.append(per)
+    for tab in ("user_embedding.weight", "item_embedding.weight"):
+        packed = [dp.pack_sparse_rows(*table_grads[r][tab]) for r in range(2)]
+        ids_all = torch.cat([p[0] for p in packed])
+        rows_all = torch.cat([p[1] for p in packed])
+        want = table_grads[0][tab][0] + table_grads[1][tab][0]
+        merged = []
+        for r in range(2):
+            mine = table_grads[r][tab][0].clone()
+            dp.merge_sparse_rows(mine, table_grads[r][tab][1], ids_all, rows_all)
+            torch.testing.assert_close(mine, want, rtol=1e-6, atol=1e-7)
+            merged.append(mine)
+        assert torch.equal(merged[0], merged[1])

@@ -141,6 +141,26 @@ def test_decoder_gen_greedy(tag, mask_unk):
     close(hid, g["hid"])
 
 
+@pytest.mark.parametrize("gen_type", ["sample", "beam"])
+def test_decoder_gen_sample_beam(gen_type):
+    """decoders.py:255-270, :307-328.  `sample` golden: the reference's own run, with torch.multinomial's Exp(1) draws
+    stored as input; `beam` golden: the reference's forward_step per token under its beam rule with floor division (the
+    reference's own back-tracking raises on this torch; oracle/make_golden.py gen_decoder_sample_beam)."""
+    g = load_golden("decoder_gen_" + gen_type)
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(R.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", use_gpu=False, embedding=emb), g)
+    dec.eval()
+    if gen_type == "sample":
+        dec.sample_noise = T(g["q"])
+    with torch.no_grad():
+        logp, hid, ret = dec(B, T(g["ids"]), T(g["h0"]), mode=R.GEN, gen_type=gen_type, beam_size=3)
+    assert torch.equal(torch.cat(ret["sequence"], dim=1), T(g["seq"]))
+    assert ret["length"] == g["length"].tolist()
+    close(logp, g["logp"], rtol=1e-4, atol=1e-5)
+    close(hid, g["hid"])
+
+
 @pytest.mark.parametrize("mode", ["dot", "general", "cat"])
 def test_attention(mode):
     g = load_golden("attention_" + mode)
@@ -334,3 +354,83 @@ def test_den_auto_oracle_matches_reference():
     for k, v in m.state_dict().items():
         if "post." + k in g:
             close(v, g["post." + k], rtol=1e-5, atol=1e-6)
+
+
+def _dls_cfg(B):
+    import types
+    return types.SimpleNamespace(batch_size=B, expand_weight=0.5, converge_weight=0.1, cip_weight=1.0, gir_weight=0.0, ost=False)
+
+
+def run_dls_auto_golden(module, g, T_, rtol, atol_rel):
+    """Shared by the oracle test below and tests/test_gpu_dls.py: feed a DLSAuto with the inputs / draws of a dls_auto_*
+    golden (made from the reference's own DLS_Auto class) and compare outputs and every gradient."""
+    restarted, training = bool(g["restarted"]), bool(g["training"])
+    module.train(training)
+    ins = {k: T_(g[k]).requires_grad_() for k in ("output", "rec_output")}
+    act1 = [T_(g["act1_%d" % i]).requires_grad_() for i in range(3)]
+    act2 = [T_(g["act2_%d" % i]).requires_grad_() for i in range(3)]
+    z, rkl = module(ins["output"], ins["rec_output"], act1, act2, restarted, noise=[T_(g["noise_%d" % i]) for i in range(3)])
+    (z.sum() * 0.1 + rkl).backward()
+    tol = lambda ref: dict(rtol=rtol, atol=atol_rel * float(np.abs(ref).max()) + 1e-7)
+    close(z.cpu(), g["z"], **tol(g["z"]))
+    close(rkl.cpu(), g["rkl"], rtol=rtol, atol=1e-6)
+    n = 0
+    for name, t in [("d_output", ins["output"]), ("d_rec_output", ins["rec_output"])] + \
+            [("d_act1_%d" % i, act1[i]) for i in range(3)] + [("d_act2_%d" % i, act2[i]) for i in range(3)]:
+        if name in g:
+            close(t.grad.cpu(), g[name], **tol(g[name]))
+            n += 1
+    assert n >= 5
+    for k, p in module.named_parameters():
+        if "g." + k in g:
+            close(p.grad.cpu(), g["g." + k], **tol(g["g." + k]))
+            n += 1
+    assert n > 40
+    for k, v in module.state_dict().items():
+        if "post." + k in g and training:
+            close(v.cpu(), g["post." + k], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["train", "restarted_train", "restarted_eval"])
+def test_dls_auto_oracle_matches_reference_class(tag):
+    """oracle DLSAuto vs the reference's own DLS_Auto.forward (dialog_models.py:3274-3352; golden from the class itself,
+    constructor deviations written in oracle/make_golden.py gen_dls_auto): the composition is pinned, not only its parts."""
+    g = load_golden("dls_auto_" + tag)
+    m = load_params(R.DLSAuto(4, 16, _dls_cfg(10)), g)
+    run_dls_auto_golden(m, g, T, 2e-4, 2e-5)
+
+
+def composed_step_inputs(g, T_):
+    from pevae_amd.dls_vae import default_config
+    V, E, H, L, B, Z, NU, NI = [int(x) for x in g["dims"]]
+    stack = "dls" if "eps_0" in g else "gauss"
+    cfg = default_config(vocab_size=V, embed_size=E, dec_cell_size=H, max_seq_len=L, n_user=NU, n_item=NI, latent_size=Z,
+                         dropout=0.0, batch_size=B, latent_stack=stack, bos_id=4, eos_id=5, unk_id=1)
+    feed = {"user_ids": T_(g["user_ids"]), "item_ids": T_(g["item_ids"]), "ratings": T_(g["ratings"]),
+            "sentence_embeddings": T_(g["input_ids"]), "input_ids": T_(g["input_ids"]), "ans_ids": T_(g["ans_ids"])}
+    eps = [T_(g["eps_%d" % i]) for i in range(3)] if stack == "dls" else T_(g["eps"])
+    return cfg, feed, eps
+
+
+@pytest.mark.parametrize("stack", ["gauss", "dls"])
+def test_composed_step_oracle_matches_reference_modules(stack):
+    """oracle/ref_step.py vs the same step composed from the reference's OWN classes (golden composed_step_*):
+    losses and every parameter gradient -- a wiring error shared by the oracle step and pevae_amd/dls_vae.py would show here."""
+    from oracle.ref_step import RefDLSVAE
+    g = load_golden("composed_step_" + stack)
+    cfg, feed, eps = composed_step_inputs(g, T)
+    m = load_params(RefDLSVAE(cfg), g)
+    m.train()
+    loss = m(feed, eps=eps)
+    m.valid_loss(loss).backward()
+    close(loss.vae_nll, g["vae_nll"], rtol=1e-5)
+    close(loss.vae_PPL, g["vae_ppl"], rtol=1e-5)
+    close(loss.vae_rkl, g["vae_rkl"], rtol=1e-5, atol=1e-6)
+    n = 0
+    for k, p in m.named_parameters():
+        if "g." + k in g:
+            # hand-rolled recurrence cells vs ATen's fused GRU: 1e-4 of the tensor's largest entry
+            # (+ 1e-6 absolute: cancellation residues in the deepest, 2-wide pyramid Block have |grad| ~ 2e-5)
+            close(p.grad, g["g." + k], rtol=1e-3, atol=1e-4 * float(np.abs(g["g." + k]).max()) + 1e-6)
+            n += 1
+    assert n == len([k for k in g if k.startswith("g.")]) and n > 15
