@@ -268,13 +268,21 @@ def main():
         if os.path.exists(pmc):
             with open(pmc) as fh:
                 traffic = json.load(fh).get("vocab_group_hbm_bytes_per_step")
+        fused = "vocab_fused_fwd" in kern_ms
+        fwd_tag = "vocab_fused_fwd" if fused else "vocab_fwd"
+        # the forward entry point: logits + softmax + NLL (2 T H V); fused, it also carries the dH product (4 T H V)
+        fwd_flop = (4.0 if fused else 2.0) * T_live * H * V
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
                     traffic_source="profiles/r02_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per step)",
-                    kernel="gemm_nt_kernel<EpiSoftmax|EpiProb|EpiStore> (vocab projection+softmax+NLL fwd+bwd group)",
+                    kernel=("vocab_fwd_dh_kernel + vocab_fwd_combine_kernel + vocab_dw_kernel + vocab_dw_reduce_kernel "
+                            "(fused vocabulary projection + softmax + NLL forward, dH and dW; no [T,V] matrix in HBM)") if fused
+                    else "gemm_nt_kernel<EpiSoftmax|EpiProb|EpiStore> (vocab projection+softmax+NLL fwd+bwd group)",
                     algorithmic_gflop_per_step=round(alg_flop / 1e9, 1), group_ms_per_step=round(vocab_ms, 4),
+                    executed_gflop_per_step=round((8.0 if fused else 8.0) * T_live * H * V / 1e9, 1),
                     token_rows=T, token_rows_computed=T_live,
-                    fwd_kernel_tflops=round(2.0 * T_live * H * V / (kern_ms["vocab_fwd"]["ms_per_step"] * 1e-3) / 1e12, 2))
+                    fwd_kernel_tflops=round(fwd_flop / (kern_ms[fwd_tag]["ms_per_step"] * 1e-3) / 1e12, 2)
+                    if fwd_tag in kern_ms else None)
 
     if rank == 0:
         cpu = cpu_baseline(cfg, args.batch, args.cpu_steps) if (args.cpu_baseline and world == 1) else None

@@ -1482,17 +1482,20 @@ def _block_args(blk):
         # a Block called twice in one step (DeNAuto's discriminator: positive and negative pairs) runs its own power
         # iteration for the second call, as torch's spectral_norm hook does; the descriptor tables are cached on the Block,
         # so that nothing is uploaded once the step is being captured into a HIP graph
-        # (a ring of four: the 1/sigma and W^T buffers of an earlier call of this step are saved for ITS backward pass
-        # and must not be overwritten by the next call)
+        # (a ring of four, indexed by the call's number within the step: the 1/sigma and W^T buffers of an earlier call
+        # of this step are saved for ITS backward pass and must not be overwritten by the next call; the k-th extra call
+        # of every step uses the same slot, so one eager step warms every slot a captured step will touch)
         ring = blk.__dict__.setdefault("_sn_ring", [{}, {}, {}, {}])
         blk.__dict__["_sn_turn"] = turn = (blk.__dict__.get("_sn_turn", -1) + 1) % len(ring)
         spectral_prepass(list(lins), blk.training, lins[0].eps, cache=ring[turn])
         us = [m.weight_u.clone() for m in lins]       # a later forward may advance the buffers before this backward runs
         vs = [m.weight_v.clone() for m in lins]
     elif getattr(lins[0], "clone_uv", False):
+        blk.__dict__["_sn_turn"] = -1                 # first call of a step (it consumed the model's pre-pass)
         us = [m.weight_u.clone() for m in lins]
         vs = [m.weight_v.clone() for m in lins]
     else:
+        blk.__dict__["_sn_turn"] = -1
         us = [m.weight_u for m in lins]
         vs = [m.weight_v for m in lins]
     inv, wts = [], []
