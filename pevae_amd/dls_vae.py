@@ -121,7 +121,18 @@ class DLSVAE(nn.Module):
         if self._cut is not None:
             self.backward_vocab(loss)
             return self.backward_rest(loss)
-        self.valid_loss(loss, batch_cnt, step=step).backward()
+        self._run_backward(lambda: self.valid_loss(loss, batch_cnt, step=step).backward())
+
+    @staticmethod
+    def _run_backward(fn):
+        """Backward pass with the recurrences' weight-gradient GEMMs off the critical path (ops.side_work); the side stream
+        is joined before this returns, so the caller sees finished gradients on the current stream."""
+        prev, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, True
+        try:
+            fn()
+        finally:
+            ops.ASYNC_WGRAD = prev
+            ops.join_side_work()
 
     def backward_vocab(self, loss):
         """First part of the backward pass with split_backward: d(valid_loss)/d(vae_nll) = 1 (:3451-3465), so this is the
@@ -138,7 +149,7 @@ class DLSVAE(nn.Module):
         if self.config.do_pred and loss.get("rating_mse") is not None:
             tensors.append(loss.rating_mse)
             grads.append(None)
-        torch.autograd.backward(tensors, grads)
+        self._run_backward(lambda: torch.autograd.backward(tensors, grads))
 
     def forward(self, data_feed, mode=TEACH_FORCE, gen_type="greedy", eps=None):
         if self.training and self.config.dropout > 0:

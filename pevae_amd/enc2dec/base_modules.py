@@ -36,8 +36,9 @@ class RNNWeights(nn.Module):
         tail = "_l{}{}".format(layer, "_reverse" if direction else "")
         return [getattr(self, n + tail) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
 
-    def forward(self, x, state=None, lengths=None):
-        """x [B,L,in] -> (out [B,L,H*dirs], h_n [layers*dirs,B,H] (LSTM: (h_n, c_n)), hseq_bf16 of the last layer or None).
+    def forward(self, x, state=None, lengths=None, x_side=False):
+        """x_side: x was produced under ops.on_side() (see ops.GRULayer).
+        x [B,L,in] -> (out [B,L,H*dirs], h_n [layers*dirs,B,H] (LSTM: (h_n, c_n)), hseq_bf16 of the last layer or None).
         lengths (list / tensor [B]): pack_padded_sequence semantics (encoders.py:55-65): a row's state stops at its
         length, outputs past it are zero and the time axis is cut to max(lengths).  The reverse direction of a
         bidirectional RNN then starts at each row's own last token: its input is the row's valid prefix reversed in
@@ -72,7 +73,8 @@ class RNNWeights(nn.Module):
                     cfinals.append(cn)
                 else:
                     h0 = None if state is None else state[layer * ndir + d]
-                    out, hn, hs = ops.GRULayer.apply(xin, h0, w_ih, w_hh, b_ih, b_hh, save, lens)
+                    out, hn, hs = ops.GRULayer.apply(xin, h0, w_ih, w_hh, b_ih, b_hh, save, lens,
+                                                     x_side and layer == 0 and d == 0 and lengths is None)
                 if mask is not None:
                     out, hs = out * mask, None            # zero rows past each length (pad_packed_sequence)
                 if d and rev_idx is not None:

@@ -192,12 +192,16 @@ class DecoderRNN(BaseRNN):
         """decoders.py:171-189: embedding -> dropout -> [cat latent] -> RNN -> [attention] -> dropout.
         defer_output_dropout: return the states BEFORE the output dropout plus the (p, site, mask) it must still get (the
         teacher-forced path folds it into the vocabulary operand pack); the 4th result is then (hseq, drop)."""
-        embedded = ops.embedding(self.embedding.weight, input_var, self.embedding.padding_idx)
-        embedded = self.input_dropout(embedded)
+        # the teacher-forced input embedding on the side stream: its backward (a sort and a segmented sum nobody waits
+        # for) then runs beside the latent stack's backward instead of in front of it
+        side = latent_variable is None and input_var.size(1) > 1 and torch.is_grad_enabled() and input_var.is_cuda
+        with ops.on_side(side):
+            embedded = ops.embedding(self.embedding.weight, input_var, self.embedding.padding_idx)
+            embedded = self.input_dropout(embedded)
         if latent_variable is not None:
             tiled = latent_variable.unsqueeze(1).repeat(1, embedded.size(1), 1)
             embedded = torch.cat([embedded, tiled], dim=-1)
-        output, hidden, hseq = self.rnn(embedded, hidden)
+        output, hidden, hseq = self.rnn(embedded, hidden, x_side=side)
         attn = None
         if self.use_attention and encoder_outputs is not None:
             output, attn = self.attention(output, encoder_outputs)

@@ -85,9 +85,113 @@ def parallel(*fns):
     return outs
 
 
+ASYNC_WGRAD = False      # set for the duration of DLSVAE.backward(): work nothing downstream waits for (weight-gradient
+_SIDE = {}               # GEMMs into gradient sinks, the decoder's embedding gradient) leaves the critical path
+
+
+def _side_state(dev=None):
+    cur = torch.cuda.current_stream(dev)
+    st = _SIDE.get(cur.device)
+    if st is None:
+        st = _SIDE[cur.device] = dict(stream=torch.cuda.Stream(device=cur.device), keep=[])
+    return cur, st
+
+
+class side_work(object):
+    """`with side_work(enabled, keep=[...])`: run the body on the device's side stream, forked from the current stream.
+    In a backward pass (ASYNC_WGRAD) the body may only accumulate into gradient sinks or produce tensors whose consumers
+    themselves run on the side stream (forward under on_side): autograd orders a consumer after the stream the node's
+    FORWARD ran on, not after this one.  `keep`: tensors of the current stream that the body reads; they stay referenced
+    until join_side_work() so that the caching allocator cannot hand their memory out."""
+
+    def __init__(self, enabled, keep=()):
+        self.enabled = bool(enabled) and ASYNC_WGRAD
+        self.keep = keep
+
+    def __enter__(self):
+        if not self.enabled:
+            return self
+        cur, st = _side_state()
+        if cur == st["stream"]:              # already there (a node whose forward ran under on_side)
+            self.enabled = False
+            return self
+        st["stream"].wait_stream(cur)
+        st["keep"].append(self.keep)
+        self.ctx = torch.cuda.stream(st["stream"])
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+class on_side(object):
+    """Forward-time region on the side stream, joined on exit: the autograd nodes created inside run their BACKWARD on
+    the side stream too, i.e. beside whatever the main stream does then (the decoder's input embedding: its gradient --
+    a sort and a segmented sum -- is needed by nobody before the optimizer)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled) and torch.cuda.is_available()
+
+    def __enter__(self):
+        if not self.enabled:
+            return self
+        self.cur, st = _side_state()
+        self.side = st["stream"]
+        self.side.wait_stream(self.cur)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+            self.cur.wait_stream(self.side)
+        return False
+
+
+SIDE_DX = os.environ.get("PEVAE_SIDE_DX", "1") == "1"
+_DEFERRED = []           # (event on the stream that queued it, closure): side work whose launch is postponed
+
+
+def defer_side_work(fn, keep=()):
+    """Run fn() on the side stream LATER (at the next join_side_work()), ordered after everything the current stream has
+    queued so far.  Postponing the launch changes nothing in what the work depends on, but under HIP-graph capture it
+    makes the critical chain, not the side work, the first successor of the node that produced their common input:
+    the graph executor keeps a node's first successor on its queue and starts the others through a cross-queue wait."""
+    if not ASYNC_WGRAD:
+        fn()
+        return
+    cur, st = _side_state()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _DEFERRED.append((ev, fn, keep))
+
+
+def join_side_work():
+    """Launch postponed side work, then make the current stream wait for the side stream (before a persistent kernel
+    that needs every CU, and at the end of the backward pass)."""
+    if not _SIDE:
+        return
+    cur, st = _side_state()
+    side = st["stream"]
+    if cur == side:
+        return
+    while _DEFERRED:
+        ev, fn, _keep = _DEFERRED.pop(0)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            fn()
+    cur.wait_stream(side)
+    st["keep"] = []
+
+
 def workspace(tag, numel, dtype, device, zero=False):
-    """Persistent scratch (reused every step, stream-ordered).  Never handed to autograd as saved state."""
-    key = (tag, dtype, device)
+    """Persistent scratch (reused every step, stream-ordered: one buffer per tag AND stream, so that the side stream's
+    kernels never share scratch with the main stream's).  Never handed to autograd as saved state."""
+    key = (tag, dtype, device, torch.cuda.current_stream(device).stream_id if torch.cuda.is_available() else 0)
     t = _WS.get(key)
     if t is None or t.numel() < numel:
         t = torch.zeros(numel, dtype=dtype, device=device) if zero else torch.empty(numel, dtype=dtype, device=device)
@@ -189,7 +293,7 @@ def gemm_nt_ct(A, lda, Bm, ldb, M, N, K, bias, out_t):
     return out_t
 
 
-def gemm_nt_wgrad(A, lda, Bm, ldb, M, N, K, sink=None, k_live=None):
+def gemm_nt_wgrad(A, lda, Bm, ldb, M, N, K, sink=None, k_live=None, ws_tag="gemm_splitk"):
     """Weight-gradient GEMM C[M,N] = A[M,K] B[N,K]^T whose K is the token count: split-K over ~2 workgroups per CU when
     the plain tiling would leave most of the chip idle.  Accumulates into `sink` when given, else returns C."""
     _need_cuda(A, Bm)
@@ -202,7 +306,7 @@ def gemm_nt_wgrad(A, lda, Bm, ldb, M, N, K, sink=None, k_live=None):
     if splits.value <= 1:
         gemm_nt(A, lda, Bm, ldb, M, N, K, out=out, accumulate=sink is not None, k_live=k_live)
     else:
-        ws = workspace("gemm_splitk", _lib.load().pv_gemm_splitk_ws_bytes(M, N, splits.value), torch.uint8, A.device)
+        ws = workspace(ws_tag, _lib.load().pv_gemm_splitk_ws_bytes(M, N, splits.value), torch.uint8, A.device)
         _lib.call("pv_gemm_bf16_nt_splitk", _p(A), lda, _p(Bm), ldb, M, N, K, splits.value, _p(ws), _p(out),
                   out.stride(0), 1 if sink is not None else 0, None, _p(k_live), _stream())
     return None if sink is not None else out
@@ -636,11 +740,12 @@ class GRULayer(torch.autograd.Function):
     hseq bf16 [(L+1)*Bpad, Hk] = every state in time-major order, reusable as a GEMM operand)."""
 
     @staticmethod
-    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, save, lengths=None):
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, save, lengths=None, x_side=False):
         _need_cuda(x, w_ih, w_hh, b_ih, b_hh, h0, lengths)
         B, L, E = x.shape
         H = w_hh.shape[1]
         dev = x.device
+        ctx.x_side = bool(x_side)           # x was produced under on_side(): its gradient's consumers run on the side stream
         Hk, K3, Bpad, NG = gru_geometry(B, H)
         Ep = round_up(E, 64)
         x_bf = cast_pack(x, L, B, Bpad, E, x.stride(1), x.stride(0), x.stride(2), Ep)
@@ -655,6 +760,7 @@ class GRULayer(torch.autograd.Function):
         hall = torch.empty(((L + 1), Bpad, H), dtype=torch.float32, device=dev)
         sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
         h0c = None if h0 is None else h0.contiguous()
+        join_side_work()
         with timed("gru_fwd"):
             _lib.call("pv_gru_fwd", _p(xprojT), L * Bpad, _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), _p(lengths), L, B, H, 0,
                       _p(hseq), _p(gsave), _p(hall), _p(hn), _p(sync), GRU_MAX_WGS, _stream())
@@ -686,6 +792,7 @@ class GRULayer(torch.autograd.Function):
         if dout is not None:
             dout = dout if dout.stride(2) == 1 else dout.contiguous()
         dhn_c = None if dhn is None else dhn.contiguous()
+        join_side_work()        # the recurrence's workgroups wait for each other: nothing else may hold CUs
         with timed("gru_bwd"):
             _lib.call("pv_gru_bwd", _p(dout), 0 if dout is None else dout.stride(0),
                       0 if dout is None else dout.stride(1), _p(dhn_c), _p(gsave), _p(hall), _p(whhT), L, B, H, 0,
@@ -693,19 +800,32 @@ class GRULayer(torch.autograd.Function):
         LAST_GRU_SYNC.append((sync, NG, "pv_gru_bwd"))
         Tt = L * Bpad
         Tp = round_up(Tt, 64)
-        # dx = dgi W_ih  (time-major rows), then back to [B,L,E]
-        wihT = transpose_to_bf16(w_ih.contiguous(), 3 * H, E, E, K3)
-        dx_tm = gemm_nt(dgi, K3, wihT, K3, Tt, E, K3)
-        dx = dx_tm.view(L, Bpad, E)[:, :B].transpose(0, 1)
-        # dW_ih = dgi^T x ; dW_hh = dgh^T h_prev   (K = all time-major rows)
-        dgiT = transpose_to_bf16(dgi, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
-        xT = transpose_to_bf16(x_bf, Tt, E, Ep, Tp, out=workspace("gru_xT", E * Tp, BF16, dev).view(E, Tp))
         p_ih, p_hh = ctx.params
-        dw_ih = gemm_nt_wgrad(dgiT, Tp, xT, Tp, 3 * H, E, Tp, grad_sink(p_ih, (3 * H, E)))
-        dghT = transpose_to_bf16(dgh, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
-        hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
-        dw_hh = gemm_nt_wgrad(dghT, Tp, hpT, Tp, 3 * H, H, Tp, grad_sink(p_hh, (3 * H, H)))
-        return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None, None
+        s_ih, s_hh = grad_sink(p_ih, (3 * H, E)), grad_sink(p_hh, (3 * H, H))
+        sinks = s_ih is not None and s_hh is not None
+        # dx = dgi W_ih  (time-major rows), then back to [B,L,E]; off the critical path when its consumers are (x_side)
+        with side_work(sinks and ctx.x_side and SIDE_DX, keep=(dgi,)):
+            wihT = transpose_to_bf16(w_ih.contiguous(), 3 * H, E, E, K3)
+            dx_tm = gemm_nt(dgi, K3, wihT, K3, Tt, E, K3)
+        dx = dx_tm.view(L, Bpad, E)[:, :B].transpose(0, 1)
+        # dW_ih = dgi^T x ; dW_hh = dgh^T h_prev   (K = all time-major rows).  Nothing downstream reads them before the
+        # optimizer: with gradient sinks they run beside whatever the backward pass does next (the latent stack's chain of
+        # small kernels, the embedding gradients)
+        def wgrads():
+            dgiT = transpose_to_bf16(dgi, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
+            xT = transpose_to_bf16(x_bf, Tt, E, Ep, Tp, out=workspace("gru_xT", E * Tp, BF16, dev).view(E, Tp))
+            r_ih = gemm_nt_wgrad(dgiT, Tp, xT, Tp, 3 * H, E, Tp, s_ih, ws_tag="gemm_splitk_rnn")
+            dghT = transpose_to_bf16(dgh, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
+            hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
+            r_hh = gemm_nt_wgrad(dghT, Tp, hpT, Tp, 3 * H, H, Tp, s_hh, ws_tag="gemm_splitk_rnn")
+            return r_ih, r_hh
+
+        if sinks:
+            defer_side_work(wgrads, keep=(dgi, dgh, x_bf, hseq))
+            dw_ih = dw_hh = None
+        else:
+            dw_ih, dw_hh = wgrads()
+        return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None, None, None
 
 
 class LSTMLayer(torch.autograd.Function):
