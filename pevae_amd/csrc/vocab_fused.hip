@@ -42,7 +42,8 @@ constexpr int BUF_BYTES = TILE_BYTES + AUX_BYTES;
 constexpr int SMEM_BYTES = 2 * BUF_BYTES;
 constexpr int UNIT = 128;               // rows (forward) / columns (dW) a workgroup's accumulators cover: 4 waves x 32
 constexpr float NEG_BIG = -1e30f;
-constexpr float RESCALE_THR = 20.f;     // a row's maximum may exceed the one in use by this much before O is rescaled (p <= e^20)
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+constexpr float RESCALE_THR = 28.f;     // log2 units: a row's maximum may exceed the one in use by this much before O is rescaled
 
 struct Segs {                            // a workgroup's item range and how units map to its slabs
   long beg, end;
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
     for (int c = 0; c < NCB; ++c)
 #pragma unroll
       for (int j = 0; j < 16; ++j) O[c][j] = 0.f;
-    float m_used = NEG_BIG, l_sum = 0.f, tl = 0.f;
+    float m_used = NEG_BIG, l_sum = 0.f, tl = 0.f;       // running maximum and target logit in log2 units
+    const float it_l2e = a.inv_temp * LOG2E;
 
     auto stage = [&](int k) {
       char* buf = smem + (k & 1) * BUF_BYTES;
@@ -220,21 +222,26 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) X[j] = 0.f;
       first_product(tile, rbase, swh, hf, X);
-      // ---- scaled logits, running maximum (shared by the two lane halves of a row), target logit -------------------
+      // ---- scaled logits in LOG2 units (exp is v_exp_f32 = 2^x: no multiply per element), running maximum (shared by the
+      // two lane halves of a row), target logit.  The column mask and the target pick are needed by one tile in hundreds:
+      // both sit behind wave-uniform branches.
       float sv[16], mx = NEG_BIG;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const f32x4 b4 = *(const f32x4*)(bias_t + 8 * g4 + 4 * hh);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int vl = 8 * g4 + 4 * hh + i, vg = v0 + vl;
-          float s = (X[4 * g4 + i] + b4[i]) * a.inv_temp;
-          s = vg < a.V ? s : NEG_BIG;
-          tl += vg == y ? s : 0.f;
-          sv[4 * g4 + i] = s;
-          mx = fmaxf(mx, s);
-        }
+        for (int i = 0; i < 4; ++i) sv[4 * g4 + i] = (X[4 * g4 + i] + b4[i]) * it_l2e;
       }
+      if (v0 + 32 > a.V) {                                 // the last tile: columns past V
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sv[j] = v0 + 8 * (j >> 2) + 4 * hh + (j & 3) < a.V ? sv[j] : NEG_BIG;
+      }
+      if (__any((unsigned)(y - v0) < 32u)) {               // some row of this wave has its target in this tile
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tl += v0 + 8 * (j >> 2) + 4 * hh + (j & 3) == y ? sv[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mx = fmaxf(mx, sv[j]);
       mx = fmaxf(mx, xor32(mx));
       if (k == 0) {
         m_used = mx;                                       // O and l are still zero: nothing to rescale
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
         // whole kernel spills (944 bytes of scratch per lane), so each one is read / scaled / written back in place.
         // MFMA results need up to 18 wait states before v_accvgpr_read may see them; the assembler pads nothing inside asm.
         const float m_new = fmaxf(m_used, mx);
-        const float alpha = __expf(m_used - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_used - m_new);
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
       bf16x8 pf[2];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float p = __expf(sv[j] - m_used);          // <= e^RESCALE_THR; masked columns: exp(-1e30 - m) = 0
+        const float p = __builtin_amdgcn_exp2f(sv[j] - m_used);   // <= 2^RESCALE_THR; masked columns: 2^(-1e30 - m) = 0
         l_sum += p;
         pf[j >> 3][j & 7] = (__bf16)p;
       }
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
       for (int j = 0; j < 16; ++j) o[(long)(32 * c + (j & 3) + 8 * (j >> 2) + 4 * hh) * UNIT] = O[c][j];
     l_sum += xor32(l_sum);
     tl += xor32(tl);
-    if (hh == 0) a.stats[slab * UNIT + 32 * w + r32] = make_float4(m_used, l_sum, tl, 0.f);
+    if (hh == 0) a.stats[slab * UNIT + 32 * w + r32] = make_float4(m_used * LN2, l_sum, tl * LN2, 0.f);
     __syncthreads();                           // the ring restarts with the next segment
   }
 }
@@ -425,6 +432,7 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) Z[c][j] = 0.f;
     float bsum = 0.f;
+    const float it_l2e = a.inv_temp * LOG2E, cb = bias_v * it_l2e;
 
     auto stage = [&](int k) {
       char* buf = smem + (k & 1) * BUF_BYTES;
@@ -450,23 +458,42 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) X[j] = 0.f;
       first_product(tile, rbase, swh, wf, X);
-      // ---- P = gs (softmax - onehot); its column sums are the bias gradient ------------------------------------------
+      // ---- P = gs (softmax - onehot); its column sums are the bias gradient.  exp(s - lse) = 2^(X it_l2e + cb - lse log2e).
+      // The row mask (rows past the live count: the last item only) and the onehot (a target inside this wave's 32 columns:
+      // one item in twenty) sit behind a wave-uniform branch.  Columns past V need no mask: nothing reads their Z rows.
       bf16x8 pf[2];
+      const bool edge = t0 + 32 > nlive;
+      const bool hit = __any((unsigned)(tgt_t[r32] - (ct * UNIT + 32 * w)) < 32u);
+      if (__builtin_expect(edge || hit, 0)) {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 l4 = *(const f32x4*)(lse_t + 8 * g4 + 4 * hh);
-        const f32x4 g_4 = *(const f32x4*)(gs_t + 8 * g4 + 4 * hh);
-        const int4 y4 = *(const int4*)(tgt_t + 8 * g4 + 4 * hh);
-        const int yy[4] = {y4.x, y4.y, y4.z, y4.w};
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 l4 = *(const f32x4*)(lse_t + 8 * g4 + 4 * hh);
+          const f32x4 g_4 = *(const f32x4*)(gs_t + 8 * g4 + 4 * hh);
+          const int4 y4 = *(const int4*)(tgt_t + 8 * g4 + 4 * hh);
+          const int yy[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int tloc = 8 * g4 + 4 * hh + i;
-          const float gsv = (t0 + tloc < nlive && v_ok) ? g_4[i] * a.inv_temp : 0.f;
-          float p = __expf((X[4 * g4 + i] + bias_v) * a.inv_temp - l4[i]);
-          p = (yy[i] == v_mine ? p - 1.f : p) * gsv;
-          p = gsv != 0.f ? p : 0.f;                          // (exp may be inf where lse is a stale 0 of a dead row)
-          bsum += p;
-          pf[(4 * g4 + i) >> 3][(4 * g4 + i) & 7] = (__bf16)p;
+          for (int i = 0; i < 4; ++i) {
+            const int tloc = 8 * g4 + 4 * hh + i;
+            const float gsv = t0 + tloc < nlive ? g_4[i] * a.inv_temp : 0.f;
+            // (the clamp keeps 2^x finite where lse is stale, e.g. the 0 of a dead row: its gsv is 0 and 0 * inf is NaN)
+            float p = __builtin_amdgcn_exp2f(fminf(fmaf(X[4 * g4 + i], it_l2e, fmaf(l4[i], -LOG2E, cb)), 126.f));
+            p = (yy[i] == v_mine ? p - 1.f : p) * gsv;
+            bsum += p;
+            pf[(4 * g4 + i) >> 3][(4 * g4 + i) & 7] = (__bf16)p;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 l4 = *(const f32x4*)(lse_t + 8 * g4 + 4 * hh);
+          const f32x4 g_4 = *(const f32x4*)(gs_t + 8 * g4 + 4 * hh);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float p = __builtin_amdgcn_exp2f(fminf(fmaf(X[4 * g4 + i], it_l2e, fmaf(l4[i], -LOG2E, cb)), 126.f)) *
+                            (g_4[i] * a.inv_temp);
+            bsum += p;
+            pf[(4 * g4 + i) >> 3][(4 * g4 + i) & 7] = (__bf16)p;
+          }
         }
       }
       // ---- Z[v][hc] += P^T[v][t] h[t][hc]: the probabilities x columns of the same h tile -----------------------------
