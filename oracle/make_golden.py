@@ -128,6 +128,33 @@ def gen_encoder(encoders):
     save("encoder_gru_varlen", x=x, lens=np.array(lens), out=out, hn=hn, **sd(enc))
 
 
+def gen_utt_encoder(encoders):
+    """RnnUttEncoder.forward (encoders.py:69-135) from the reference class: [B, n_ctx, n_tok] token ids -> one vector per
+    utterance.  'attn': bidirectional GRU, extra per-utterance feature column, additive self-attention pooling (:117-122);
+    'last': unidirectional GRU with a repeated initial state (:104-105), last state as the utterance vector (:123-126)."""
+    for tag, kw, bidir in (("attn", dict(bidirection=True, use_attn=True, feat_size=1), True),
+                           ("last", dict(bidirection=False, use_attn=False, feat_size=0), False)):
+        torch.manual_seed(13)
+        V, E, H, B, C, Lt = 23, 8, 16, 3, 2, 5
+        enc = encoders.RnnUttEncoder(H, 0.0, rnn_cell="gru", vocab_size=V, embed_dim=E, **kw)
+        utts = torch.randint(0, V, (B, C, Lt))
+        feats = torch.randn(B, C) if kw["feat_size"] else None
+        init = None if bidir else torch.randn(1, B, H) * 0.5
+        utt, enc_outs, enc_last, attn = enc(utts, feats=feats, init_state=init, return_all=True)
+        w = torch.randn_like(utt)
+        loss = (utt * w).sum()
+        loss.backward()
+        extra = {}
+        if feats is not None:
+            extra["feats"] = feats
+        if init is not None:
+            extra["init_state"] = init
+        if attn is not None:
+            extra["attn"] = attn
+        save("utt_encoder_" + tag, utterances=utts.numpy(), w=w, utt=utt, enc_outs=enc_outs, enc_last=enc_last, loss=loss,
+             **extra, **sd(enc), **grads(enc))
+
+
 def gen_encoder_bi_varlen(encoders):
     """Bidirectional GRU through the reference's pack_padded_sequence path (encoders.py:55-65): the reverse direction
     starts at each row's own last token."""
@@ -434,11 +461,11 @@ class _CpuCurrentDevice:
         torch.cuda.current_device = self._orig
 
 
-def _dls_cfg(B):
+def _dls_cfg(B, gir_weight=0.0):
     # cip_weight / gir_weight are read by DLS_Auto.forward (:3287, :3311) but defined by no parser.
-    # gir_weight = 0 switches the density-estimate regulariser off in value and gradient: the HIP path leaves that
-    # term out (it raises in the reference as written: torch.log of the Python int n_batch = -1, :3169, :3235).
-    return types.SimpleNamespace(batch_size=B, expand_weight=0.5, converge_weight=0.1, cip_weight=1.0, gir_weight=0.0,
+    # gir_weight = 0 switches the density-estimate regulariser off in value and gradient (it raises in the reference as
+    # written: torch.log of the Python int n_batch = -1, :3169, :3235); the 'train_gir' fixture switches it on.
+    return types.SimpleNamespace(batch_size=B, expand_weight=0.5, converge_weight=0.1, cip_weight=1.0, gir_weight=gir_weight,
                                  ost=False)
 
 
@@ -458,8 +485,9 @@ def gen_dls_auto():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import ref_modules as R
     B, d0, dmax = 10, 4, 16
-    for tag, restarted, training in (("train", False, True), ("restarted_train", True, True), ("restarted_eval", True, False)):
-        cfg = _dls_cfg(B)
+    for tag, restarted, training in (("train", False, True), ("restarted_train", True, True), ("restarted_eval", True, False),
+                                     ("train_gir", False, True)):
+        cfg = _dls_cfg(B, gir_weight=0.25 if tag == "train_gir" else 0.0)      # train_gir: density-estimate term on
         torch.manual_seed(81)
         with _CpuCurrentDevice():
             m = dm.DLS_Auto(d0, dmax, cfg)
@@ -477,13 +505,15 @@ def gen_dls_auto():
         noise = _redraw_uniform(82, [(B, w) for w in widths])
         o = R.DLSAuto(d0, dmax, cfg)
         o.load_state_dict({k: torch.from_numpy(v) for k, v in pre.items()})
+        o.n_batch = torch.tensor(float(B))
         o.train(training)
         z2, rkl2 = o(output.detach(), rec_output.detach(), [a.detach() for a in act1], [a.detach() for a in act2],
                      restarted, noise=noise)
         assert torch.allclose(z2, z, rtol=1e-4, atol=2e-5) and abs(float(rkl2) - float(rkl)) <= 1e-5 * abs(float(rkl)), \
             (tag, float((z2 - z).abs().max()), float(rkl2), float(rkl))
         arrs = dict(output=output, rec_output=rec_output, z=z, rkl=rkl, d_output=output.grad, d_rec_output=rec_output.grad,
-                    restarted=np.array(restarted), training=np.array(training))
+                    restarted=np.array(restarted), training=np.array(training), gir_weight=np.array(cfg.gir_weight),
+                    n_batch=np.array(float(B)))
         for i in range(3):
             arrs.update({"act1_%d" % i: act1[i], "act2_%d" % i: act2[i], "noise_%d" % i: noise[i]})
             for nm, a in (("d_act1_%d" % i, act1[i]), ("d_act2_%d" % i, act2[i])):
@@ -677,7 +707,7 @@ def main():
     torch.set_num_threads(4)
     torch.use_deterministic_algorithms(False)
     encoders, decoders, base_modules, nn_lib, criterions, utils = import_reference()
-    todo = dict(encoder=lambda: gen_encoder(encoders), encoder_bi_varlen=lambda: gen_encoder_bi_varlen(encoders),
+    todo = dict(encoder=lambda: gen_encoder(encoders), utt_encoder=lambda: gen_utt_encoder(encoders), encoder_bi_varlen=lambda: gen_encoder_bi_varlen(encoders),
                 encoder_lstm_varlen=lambda: gen_encoder_lstm_varlen(encoders), decoder=lambda: gen_decoder(decoders),
                 attention=lambda: gen_attention(decoders), connectors=lambda: gen_connectors(nn_lib),
                 criterions=lambda: gen_criterions(criterions),

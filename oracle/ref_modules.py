@@ -256,6 +256,44 @@ class EncoderRNN(BaseRNN):
         return run_rnn(self.rnn, emb, init_state, lens, self.training)         # encoders.py:59-66
 
 
+class RnnUttEncoder(nn.Module):
+    """models/enc2dec/encoders.py:69-135: word embedding (+ one feature column per utterance) -> EncoderRNN over every
+    utterance of every context -> the utterance vector: softmax-weighted sum of the states (use_attn, :117-122) or the
+    last state(s) (:123-126)."""
+
+    def __init__(self, utt_cell_size, dropout, rnn_cell="gru", bidirection=True, use_attn=False, embedding=None,
+                 vocab_size=None, embed_dim=None, feat_size=0):
+        super().__init__()
+        self.embedding = nn.Embedding(vocab_size, embed_dim) if embedding is None else embedding       # :77-82
+        self.embed_size = self.embedding.embedding_dim
+        self.rnn = EncoderRNN(self.embed_size + feat_size, utt_cell_size, 0.0, dropout, rnn_cell=rnn_cell,
+                              variable_lengths=False, bidirection=bidirection)                           # :84-87
+        self.output_size = utt_cell_size * (2 if bidirection else 1)
+        self.use_attn = use_attn
+        if use_attn:                                                                                     # :93-96
+            self.key_w = nn.Linear(self.output_size, utt_cell_size)
+            self.query = nn.Linear(utt_cell_size, 1)
+
+    def forward(self, utterances, feats=None, init_state=None, return_all=False):
+        B, n_ctx, n_tok = (int(s) for s in utterances.size())
+        if init_state is not None:
+            init_state = init_state.repeat(1, n_ctx, 1)                                                  # :104-105
+        words = self.embedding(utterances.view(-1, n_tok))                                               # :108-109
+        if feats is not None:                                                                            # :111-114
+            words = torch.cat([words, feats.view(-1, 1).unsqueeze(1).repeat(1, n_tok, 1)], dim=2)
+        enc_outs, enc_last = self.rnn(words, init_state=init_state)                                      # :116
+        if self.use_attn:                                                                                # :118-122
+            score = self.query(torch.tanh(self.key_w(enc_outs))).squeeze(2)
+            e = (score - score.max(dim=-1, keepdim=True).values).exp()
+            attn = (e / e.sum(dim=-1, keepdim=True)).unsqueeze(2)
+            utt = (attn * enc_outs).sum(dim=1)
+        else:                                                                                            # :124-126
+            attn = None
+            utt = enc_last.transpose(0, 1).contiguous().view(-1, self.output_size)
+        utt = utt.view(B, n_ctx, self.output_size)                                                       # :128
+        return (utt, enc_outs, enc_last, attn) if return_all else utt
+
+
 class Attention(nn.Module):
     """models/enc2dec/decoders.py:15-118 ('dot' | 'general' | 'cat')."""
 
@@ -731,14 +769,27 @@ class DlsPyramid(nn.Module):
         return output, acts
 
 
+def density_estimate(mean, logvar, sample, n_batch):
+    """DLS_Auto.density_estimate + _density_estimate, dialog_models.py:3227-3236, with the standard-normal log density of
+    gau_list[i] (:3198, :3203) written out: for every pair (a, b) the sample of row a is standardised by the Gaussian of
+    row b, log N(0, 1) is summed over the features and over b, log(n_batch * B) is subtracted, and the mean over a is
+    taken.  `n_batch` is the reference's self.n_batch (:3169 sets the Python int -1, on which torch.log raises: the
+    term only runs with n_batch a tensor, see oracle/make_golden.py gen_dls_auto)."""
+    var = logvar.exp()
+    rs = sample.expand(sample.size(0), sample.size(0), sample.size(1)).transpose(0, 1)      # rs[a][b] = sample[a]
+    x = (rs - mean) / var
+    log_prob = -0.5 * x * x - 0.5 * math.log(2 * math.pi)
+    prob = log_prob.sum(-1).sum(-1) - torch.log(n_batch * var.size(0))
+    return prob.mean()
+
+
 class DLSAuto(nn.Module):
     """DLS_Auto.forward, dialog_models.py:3274-3352 (train branch :3285-3311, restarted / ost branch :3312-3351),
-    restated on the oracle Block.  NOT reproduced: the density-estimate regulariser (:3232-3236, :3308, :3311), which
-    raises in the reference itself (torch.log of the Python int n_batch = -1); `batch_arrange` is arange(actual
-    batch) instead of arange(config.batch_size) (:3186).  The uniform draws of dis_reparameterization (:3206-3207) are
-    passed in as `noise` (one [B, d] tensor per level).  Parity of this composition is unpinned by the reference (its
-    constructor needs a CUDA device, :3198); its parts -- Block, gaussian_analytical_kl, cons_loss -- are pinned by
-    tests/golden/block.npz and dls_helpers.npz."""
+    restated on the oracle Block, including the density-estimate regulariser (:3232-3236, :3308, :3311) when
+    config.gir_weight != 0 (it needs `self.n_batch` as a tensor: the reference's Python int -1 makes torch.log raise).
+    `batch_arrange` is arange(actual batch) instead of arange(config.batch_size) (:3186).  The uniform draws of
+    dis_reparameterization (:3206-3207) are passed in as `noise` (one [B, d] tensor per level).  Pinned by
+    tests/golden/dls_auto_*.npz, generated from the reference class itself."""
 
     def __init__(self, input_dim, output_dim, config):
         super().__init__()
@@ -760,6 +811,9 @@ class DLSAuto(nn.Module):
         rkl = cons_loss(output, rec_output, arange) * cip
         last_sample = last_t = None
         train_branch = not restarted and not getattr(cfg, "ost", False)
+        gir = getattr(cfg, "gir_weight", 0.0)
+        n_batch = getattr(self, "n_batch", None)
+        qgroup, amean, alogvar, asample = 0, None, None, None                                      # :3280-3283
         for i, (layer, dis, dis2) in enumerate(zip(self.layers, self.dis_layers, self.dis_layers2)):
             a1, a2 = act1[-i - 1], act2[-i - 1]
             if last_sample is None:
@@ -777,6 +831,10 @@ class DLSAuto(nn.Module):
                 rkl = rkl + ew * gaussian_analytical_kl(t_mean, mean.detach(), t_lv, lv.detach())
                 rkl = rkl + cw * gaussian_analytical_kl(t_mean.detach(), mean, t_lv.detach(), lv)
                 rkl = rkl + cons_loss(a1, a2, arange) * cip
+                if gir != 0:
+                    cat = (lambda u, v: v if u is None else torch.cat([u, v], -1))
+                    amean, alogvar, asample = cat(amean, t_mean), cat(alogvar, t_lv), cat(asample, last_sample)   # :3293-3302
+                    qgroup = qgroup + density_estimate(t_mean, t_lv, last_sample, n_batch)          # :3308
                 output = layer(output) + last_sample
             else:
                 if self.training:
@@ -786,6 +844,8 @@ class DLSAuto(nn.Module):
                 else:
                     last_sample = t_mean + a2
                 output = torch.nan_to_num(layer(output) + last_sample)
+        if train_branch and gir != 0:
+            rkl = rkl + torch.abs((qgroup - density_estimate(amean, alogvar, asample, n_batch)) * gir)   # :3311
         return output, rkl
 
 

@@ -4,7 +4,8 @@
 
 Deviations, all forced by the reference being un-runnable as written:
   * DLS_Auto's density-estimate regulariser (:3232-3236, :3308, :3311) takes torch.log of a Python int
-    (`n_batch = -1`) and raises; it is left out (gir_weight term = 0).
+    (`n_batch = -1`) and raises, and config.gir_weight is defined by no parser; it is computed when config.gir_weight is
+    non-zero and `n_batch` has been set to a positive number, in closed form (see DLSAuto.density_term).
   * `gau_list` / `batch_arrange` need CUDA and a fixed batch size at construction (:3186, :3198); the InfoNCE targets
     are arange(actual batch) here.
   * uniform noise for `dis_reparameterization` (:3206-3207) can be passed in (`noise=[...]`) so that parity tests are
@@ -140,6 +141,7 @@ class DLSAuto(nn.Module):
     def __init__(self, input_dim, output_dim, config):
         super().__init__()
         self.config = config
+        self.n_batch = -1                                  # :3169; the density term needs a positive number here
         self.layers, self.dis_layers, self.dis_layers2 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         cnt = 0
         while input_dim <= output_dim:
@@ -149,6 +151,23 @@ class DLSAuto(nn.Module):
             self.dis_layers2.append(Block(input_dim * k, input_dim * 4, input_dim * 4))
             input_dim *= 2
             cnt += 1
+
+    def density_term(self, batch):
+        """|qgroup - density_estimate(concatenated levels)| * gir_weight (dialog_models.py:3308, :3311).
+        density_estimate (:3232-3236) is  mean_a[ sum_b sum_d log N((s[a,d] - m[b,d]) / v[b,d]; 0, 1) ] - log(n_batch * B):
+        the double sum is additive over the feature axis, so the sums of the per-level calls (qgroup) cancel against the
+        one call on the concatenated features and what is left is the constant (levels - 1) * log(n_batch * B) -- no
+        kernel, no gradient (the reference's own value differs from it by fp32 rounding of the two ~1e3 sums: 3e-5 at
+        B = 10; pinned by tests/golden/dls_auto_train_gir.npz)."""
+        gir = float(getattr(self.config, "gir_weight", 0.0) or 0.0)
+        if gir == 0.0:
+            return 0.0
+        n_batch = float(self.n_batch)
+        if not n_batch > 0:
+            raise ValueError("DLS_Auto: gir_weight != 0 needs n_batch > 0 (the reference's n_batch = -1, "
+                             "dialog_models.py:3169, makes its torch.log raise)")
+        import math
+        return abs(gir * (len(self.layers) - 1) * math.log(n_batch * batch))
 
     def forward(self, output, rec_output, act1, act2, restarted=False, noise=None):
         cfg = self.config
@@ -197,6 +216,10 @@ class DLSAuto(nn.Module):
                 else:
                     last_sample = t_mean + a2                                                      # :3350
                 output = torch.nan_to_num(lay_out + last_sample)                                   # :3351
+        if not restarted and not getattr(cfg, "ost", False):
+            dens = self.density_term(output.shape[0])
+            if dens:
+                rkl = rkl + dens                                                                   # :3311
         return output, rkl
 
 

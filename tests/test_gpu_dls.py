@@ -205,12 +205,12 @@ def test_cons_loss_sum_matches_single_calls(dev):
         np.testing.assert_allclose(b.grad.cpu().numpy(), d.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["train", "restarted_train", "restarted_eval"])
+@pytest.mark.parametrize("tag", ["train", "restarted_train", "restarted_eval", "train_gir"])
 def test_dls_auto_golden_from_reference_class(dev, tag):
     """L.DLSAuto (HIP) against the golden made from the reference's own DLS_Auto class (dialog_models.py:3274-3352):
-    z, rkl, every input / parameter gradient, the advanced power-iteration vectors."""
+    z, rkl, every input / parameter gradient, the advanced power-iteration vectors.  train_gir: with the density-estimate
+    regulariser (:3232-3236, :3311) switched on in the reference; the HIP path adds its closed form."""
     from pevae_amd import dls_latent as L
-    from test_oracle_golden import _dls_cfg, run_dls_auto_golden
+    from test_oracle_golden import dls_auto_from_golden, run_dls_auto_golden
     g = load_golden("dls_auto_" + tag)
-    m = load_params(L.DLSAuto(4, 16, _dls_cfg(10)), g).to(dev)
-    run_dls_auto_golden(m, g, lambda a: T(a, dev), 5e-4, 1e-4)
+    run_dls_auto_golden(dls_auto_from_golden(L.DLSAuto, g, dev), g, lambda a: T(a, dev), 5e-4, 1e-4)

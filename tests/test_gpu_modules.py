@@ -68,6 +68,35 @@ def test_encoder_rnn(dev, tag, kw):
     close(hn0, g["hn_nostate"], rtol=0, atol=3e-2)
 
 
+@pytest.mark.parametrize("tag", ["attn", "last"])
+def test_utt_encoder(dev, tag):
+    """RnnUttEncoder (HIP) vs the golden from the reference class (encoders.py:69-135): bidirectional GRU + feature column +
+    attention pooling, and unidirectional GRU with a repeated initial state + last-state pooling."""
+    from pevae_amd.enc2dec.encoders import RnnUttEncoder
+    from pevae_amd import ops
+    from test_oracle_golden import _utt_encoder_case
+    g = load_golden("utt_encoder_" + tag)
+    enc, feats, init = _utt_encoder_case(RnnUttEncoder, g, tag, lambda a: T(a, dev))
+    enc = enc.to(dev)
+    utt, enc_outs, enc_last, attn = enc(T(g["utterances"], dev), feats=feats, init_state=init, return_all=True)
+    (utt * T(g["w"], dev)).sum().backward()
+    torch.cuda.synchronize()
+    ops.gru_check_all()
+    close(utt, g["utt"], rtol=0, atol=3e-2)
+    close(enc_outs, g["enc_outs"], rtol=0, atol=3e-2)
+    close(enc_last, g["enc_last"], rtol=0, atol=3e-2)
+    if tag == "attn":
+        close(attn, g["attn"], rtol=0, atol=2e-2)
+    n = 0
+    for k, p in enc.named_parameters():
+        if k == "query.bias":            # a softmax is shift invariant: this gradient is zero, the golden holds its rounding
+            assert float(p.grad.abs().max()) < 1e-5
+            continue
+        assert relmax(p.grad, g["g." + k]) < 5e-2, k
+        n += 1
+    assert n >= 5
+
+
 def test_encoder_lstm(dev):
     """rnn_cell='lstm' (base_modules.py:42-51): (h, c) state in and out, golden from the reference's nn.LSTM path."""
     from pevae_amd.enc2dec.encoders import EncoderRNN

@@ -56,6 +56,30 @@ def test_encoder(tag, kw):
     close(hn0[0] if isinstance(hn0, tuple) else hn0, g["hn_nostate"])
 
 
+def _utt_encoder_case(cls, g, tag, to=lambda a: T(a)):
+    kw = dict(bidirection=True, use_attn=True, feat_size=1) if tag == "attn" else dict(bidirection=False, use_attn=False)
+    enc = load_params(cls(16, 0.0, rnn_cell="gru", vocab_size=23, embed_dim=8, **kw), g)
+    feats = to(g["feats"]) if "feats" in g else None
+    init = to(g["init_state"]) if "init_state" in g else None
+    return enc, feats, init
+
+
+@pytest.mark.parametrize("tag", ["attn", "last"])
+def test_utt_encoder(tag):
+    """oracle RnnUttEncoder vs the reference class (encoders.py:69-135): utterance vectors, states, attention weights and
+    every parameter gradient."""
+    g = load_golden("utt_encoder_" + tag)
+    enc, feats, init = _utt_encoder_case(R.RnnUttEncoder, g, tag)
+    utt, enc_outs, enc_last, attn = enc(T(g["utterances"]), feats=feats, init_state=init, return_all=True)
+    (utt * T(g["w"])).sum().backward()
+    close(utt, g["utt"])
+    close(enc_outs, g["enc_outs"])
+    close(enc_last, g["enc_last"])
+    if tag == "attn":
+        close(attn, g["attn"])
+    check_grads(enc, g, rtol=1e-4, atol=1e-5)
+
+
 def test_encoder_varlen():
     g = load_golden("encoder_gru_varlen")
     enc = load_params(R.EncoderRNN(8, 16, variable_lengths=True), g)
@@ -356,9 +380,18 @@ def test_den_auto_oracle_matches_reference():
             close(v, g["post." + k], rtol=1e-5, atol=1e-6)
 
 
-def _dls_cfg(B):
+def _dls_cfg(B, gir_weight=0.0):
     import types
-    return types.SimpleNamespace(batch_size=B, expand_weight=0.5, converge_weight=0.1, cip_weight=1.0, gir_weight=0.0, ost=False)
+    return types.SimpleNamespace(batch_size=B, expand_weight=0.5, converge_weight=0.1, cip_weight=1.0, gir_weight=gir_weight,
+                                 ost=False)
+
+
+def dls_auto_from_golden(cls, g, dev=None):
+    """A DLSAuto (oracle or HIP) set up as the reference class was when the golden was made: gir_weight and n_batch
+    (the density-estimate regulariser, dialog_models.py:3232-3236, :3311) come from the fixture."""
+    m = load_params(cls(4, 16, _dls_cfg(10, float(g["gir_weight"]))), g)
+    m.n_batch = torch.tensor(float(g["n_batch"]))
+    return m if dev is None else m.to(dev)
 
 
 def run_dls_auto_golden(module, g, T_, rtol, atol_rel):
@@ -391,13 +424,12 @@ def run_dls_auto_golden(module, g, T_, rtol, atol_rel):
             close(v.cpu(), g["post." + k], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["train", "restarted_train", "restarted_eval"])
+@pytest.mark.parametrize("tag", ["train", "restarted_train", "restarted_eval", "train_gir"])
 def test_dls_auto_oracle_matches_reference_class(tag):
     """oracle DLSAuto vs the reference's own DLS_Auto.forward (dialog_models.py:3274-3352; golden from the class itself,
     constructor deviations written in oracle/make_golden.py gen_dls_auto): the composition is pinned, not only its parts."""
     g = load_golden("dls_auto_" + tag)
-    m = load_params(R.DLSAuto(4, 16, _dls_cfg(10)), g)
-    run_dls_auto_golden(m, g, T, 2e-4, 2e-5)
+    run_dls_auto_golden(dls_auto_from_golden(R.DLSAuto, g), g, T, 2e-4, 2e-5)
 
 
 def composed_step_inputs(g, T_):

@@ -34,11 +34,10 @@ with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, tor
                             record_shapes=True, with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
-want = ("aten::add", "aten::add_", "aten::fill_", "aten::zero_", "aten::copy_", "aten::cat", "aten::mul", "aten::sum",
-        "aten::zeros", "aten::clone", "aten::contiguous", "aten::index_select", "aten::sort", "aten::neg", "aten::div")
+want = None
 count = collections.Counter()
 for e in prof.events():
-    if e.name in want and e.device_time_total > 0 and not any(c.name in want and c.device_time_total > 0 for c in e.cpu_children):
+    if e.name.startswith("aten::") and e.device_time_total > 0 and not any(c.name.startswith("aten::") and c.device_time_total > 0 for c in e.cpu_children):
         stack = [s for s in (e.stack or []) if "/pevae_amd/" in s or "bench" in s][:3]
         par = e.cpu_parent.name if e.cpu_parent is not None else "-"
         count[(e.name, str(e.input_shapes), par, " <- ".join(s.split("/pevae_amd/")[-1] for s in stack))] += 1
