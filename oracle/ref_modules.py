@@ -55,11 +55,41 @@ def kl_anneal_function(anneal_function, step, k, x0, warmup_step=0, warmup_value
 # recurrent cells (torch.nn.GRU / nn.LSTM semantics, which is what base_modules.py:42 builds)
 # ----------------------------------------------------------------------------------------
 
+EMULATE_BF16_MFMA = False     # True (full-size GPU tests): the products the HIP path runs on the bf16 matrix core -- the
+                              # recurrences' input / hidden projections and the vocabulary projection -- round BOTH
+                              # operands to bf16, forward and backward, and accumulate in fp32 like the MFMA does
+
+
+def _rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _MatmulNTbf16(torch.autograd.Function):
+    """y = a w^T with bf16-rounded operands; backward da = rb(dy) rb(w), dw = rb(dy)^T rb(a): what gemm_bf16.hip /
+    gru.hip / vocab_fused.hip compute (their dgi / dgh / P operands are stored or formed in bf16)."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        ctx.save_for_backward(a, w)
+        return _rb(a) @ _rb(w).t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, w = ctx.saved_tensors
+        dyr = _rb(dy)
+        return dyr @ _rb(w), dyr.reshape(-1, dyr.shape[-1]).t() @ _rb(a).reshape(-1, a.shape[-1])
+
+
+def mm_nt(a, w):
+    """a [.., K] x w [N, K]^T: fp32 as the reference computes it, or with the matrix core's operand rounding."""
+    return _MatmulNTbf16.apply(a, w) if EMULATE_BF16_MFMA else a @ w.t()
+
+
 def gru_cell(x_t, h, w_ih, w_hh, b_ih, b_hh):
     """One GRU step, gate order (r, z, n).  SURVEY 8(a) row a2."""
     H = h.shape[-1]
-    gi = x_t @ w_ih.t() + (b_ih if b_ih is not None else 0.0)
-    gh = h @ w_hh.t() + (b_hh if b_hh is not None else 0.0)
+    gi = mm_nt(x_t, w_ih) + (b_ih if b_ih is not None else 0.0)
+    gh = mm_nt(h, w_hh) + (b_hh if b_hh is not None else 0.0)
     r = torch.sigmoid(gi[..., :H] + gh[..., :H])
     z = torch.sigmoid(gi[..., H:2 * H] + gh[..., H:2 * H])
     n = torch.tanh(gi[..., 2 * H:] + r * gh[..., 2 * H:])
@@ -69,7 +99,7 @@ def gru_cell(x_t, h, w_ih, w_hh, b_ih, b_hh):
 def lstm_cell(x_t, h, c, w_ih, w_hh, b_ih, b_hh):
     """One LSTM step, gate order (i, f, g, o)."""
     H = h.shape[-1]
-    g = x_t @ w_ih.t() + h @ w_hh.t()
+    g = mm_nt(x_t, w_ih) + mm_nt(h, w_hh)
     if b_ih is not None:
         g = g + b_ih + b_hh
     i = torch.sigmoid(g[..., :H])
@@ -373,8 +403,8 @@ class DecoderRNN(BaseRNN):
 
     def _project(self, flat):
         if self.tie_output_embed:                                              # decoders.py:159-160
-            return flat @ self.embedding.weight.t()
-        return self.project(flat)
+            return mm_nt(flat, self.embedding.weight)
+        return mm_nt(flat, self.project.weight) + self.project.bias
 
     def forward_step(self, input_var, hidden, encoder_outputs, latent_variable=None):
         B, Lout = input_var.size(0), input_var.size(1)

@@ -15,6 +15,45 @@ def dev():
     return torch.device("cuda:0")
 
 
+# Full-size tolerances against the bf16-emulating oracle (chosen from PEVAE_TOL_REPORT=1 runs, about 3x the worst
+# parameter): what is left is accumulation order, the recurrences' fast sigmoid / tanh, and elements that round to a
+# different bf16 neighbour on the two sides.
+FULL_LOSS_RTOL = 2e-3     # losses (worst seen: < 5e-4)
+FULL_GRAD_TOL = 4e-3      # max |g - g_oracle| / max |g_oracle| per parameter (worst seen: 1.2e-3; was 8e-2 against the fp32 oracle)
+FULL_COS_TOL = 5e-5       # 1 - cosine per parameter of >= 4096 elements (worst seen: 6e-6; was 1e-2)
+
+
+class bf16_oracle(object):
+    """Run the oracle with the matrix core's operand rounding (oracle.ref_modules.EMULATE_BF16_MFMA): the full-size
+    comparisons then measure the kernels, not the bf16 format."""
+
+    def __enter__(self):
+        import oracle.ref_modules as R
+        self.R, self.prev = R, R.EMULATE_BF16_MFMA
+        R.EMULATE_BF16_MFMA = True
+
+    def __exit__(self, *exc):
+        self.R.EMULATE_BF16_MFMA = self.prev
+        return False
+
+
+def grad_report(name, g, r, worst):
+    """max |g - r| / max |r| and 1 - cos, collected for PEVAE_TOL_REPORT=1 runs (how the tolerances below were chosen)."""
+    scale = float(r.abs().max()) + 1e-9
+    err = float((g - r).abs().max()) / scale
+    cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-20)) if r.numel() >= 4096 else 1.0
+    worst.append((err, 1.0 - cos, name))
+    return err, cos
+
+
+def print_report(tag, worst):
+    import os
+    if os.environ.get("PEVAE_TOL_REPORT"):
+        worst.sort(reverse=True)
+        print("\n[%s] worst relative gradient errors:" % tag, [(round(e, 5), n) for e, _, n in worst[:6]])
+        print("[%s] worst 1 - cos:" % tag, sorted([(round(c, 7), n) for _, c, n in worst], reverse=True)[:4])
+
+
 def _pair(cfg, dev):
     from pevae_amd.dls_vae import DLSVAE
     torch.manual_seed(0)
@@ -168,18 +207,19 @@ def test_step_full_size_oracle_and_properties(dev):
 
     loss, grads = run(feed_d)
 
-    # (1) the oracle at full size; tolerances as in test_step_matches_oracle (bf16 MFMA operands, fp32 accumulate)
-    loss_r = ref(feed, eps=eps)
-    ref.valid_loss(loss_r).backward()
-    assert abs(float(loss.vae_nll.detach()) - float(loss_r.vae_nll.detach())) <= 2e-2 * abs(float(loss_r.vae_nll.detach()))
-    assert abs(float(loss.vae_rkl.detach()) - float(loss_r.vae_rkl.detach())) <= 2e-2 * abs(float(loss_r.vae_rkl.detach())) + 1e-4
+    # (1) the oracle at full size, its matrix-core products rounded to bf16 like the kernels' (forward and backward)
+    with bf16_oracle():
+        loss_r = ref(feed, eps=eps)
+        ref.valid_loss(loss_r).backward()
+    assert abs(float(loss.vae_nll.detach()) - float(loss_r.vae_nll.detach())) <= FULL_LOSS_RTOL * abs(float(loss_r.vae_nll.detach()))
+    assert abs(float(loss.vae_rkl.detach()) - float(loss_r.vae_rkl.detach())) <= FULL_LOSS_RTOL * abs(float(loss_r.vae_rkl.detach())) + 1e-4
+    worst = []
     for n, p in ref.named_parameters():
-        g, r = grads[n].cpu(), p.grad
-        scale = float(r.abs().max()) + 1e-9
-        assert float((g - r).abs().max()) <= 8e-2 * scale, (n, float((g - r).abs().max()), scale)
-        if r.numel() >= 4096:
-            cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-20))
-            assert cos > 0.99, (n, cos)
+        err, cos = grad_report(n, grads[n].cpu(), p.grad, worst)
+    print_report("yelp", worst)
+    for err, omc, n in worst:
+        assert err <= FULL_GRAD_TOL, (n, err)
+        assert omc <= FULL_COS_TOL, (n, omc)
 
     # (2) no atomics anywhere on the path: a second run reproduces every bit
     loss2, grads2 = run(feed_d)
@@ -241,18 +281,21 @@ def test_step_full_size_attention_oracle(dev):
         return loss, {n: p.grad.clone() for n, p in gpu.named_parameters()}
 
     loss, grads = run()
-    loss_r = ref(feed, eps=eps)
-    ref.valid_loss(loss_r).backward()
-    assert abs(float(loss.vae_nll.detach()) - float(loss_r.vae_nll.detach())) <= 2e-2 * abs(float(loss_r.vae_nll.detach()))
-    assert abs(float(loss.vae_rkl.detach()) - float(loss_r.vae_rkl.detach())) <= 2e-2 * abs(float(loss_r.vae_rkl.detach())) + 1e-4
+    with bf16_oracle():
+        loss_r = ref(feed, eps=eps)
+        ref.valid_loss(loss_r).backward()
+    assert abs(float(loss.vae_nll.detach()) - float(loss_r.vae_nll.detach())) <= FULL_LOSS_RTOL * abs(float(loss_r.vae_nll.detach()))
+    assert abs(float(loss.vae_rkl.detach()) - float(loss_r.vae_rkl.detach())) <= FULL_LOSS_RTOL * abs(float(loss_r.vae_rkl.detach())) + 1e-4
+    worst = []
     for n, p in ref.named_parameters():
-        g, r = grads[n].cpu(), p.grad
-        scale = float(r.abs().max()) + 1e-9
-        assert float((g - r).abs().max()) <= 8e-2 * scale + 1e-8, (n,   # query_w.bias: softmax shift invariance, exact 0
-            float((g - r).abs().max()), scale)
-        if r.numel() >= 4096 and "attention.dec_w" not in n:       # see test_step_matches_oracle
-            cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-20))
-            assert cos > 0.99, (n, cos)
+        if "query_w.bias" in n:          # softmax shift invariance: exactly zero in exact arithmetic, rounding on both sides
+            assert float(grads[n].abs().max()) <= 1e-6 + 1e-3 * float(p.grad.abs().max())
+            continue
+        grad_report(n, grads[n].cpu(), p.grad, worst)
+    print_report("attention", worst)
+    for err, omc, n in worst:
+        assert err <= FULL_GRAD_TOL, (n, err)
+        assert omc <= FULL_COS_TOL, (n, omc)
     loss2, grads2 = run()
     assert float(loss.vae_nll.detach()) == float(loss2.vae_nll.detach())
     for n in grads:
@@ -296,23 +339,25 @@ def _full_size_vs_oracle(gpu, ref, feed, feed_d, eps, eps_d, skip_cos=()):
     gpu.valid_loss(loss).backward()
     torch.cuda.synchronize()
     ops.gru_check_all()
-    loss_r = ref(feed, eps=eps)
-    ref.valid_loss(loss_r).backward()
+    with bf16_oracle():
+        loss_r = ref(feed, eps=eps)
+        ref.valid_loss(loss_r).backward()
     for key in ("vae_nll", "vae_rkl", "rating_mse"):
         if loss_r.get(key) is not None:
             a, b = float(loss[key].detach()), float(loss_r[key].detach())
-            assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, (key, a, b)
+            assert abs(a - b) <= FULL_LOSS_RTOL * abs(b) + 1e-4, (key, a, b)
     grads = {n: p.grad for n, p in gpu.named_parameters()}
+    worst = []
     for n, p in ref.named_parameters():
         if p.grad is None:
             assert grads[n] is None or not grads[n].any(), n
             continue
-        g, r = grads[n].cpu(), p.grad
-        scale = float(r.abs().max()) + 1e-9
-        assert float((g - r).abs().max()) <= 8e-2 * scale + 1e-8, (n, float((g - r).abs().max()), scale)
-        if r.numel() >= 4096 and not any(s in n for s in skip_cos):
-            cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-20))
-            assert cos > 0.99, (n, cos)
+        grad_report(n, grads[n].cpu(), p.grad, worst)
+    print_report("full", worst)
+    for err, omc, n in worst:
+        assert err <= FULL_GRAD_TOL, (n, err)
+        if not any(s in n for s in skip_cos):
+            assert omc <= FULL_COS_TOL, (n, omc)
     return loss, grads
 
 
