@@ -306,10 +306,16 @@ typedef struct pv_block_call {      /* one Block of a launch; arrays are in the 
   float* dgamma;
   float* dbeta;
 } pv_block_call;
-/* Up to PV_BLOCK_GROUP_MAX INDEPENDENT Blocks per launch (each alone fills 16 CUs at batch 256: the two pyramids' Blocks
- * of a level, or the three Blocks of a DLS_Auto level, run side by side). */
+/* Up to PV_BLOCK_GROUP_MAX INDEPENDENT Blocks per launch (the two pyramids' Blocks of a level, or the three Blocks of a
+ * DLS_Auto level, run side by side).  Forward: Blocks 256 / 512 wide are walked by clusters of 2 / 4 workgroups per
+ * 16-row slab that split every layer's columns and hand their slices to each other through `save` (bounded waits;
+ * pv_block_sync_error reports a wait that gave up).  Launches of pv_block_fwd on ONE device must not overlap each
+ * other (they share the device's hand-off counters); stream order, as every caller here uses, is enough. */
 int pv_block_fwd(const pv_block_call* calls, int n, void* stream);
 int pv_block_bwd(const pv_block_call* calls, int n, void* stream);
+/* *flag = 1 if an inter-workgroup wait of pv_block_fwd has timed out since the library was loaded (synchronises the
+ * device; tests and debugging -- a timed-out launch has produced garbage).  No counterpart in the reference. */
+int pv_block_sync_error(int* flag);
 /* One level of DLS_Auto's train branch (:3285-3311) as two elementwise launches.  Q / Pr [B][2n]: outputs of dis_layer /
  * dis_layer2 (mean | log sigma halves).  ls = mean + exp(logsigma) * eps + a2 (:3299-3300), out = lay + ls (:3310),
  * kl[0] = (ew + cw) * mean_b sum_d KL(prior || posterior) (:3305-3306; the backward gives the prior's gradient the

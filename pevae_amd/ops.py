@@ -721,10 +721,20 @@ LAST_GRU_SYNC = collections.deque(maxlen=64)
 
 
 def gru_check_all():
-    """Raise if any recent persistent-GRU launch reported a timed-out wait (synchronises the device)."""
+    """Raise if any recent persistent-GRU launch, or a Block forward's cluster hand-off, reported a timed-out wait
+    (synchronises the device)."""
     while LAST_GRU_SYNC:
         sync, NG, tag = LAST_GRU_SYNC.pop()
         gru_check_sync(sync, NG, tag)
+    block_check()
+
+
+def block_check():
+    """Raise if an inter-workgroup wait of pv_block_fwd has given up (synchronises the device)."""
+    flag = C.c_int(0)
+    _lib.call("pv_block_sync_error", C.byref(flag))
+    if flag.value:
+        raise _lib.PevaeHipError("pv_block_fwd: a bounded inter-workgroup wait timed out")
 
 
 def gru_check_sync(sync, NG, what):

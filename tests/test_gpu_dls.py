@@ -47,7 +47,8 @@ def test_block_golden(dev):
 
 
 @pytest.mark.parametrize("M,din,dout,mid,sinks", [(37, 48, 32, 96, False), (256, 128, 64, 64, True), (16, 16, 16, 16, False),
-                                                  (70, 512, 256, 256, True)])
+                                                  (70, 512, 256, 256, True), (256, 256, 512, 512, False),
+                                                  (250, 192, 256, 256, True)])
 def test_block_fused_matches_unfused(dev, M, din, dout, mid, sinks):
     """The one-launch Block kernels (pv_block_fwd / pv_block_bwd) against the per-linear path that the reference goldens
     pin (test_block_golden), on ragged row counts, with gradients returned and accumulated into existing .grad."""
@@ -79,6 +80,7 @@ def test_block_fused_matches_unfused(dev, M, din, dout, mid, sinks):
         close(p.grad, q.grad, rtol=1e-4, atol=1e-4 * float(q.grad.abs().max()) + 1e-6)
     for (k, u), (_, v) in zip(blk_a.named_buffers(), blk_b.named_buffers()):
         close(u, v, rtol=1e-5, atol=1e-6)
+    ops.block_check()          # no hand-off between the workgroups of a slab (512 / 256-wide Blocks) gave up
 
 
 @pytest.mark.parametrize("name", ["dlsrec", "dlspri"])

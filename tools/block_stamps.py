@@ -15,7 +15,7 @@ def main():
     lib = _lib.load()
     buf = (ctypes.c_ulonglong * 64)()
     names_f = ["start", "x+gelu|bar", "L0", "bar", "L1", "bar", "L2", "bar", "L3", "bar", "L4(end)", "-", "LN|bar"]
-    for din, dout, mid in ((512, 256, 256), (64, 32, 32)):
+    for din, dout, mid in ((512, 256, 256), (256, 128, 128), (256, 512, 512), (64, 32, 32)):
         blk = L.Block(din, dout, mid).to(dev).train()
         x = torch.randn(256, din, device=dev)
         w = torch.randn(256, dout, device=dev)
