@@ -313,6 +313,12 @@ typedef struct pv_block_call {      /* one Block of a launch; arrays are in the 
  * other (they share the device's hand-off counters); stream order, as every caller here uses, is enough. */
 int pv_block_fwd(const pv_block_call* calls, int n, void* stream);
 int pv_block_bwd(const pv_block_call* calls, int n, void* stream);
+/* pv_block_bwd in two launches: phase 1 = the dx chain (block_bwd_dx_kernel: dL/dx, dY, the per-workgroup partials),
+ * phase 2 = everything nothing downstream waits for (the weight-gradient GEMMs and the bias / LayerNorm parameter
+ * reductions, which read what phase 1 wrote); phase 3 = both = pv_block_bwd.  A caller may issue phase 2 later and on
+ * another stream, ordered after phase 1, so that it runs beside the next Block's dx chain.  No counterpart in the
+ * reference (autograd orders its per-linear backward nodes itself). */
+int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* stream);
 /* *flag = 1 if an inter-workgroup wait of pv_block_fwd has timed out since the library was loaded (synchronises the
  * device; tests and debugging -- a timed-out launch has produced garbage).  No counterpart in the reference. */
 int pv_block_sync_error(int* flag);

@@ -958,8 +958,11 @@ int pv_block_sync_error(int* flag) {
   return PV_OK;
 }
 
-int pv_block_bwd(const pv_block_call* calls, int n, void* stream) {
+int pv_block_bwd(const pv_block_call* calls, int n, void* stream) { return pv_block_bwd_phase(calls, n, 3, stream); }
+
+int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* stream) {
   PV_REQUIRE(calls && n >= 1 && n <= PV_BLOCK_GROUP_MAX, "pv_block_bwd: 1..%d blocks per launch", PV_BLOCK_GROUP_MAX);
+  PV_REQUIRE(phase >= 1 && phase <= 3, "pv_block_bwd_phase: phase is a mask of 1 (dx chain) and 2 (parameter gradients)");
   hipStream_t st = (hipStream_t)stream;
   BlockBwdGroup g;
   ParamReduceGroup pr;
@@ -1016,11 +1019,14 @@ int pv_block_bwd(const pv_block_call* calls, int n, void* stream) {
     g.a[b] = g.a[0];
     pr.r[b] = pr.r[0];
   }
-  static size_t seen = 0;
-  int rc = set_lds(block_bwd_dx_kernel, smem, &seen);
-  if (rc) return rc;
-  hipLaunchKernelGGL(block_bwd_dx_kernel, dim3(nwg_max, n), dim3(NT), smem, st, g);
-  PV_LAUNCH_CHECK("block_bwd_dx_kernel");
+  if (phase & 1) {
+    static size_t seen = 0;
+    int rc = set_lds(block_bwd_dx_kernel, smem, &seen);
+    if (rc) return rc;
+    hipLaunchKernelGGL(block_bwd_dx_kernel, dim3(nwg_max, n), dim3(NT), smem, st, g);
+    PV_LAUNCH_CHECK("block_bwd_dx_kernel");
+  }
+  if (!(phase & 2)) return PV_OK;
   // the 5 n weight-gradient GEMMs in one launch, the bias / LayerNorm-parameter reductions riding on it
   ColReduceJob jobs[PV_BLOCK_GROUP_MAX];
   for (int b = 0; b < n; ++b) {

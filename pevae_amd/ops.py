@@ -153,6 +153,7 @@ class on_side(object):
 
 
 SIDE_DX = os.environ.get("PEVAE_SIDE_DX", "1") == "1"
+SIDE_BLOCK_WGRAD = os.environ.get("PEVAE_SIDE_BLOCK_WGRAD", "1") == "1"
 _DEFERRED = []           # (event on the stream that queued it, closure): side work whose launch is postponed
 
 
@@ -1562,7 +1563,7 @@ class BlockGroupFn(torch.autograd.Function):
         dev = st[0].device
         live = [b for b in range(n) if douts[b] is not None]
         calls = (_lib.BlockCall * max(len(live), 1))()
-        keep, results = [], {}
+        keep, results, all_fused = [], {}, True
         for k, b in enumerate(live):
             t = st[b * per:(b + 1) * per]
             x2, out, save, mean, rstd, g = t[:6]
@@ -1577,6 +1578,7 @@ class BlockGroupFn(torch.autograd.Function):
             params = list(p_W) + list(p_bias) + [p_g, p_b]
             sinks = [grad_sink(p, tuple(p.shape)) for p in params]
             fused = all(s is not None for s in sinks)      # all-or-nothing: one accumulate flag per Block
+            all_fused = all_fused and fused
             grads = sinks if fused else [torch.empty(tuple(p.shape), dtype=torch.float32, device=dev) for p in params]
             c = calls[k]
             c.M, c.Din, c.mid, c.Dout, c.ln_eps, c.accumulate = M, din, mid, do, 0.0, 1 if fused else 0
@@ -1591,7 +1593,14 @@ class BlockGroupFn(torch.autograd.Function):
             keep += [d2, dY, cpart, ppart]
             results[b] = (dx.view(xshape), None if fused else grads)
         if live:
-            _lib.call("pv_block_bwd", C.byref(calls), len(live), _stream())
+            if ASYNC_WGRAD and all_fused and SIDE_BLOCK_WGRAD:
+                # the dx chain now; the parameter gradients (full-chip GEMMs into the gradient sinks, nothing downstream reads
+                # them) later on the side stream, beside the next Blocks' dx chains
+                _lib.call("pv_block_bwd_phase", C.byref(calls), len(live), 1, _stream())
+                nlive, held = len(live), (calls, keep, list(st), [douts[b] for b in live])
+                defer_side_work(lambda: _lib.call("pv_block_bwd_phase", C.byref(held[0]), nlive, 2, _stream()), keep=held)
+            else:
+                _lib.call("pv_block_bwd", C.byref(calls), len(live), _stream())
         ret = [None]
         for b in range(n):
             if b not in results:
