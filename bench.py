@@ -105,7 +105,11 @@ def main():
     torch.manual_seed(0)                                    # identical initial weights on every rank
     model = DLSVAE(cfg).to(dev)
     model.train()
-    model.split_backward = True
+    # N > 1: the backward pass is cut after the vocabulary projection so that its gradient's all-reduce can start early
+    # (north star item 5).  N = 1: nothing is exchanged, so the backward pass stays whole and the vocabulary projection's
+    # weight gradient leaves the critical path instead (ops.defer_after_recurrence: it runs beside the latent stack).
+    split = world > 1 and bool(args.overlap)
+    model.split_backward = split
     # the flat gradient holds the SUM over ranks; 1/world is applied inside the guard / Adam kernels
     opt = FlatAdam(model.parameters(), lr=cfg.init_lr, max_norm=cfg.grad_clip, warmup_steps=cfg.warmup_steps,
                    grad_scale=1.0 / world)
@@ -147,14 +151,18 @@ def main():
     n_params = sum(p.numel() for p in model.parameters())
     state = {}
 
-    def part_a():                                   # zero_grad, forward, vocabulary backward
+    def part_a():                                   # zero_grad, forward, vocabulary backward (N = 1: the whole backward)
         opt.zero_grad()
         state["loss"] = loss = model(feed)
-        model.backward_vocab(loss)
+        if split:
+            model.backward_vocab(loss)
+        else:
+            model.backward(0, loss)
         return loss
 
     def part_b():                                   # the rest of the backward pass
-        model.backward_rest(state["loss"])
+        if split:
+            model.backward_rest(state["loss"])
 
     def fwd_bwd():
         loss = part_a()
@@ -186,8 +194,9 @@ def main():
         ga, gb, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga, stream=side):
             static_loss = part_a()
-        with torch.cuda.graph(gb, pool=ga.pool(), stream=side):
-            part_b()
+        if split:
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=side):
+                part_b()
         with torch.cuda.graph(g2, pool=ga.pool(), stream=side):
             opt.step()
         ops.LAST_GRU_SYNC.clear()
@@ -196,7 +205,8 @@ def main():
             select(i)
             ga.replay()
             reducer.start()
-            gb.replay()
+            if split:
+                gb.replay()
             reducer.finish(sparse_ids)
             g2.replay()
             return static_loss

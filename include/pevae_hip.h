@@ -107,6 +107,13 @@ size_t pv_vocab_fused_dw_ws_bytes(int V);
 int pv_vocab_fused_dw(const void* h, int ldh, const void* W, int ldw, const float* bias, const int* target32, const float* lse,
                       const float* gscale, int T, int V, int H, float inv_temp, void* workspace, float* dW, int lddw,
                       int accumulate, float* dbias, const int* live_rows, void* stream);
+/* pv_vocab_fused_dw on `wgs` workgroups instead of one per CU (0 = one per CU; the stream-K split takes any count) and
+ * with dbias accumulated too (accumulate_bias != 0).  Nothing downstream of the vocabulary projection's backward reads dW
+ * or dbias before the optimizer, so a caller may run this launch on a second stream beside the latent stack's backward --
+ * a chain of small kernels -- and leave that chain the CUs it needs.  No counterpart in the reference. */
+int pv_vocab_fused_dw_wgs(const void* h, int ldh, const void* W, int ldw, const float* bias, const int* target32, const float* lse,
+                          const float* gscale, int T, int V, int H, float inv_temp, void* workspace, float* dW, int lddw,
+                          int accumulate, float* dbias, int accumulate_bias, const int* live_rows, int wgs, void* stream);
 /* pv_vocab_gather with the targets also as int32; perm == NULL: identity order (h_c / target_c may be NULL). */
 int pv_vocab_gather32(const void* h, int ldh, const int64_t* target, const int64_t* perm, int T, int H, void* h_c, int ldc,
                       int64_t* target_c, int* target32, void* stream);

@@ -516,7 +516,7 @@ struct DwReduceArgs {
   const float* z_slab;
   const float* b_slab;
   const int* live;
-  int T, V, max_seg, G, lddw, accumulate;
+  int T, V, max_seg, G, lddw, accumulate, accumulate_bias;
   float* dW;            // [V][lddw]
   float* dbias;         // [V]
 };
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void vocab_dw_reduce_kernel(DwReduceArgs a) {
         const long sl = slab_of(w);
         if (sl >= 0) acc += a.b_slab[sl * UNIT + vl];
       }
-      a.dbias[v] = acc;
+      a.dbias[v] = a.accumulate_bias ? a.dbias[v] + acc : acc;
     }
   }
 }
@@ -654,6 +654,13 @@ size_t pv_vocab_fused_dw_ws_bytes(int V) {
 int pv_vocab_fused_dw(const void* h, int ldh, const void* W, int ldw, const float* bias, const int* target32, const float* lse,
                       const float* gscale, int T, int V, int H, float inv_temp, void* workspace, float* dW, int lddw,
                       int accumulate, float* dbias, const int* live_rows, void* stream) {
+  return pv_vocab_fused_dw_wgs(h, ldh, W, ldw, bias, target32, lse, gscale, T, V, H, inv_temp, workspace, dW, lddw, accumulate,
+                               dbias, 0, live_rows, 0, stream);
+}
+
+int pv_vocab_fused_dw_wgs(const void* h, int ldh, const void* W, int ldw, const float* bias, const int* target32, const float* lse,
+                          const float* gscale, int T, int V, int H, float inv_temp, void* workspace, float* dW, int lddw,
+                          int accumulate, float* dbias, int accumulate_bias, const int* live_rows, int wgs, void* stream) {
   int rc = check_common(h, ldh, W, ldw, T, V, H, "pv_vocab_fused_dw");
   if (rc) return rc;
   PV_REQUIRE(bias && target32 && lse && gscale && workspace && dW && dbias, "pv_vocab_fused_dw: null argument");
@@ -665,14 +672,17 @@ int pv_vocab_fused_dw(const void* h, int ldh, const void* W, int ldw, const floa
     if (rc) return rc;
     attr = true;
   }
-  const int G = grid_wgs(), ms = max_seg_dw(V, G);
+  PV_REQUIRE(wgs >= 0, "pv_vocab_fused_dw_wgs: wgs = %d", wgs);
+  const int G = wgs > 0 && wgs < grid_wgs() ? wgs : grid_wgs(), ms = max_seg_dw(V, G);
+  PV_REQUIRE((size_t)G * ms * ((size_t)UNIT * HD + UNIT) * sizeof(float) <= pv_vocab_fused_dw_ws_bytes(V),
+             "pv_vocab_fused_dw_wgs: %d workgroups need more than pv_vocab_fused_dw_ws_bytes", G);
   float* z_slab = (float*)workspace;
   float* b_slab = z_slab + (size_t)G * ms * UNIT * HD;
   hipStream_t st = (hipStream_t)stream;
   DwArgs a{(const bf16_t*)h, (const bf16_t*)W, bias, target32, lse, gscale, live_rows, T, V, ldh, ldw, ms, inv_temp, z_slab, b_slab};
   hipLaunchKernelGGL(vocab_dw_kernel, dim3(G), dim3(256), SMEM_BYTES, st, a);
   PV_LAUNCH_CHECK("vocab_dw_kernel");
-  DwReduceArgs r{z_slab, b_slab, live_rows, T, V, ms, G, lddw, accumulate, dW, dbias};
+  DwReduceArgs r{z_slab, b_slab, live_rows, T, V, ms, G, lddw, accumulate, accumulate_bias, dW, dbias};
   hipLaunchKernelGGL(vocab_dw_reduce_kernel, dim3(cdiv(V, UNIT), UNIT / 16), dim3(256), 0, st, r);
   PV_LAUNCH_CHECK("vocab_dw_reduce_kernel");
   return PV_OK;

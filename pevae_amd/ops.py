@@ -154,6 +154,11 @@ class on_side(object):
 
 SIDE_DX = os.environ.get("PEVAE_SIDE_DX", "1") == "1"
 SIDE_BLOCK_WGRAD = os.environ.get("PEVAE_SIDE_BLOCK_WGRAD", "1") == "1"
+# > 0: the vocabulary dW runs on that many workgroups on a second stream beside the latent stack's backward.  Measured at
+# the Yelp shape: 128 / 160 / 192 workgroups -> 3.94 / 3.83 / 3.77 ms per step against 3.68 with the kernel left in front of
+# the decoder recurrence (a workgroup of it owns a whole CU, and the chain of small kernels it runs beside then waits for
+# CUs): off by default.
+VOCAB_DW_SIDE_WGS = int(os.environ.get("PEVAE_VOCAB_DW_SIDE_WGS", "0"))
 _DEFERRED = []           # (event on the stream that queued it, closure): side work whose launch is postponed
 
 
@@ -171,8 +176,43 @@ def defer_side_work(fn, keep=()):
     _DEFERRED.append((ev, fn, keep))
 
 
+_AFTER_RNN = []          # closures for the SECOND side stream, launched right after the next persistent recurrence kernel
+
+
+def defer_after_recurrence(fn, keep=()):
+    """Run fn() on a second side stream once the next persistent GRU / LSTM backward kernel has been queued (ordered after
+    that kernel, which needs every CU): the vocabulary projection's weight gradient -- a long full-chip kernel nothing
+    reads before the optimizer -- then runs beside the latent stack's backward instead of in front of the recurrence.
+    Without ASYNC_WGRAD it runs at once."""
+    if not ASYNC_WGRAD:
+        fn()
+        return
+    _AFTER_RNN.append((fn, keep))
+
+
+def _second_stream(st):
+    if "stream2" not in st:
+        st["stream2"] = torch.cuda.Stream(device=st["stream"].device)
+    return st["stream2"]
+
+
+def launch_after_recurrence():
+    """Called right after a persistent recurrence kernel has been queued on the current stream."""
+    if not _AFTER_RNN:
+        return
+    cur, st = _side_state()
+    s2 = _second_stream(st)
+    s2.wait_stream(cur)
+    st["busy2"] = True
+    while _AFTER_RNN:
+        fn, keep = _AFTER_RNN.pop(0)
+        st["keep"].append(keep)
+        with torch.cuda.stream(s2):
+            fn()
+
+
 def join_side_work():
-    """Launch postponed side work, then make the current stream wait for the side stream (before a persistent kernel
+    """Launch postponed side work, then make the current stream wait for the side streams (before a persistent kernel
     that needs every CU, and at the end of the backward pass)."""
     if not _SIDE:
         return
@@ -186,6 +226,11 @@ def join_side_work():
         with torch.cuda.stream(side):
             fn()
     cur.wait_stream(side)
+    if _AFTER_RNN:                     # no recurrence came: run what waited for one now
+        launch_after_recurrence()
+    if st.get("busy2"):
+        cur.wait_stream(st["stream2"])
+        st["busy2"] = False
     st["keep"] = []
 
 
@@ -589,11 +634,25 @@ class VocabNLL(torch.autograd.Function):
         sink = grad_sink(weight, (V, H))
         dW = sink if sink is not None else torch.empty((V, H), dtype=torch.float32, device=dev)
         dbias = torch.empty(V, dtype=torch.float32, device=dev)
-        ws = workspace("vocab_fused_dw", _lib.load().pv_vocab_fused_dw_ws_bytes(V), torch.uint8, dev)
-        with timed("vocab_fused_dw"):
-            _lib.call("pv_vocab_fused_dw", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(t32), _p(lse), _p(gscale), T, V, Hp,
-                      inv_temp, _p(ws), _p(dW), H, 1 if sink is not None else 0, _p(dbias), _p(count), _stream())
-        return dH, (None if sink is not None else dW), dbias
+        sink_b = grad_sink(_bias, (V,)) if sink is not None else None
+        if sink_b is not None:
+            dbias = sink_b
+        ws_bytes = _lib.load().pv_vocab_fused_dw_ws_bytes(V)
+
+        def launch(wgs=0):
+            ws = workspace("vocab_fused_dw", ws_bytes, torch.uint8, dev)         # (of the stream it runs on)
+            with timed("vocab_fused_dw"):
+                _lib.call("pv_vocab_fused_dw_wgs", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(t32), _p(lse), _p(gscale), T, V, Hp,
+                          inv_temp, _p(ws), _p(dW), H, 1 if sink is not None else 0, _p(dbias), 1 if sink_b is not None else 0,
+                          _p(count), wgs, _stream())
+
+        if sink_b is not None and ASYNC_WGRAD and VOCAB_DW_SIDE_WGS > 0:
+            # both gradients sink into the flat buffer and nothing downstream reads them: off the critical path, on fewer
+            # workgroups than CUs so that the latent stack's backward keeps the CUs it needs
+            defer_after_recurrence(lambda: launch(VOCAB_DW_SIDE_WGS), keep=(h_bf, w_bf, bias, t32, lse, gscale, count, dW, dbias))
+        else:
+            launch()
+        return dH, (None if sink is not None else dW), (None if sink_b is not None else dbias)
 
     @staticmethod
     def backward(ctx, dnll, _dlse):
@@ -809,6 +868,7 @@ class GRULayer(torch.autograd.Function):
                       0 if dout is None else dout.stride(1), _p(dhn_c), _p(gsave), _p(hall), _p(whhT), L, B, H, 0,
                       _p(dgi), _p(dgh), _p(dh0), _p(dbp), _p(db_ih), _p(db_hh), _p(sync), GRU_MAX_WGS, _stream())
         LAST_GRU_SYNC.append((sync, NG, "pv_gru_bwd"))
+        launch_after_recurrence()
         Tt = L * Bpad
         Tp = round_up(Tt, 64)
         p_ih, p_hh = ctx.params

@@ -173,6 +173,46 @@ def test_vocab_fused_kernels(dev, T, V, temp, case):
         assert relerr(dw, Wd.grad) < 2e-2 and relerr(dh, hd.grad) < 2e-2
 
 
+def test_vocab_fused_dw_on_fewer_workgroups_into_sinks(dev):
+    """pv_vocab_fused_dw_wgs: the stream-K split of the weight-gradient kernel takes any workgroup count, and dW / dbias
+    accumulate into existing gradients (the flat buffer's views).  100 workgroups + accumulation against one-per-CU +
+    returned gradients: the same numbers up to the order of the segment folds; and the deferred launch
+    (ops.defer_after_recurrence, here flushed by join_side_work since no recurrence follows) leaves the same bits as the
+    immediate one."""
+    from pevae_amd import ops
+    T, V, H = 700, 3001, 512
+    g = torch.Generator().manual_seed(5)
+    hid = (torch.randn(T, H, generator=g) * 0.5).to(dev)
+    W0 = (torch.randn(V, H, generator=g) * 0.05).to(dev)
+    b0 = (torch.randn(V, generator=g) * 0.1).to(dev)
+    tgt = torch.randint(1, V, (T,), generator=g)
+    tgt[::4] = 0
+    tgt = tgt.to(dev)
+
+    def run(sinks, wgs, deferred):
+        W, b = torch.nn.Parameter(W0.clone()), torch.nn.Parameter(b0.clone())
+        if sinks:
+            W.grad, b.grad = torch.full_like(W, 0.5), torch.full_like(b, -0.25)
+        hd = hid.clone().requires_grad_()
+        prev = ops.VOCAB_DW_SIDE_WGS, ops.ASYNC_WGRAD
+        ops.VOCAB_DW_SIDE_WGS, ops.ASYNC_WGRAD = wgs, deferred
+        try:
+            nll, _ = ops.VocabNLL.apply(hd, W, b, tgt, 1.0, 0, None, None)
+            nll.sum().backward()
+        finally:
+            ops.VOCAB_DW_SIDE_WGS, ops.ASYNC_WGRAD = prev
+            ops.join_side_work()
+        torch.cuda.synchronize()
+        return W.grad.clone(), b.grad.clone(), hd.grad.clone()
+
+    dw_a, db_a, dh_a = run(False, 0, False)
+    dw_b, db_b, dh_b = run(True, 100, True)
+    assert torch.equal(dh_a, dh_b)
+    assert relerr(dw_b - 0.5, dw_a) < 1e-5 and relerr(db_b + 0.25, db_a) < 1e-5
+    dw_c, db_c, _ = run(True, 100, True)
+    assert torch.equal(dw_b, dw_c) and torch.equal(db_b, db_c)
+
+
 def gru_ref(x, h0, w_ih, w_hh, b_ih, b_hh, emulate_bf16):
     """oracle GRU (R.gru_cell arithmetic) with optional bf16 rounding of the MFMA operands (straight-through)."""
     def q(t):
