@@ -183,6 +183,14 @@ class DLSAuto(nn.Module):
         else:
             rkl = scaled(ops.cons_loss(output, rec_output))
         last_sample = last_t = None
+        if noise is None and not restarted and not getattr(cfg, "ost", False):
+            # the uniform draws of every level (:3206-3207) in one launch
+            a2s = [act2[-i - 1] for i in range(len(self.layers))]
+            flat = torch.rand(sum(a.numel() for a in a2s), device=output.device, dtype=output.dtype)
+            noise, at = [], 0
+            for a in a2s:
+                noise.append(flat[at:at + a.numel()].view(a.shape))
+                at += a.numel()
         for i, (layer, dis, dis2) in enumerate(zip(self.layers, self.dis_layers, self.dis_layers2)):
             a1, a2 = act1[-i - 1], act2[-i - 1]
             train_branch = not restarted and not getattr(cfg, "ost", False)

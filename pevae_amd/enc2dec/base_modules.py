@@ -11,6 +11,16 @@ from .. import ops
 PAD, EOS = "<pad>", "</s>"      # models/dataset/corpora.py constants used by base_modules.py:10-11
 
 
+def _pick(state, i):
+    """state[i] of a [layers * dirs, B, H] state; a view without a select node (whose backward is a zero fill + a copy)
+    when there is only one."""
+    return state.squeeze(0) if state.shape[0] == 1 else state[i]
+
+
+def _stack(finals):
+    return finals[0].unsqueeze(0) if len(finals) == 1 else torch.stack(finals, dim=0)
+
+
 class RNNWeights(nn.Module):
     """Parameters named and initialised like torch.nn.GRU / nn.LSTM (`weight_ih_l0`, `..._reverse`), because
     reference checkpoints carry `rnn.weight_ih_l0` ... (base_modules.py:42)."""
@@ -72,7 +82,7 @@ class RNNWeights(nn.Module):
                     out, hn, cn, hs = ops.LSTMLayer.apply(xin, h0, c0, w_ih, w_hh, b_ih, b_hh, save, lens)
                     cfinals.append(cn)
                 else:
-                    h0 = None if state is None else state[layer * ndir + d]
+                    h0 = None if state is None else _pick(state, layer * ndir + d)
                     out, hn, hs = ops.GRULayer.apply(xin, h0, w_ih, w_hh, b_ih, b_hh, save, lens,
                                                      x_side and layer == 0 and d == 0 and lengths is None)
                 if mask is not None:
@@ -88,8 +98,8 @@ class RNNWeights(nn.Module):
                 x = self.between_layers(x)
                 hseq = None
         if lstm:
-            return x, (torch.stack(finals, dim=0), torch.stack(cfinals, dim=0)), hseq
-        return x, torch.stack(finals, dim=0), hseq
+            return x, (_stack(finals), _stack(cfinals)), hseq
+        return x, _stack(finals), hseq
 
 
 class BaseRNN(nn.Module):

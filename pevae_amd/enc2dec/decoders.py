@@ -148,6 +148,12 @@ class DeferredLogProbs(object):
         return func(*args, **kwargs)
 
 
+def _repeat_layers(state, n_layers):
+    """init_state.repeat(n_layers, 1, 1) (decoders.py:226-232); for one layer that is the tensor itself -- no copy forward,
+    no sum backward."""
+    return state if n_layers == 1 else state.repeat(n_layers, 1, 1)
+
+
 class DecoderRNN(BaseRNN):
     """decoders.py:121-337.  Deviations from the reference, both needed to make documented features usable:
     (1) `Attention` IS built when use_attention=True (the reference forces it off at decoders.py:154 yet keeps
@@ -251,9 +257,9 @@ class DecoderRNN(BaseRNN):
         elif init_state is None:
             decoder_hidden = None
         elif lstm:
-            decoder_hidden = tuple(s.repeat(self.n_layers, 1, 1) for s in init_state)
+            decoder_hidden = tuple(_repeat_layers(s, self.n_layers) for s in init_state)
         else:
-            decoder_hidden = init_state.repeat(self.n_layers, 1, 1)
+            decoder_hidden = _repeat_layers(init_state, self.n_layers)
 
         sequence_symbols, back_pointers = [], []
         lengths = np.array([self.max_length] * batch_size * beam_size)
