@@ -46,8 +46,9 @@ class RNNWeights(nn.Module):
         tail = "_l{}{}".format(layer, "_reverse" if direction else "")
         return [getattr(self, n + tail) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
 
-    def forward(self, x, state=None, lengths=None, x_side=False):
-        """x_side: x was produced under ops.on_side() (see ops.GRULayer).
+    def forward(self, x, state=None, lengths=None, x_side=False, dx_consumer=None):
+        """x_side: x was produced under ops.on_side(); dx_consumer: x is a leaf value whose gradient goes to this closure
+        (ops.embed_dropout_leaf) -- single-layer unidirectional GRU only (see ops.GRULayer).
         x [B,L,in] -> (out [B,L,H*dirs], h_n [layers*dirs,B,H] (LSTM: (h_n, c_n)), hseq_bf16 of the last layer or None).
         lengths (list / tensor [B]): pack_padded_sequence semantics (encoders.py:55-65): a row's state stops at its
         length, outputs past it are zero and the time axis is cut to max(lengths).  The reverse direction of a
@@ -55,6 +56,7 @@ class RNNWeights(nn.Module):
         place (one gather), which turns it into the forward problem with the same lengths."""
         lstm = self.cell == "lstm"
         ndir = 2 if self.bidirectional else 1
+        assert dx_consumer is None or (not lstm and ndir == 1 and self.num_layers == 1 and lengths is None)
         lens = mask = None
         rev_idx = None
         if lengths is not None:
@@ -84,7 +86,8 @@ class RNNWeights(nn.Module):
                 else:
                     h0 = None if state is None else _pick(state, layer * ndir + d)
                     out, hn, hs = ops.GRULayer.apply(xin, h0, w_ih, w_hh, b_ih, b_hh, save, lens,
-                                                     x_side and layer == 0 and d == 0 and lengths is None)
+                                                     x_side and layer == 0 and d == 0 and lengths is None,
+                                                     dx_consumer if layer == 0 and d == 0 else None)
                 if mask is not None:
                     out, hs = out * mask, None            # zero rows past each length (pad_packed_sequence)
                 if d and rev_idx is not None:

@@ -201,13 +201,23 @@ class DecoderRNN(BaseRNN):
         # the teacher-forced input embedding on the side stream: its backward (a sort and a segmented sum nobody waits
         # for) then runs beside the latent stack's backward instead of in front of it
         side = latent_variable is None and input_var.size(1) > 1 and torch.is_grad_enabled() and input_var.is_cuda
-        with ops.on_side(side):
-            embedded = ops.embedding(self.embedding.weight, input_var, self.embedding.padding_idx)
-            embedded = self.input_dropout(embedded)
-        if latent_variable is not None:
-            tiled = latent_variable.unsqueeze(1).repeat(1, embedded.size(1), 1)
-            embedded = torch.cat([embedded, tiled], dim=-1)
-        output, hidden, hseq = self.rnn(embedded, hidden, x_side=side)
+        leaf = None
+        if (side and ops.LEAF_DECODER_INPUT and self.rnn.cell == "gru" and self.rnn.num_layers == 1
+                and not self.rnn.bidirectional):
+            # with a gradient sink on the table: no autograd nodes for the input at all, its gradient is taken to the table
+            # inside the recurrence's postponed side-stream work
+            leaf = ops.embed_dropout_leaf(self.embedding.weight, input_var, self.embedding.padding_idx, self.input_dropout)
+        if leaf is not None:
+            embedded, consumer = leaf
+            output, hidden, hseq = self.rnn(embedded, hidden, dx_consumer=consumer)
+        else:
+            with ops.on_side(side):
+                embedded = ops.embedding(self.embedding.weight, input_var, self.embedding.padding_idx)
+                embedded = self.input_dropout(embedded)
+            if latent_variable is not None:
+                tiled = latent_variable.unsqueeze(1).repeat(1, embedded.size(1), 1)
+                embedded = torch.cat([embedded, tiled], dim=-1)
+            output, hidden, hseq = self.rnn(embedded, hidden, x_side=side)
         attn = None
         if self.use_attention and encoder_outputs is not None:
             output, attn = self.attention(output, encoder_outputs)

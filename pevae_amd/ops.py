@@ -153,6 +153,7 @@ class on_side(object):
 
 
 SIDE_DX = os.environ.get("PEVAE_SIDE_DX", "1") == "1"
+LEAF_DECODER_INPUT = os.environ.get("PEVAE_LEAF_DECODER_INPUT", "1") == "1"
 SIDE_BLOCK_WGRAD = os.environ.get("PEVAE_SIDE_BLOCK_WGRAD", "1") == "1"
 # > 0: the vocabulary dW runs on that many workgroups on a second stream beside the latent stack's backward.  Measured at
 # the Yelp shape: 128 / 160 / 192 workgroups -> 3.94 / 3.83 / 3.77 ms per step against 3.68 with the kernel left in front of
@@ -810,12 +811,13 @@ class GRULayer(torch.autograd.Function):
     hseq bf16 [(L+1)*Bpad, Hk] = every state in time-major order, reusable as a GEMM operand)."""
 
     @staticmethod
-    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, save, lengths=None, x_side=False):
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, save, lengths=None, x_side=False, dx_consumer=None):
         _need_cuda(x, w_ih, w_hh, b_ih, b_hh, h0, lengths)
         B, L, E = x.shape
         H = w_hh.shape[1]
         dev = x.device
         ctx.x_side = bool(x_side)           # x was produced under on_side(): its gradient's consumers run on the side stream
+        ctx.dx_consumer = dx_consumer       # x is a leaf value (embed_dropout_leaf): this closure takes dL/dx
         Hk, K3, Bpad, NG = gru_geometry(B, H)
         Ep = round_up(E, 64)
         x_bf = cast_pack(x, L, B, Bpad, E, x.stride(1), x.stride(0), x.stride(2), Ep)
@@ -874,11 +876,20 @@ class GRULayer(torch.autograd.Function):
         p_ih, p_hh = ctx.params
         s_ih, s_hh = grad_sink(p_ih, (3 * H, E)), grad_sink(p_hh, (3 * H, H))
         sinks = s_ih is not None and s_hh is not None
-        # dx = dgi W_ih  (time-major rows), then back to [B,L,E]; off the critical path when its consumers are (x_side)
-        with side_work(sinks and ctx.x_side and SIDE_DX, keep=(dgi,)):
+        # dx = dgi W_ih  (time-major rows), then back to [B,L,E]; off the critical path when its consumers are (x_side),
+        # or handed to the closure of a leaf input inside a postponed launch (dx_consumer)
+        def input_grad():
             wihT = transpose_to_bf16(w_ih.contiguous(), 3 * H, E, E, K3)
             dx_tm = gemm_nt(dgi, K3, wihT, K3, Tt, E, K3)
-        dx = dx_tm.view(L, Bpad, E)[:, :B].transpose(0, 1)
+            return dx_tm.view(L, Bpad, E)[:, :B].transpose(0, 1)
+
+        if ctx.dx_consumer is not None:
+            consumer = ctx.dx_consumer
+            defer_side_work(lambda: consumer(input_grad()), keep=(dgi,))
+            dx = None
+        else:
+            with side_work(sinks and ctx.x_side and SIDE_DX, keep=(dgi,)):
+                dx = input_grad()
         # dW_ih = dgi^T x ; dW_hh = dgh^T h_prev   (K = all time-major rows).  Nothing downstream reads them before the
         # optimizer: with gradient sinks they run beside whatever the backward pass does next (the latent stack's chain of
         # small kernels, the embedding gradients)
@@ -896,7 +907,7 @@ class GRULayer(torch.autograd.Function):
             dw_ih = dw_hh = None
         else:
             dw_ih, dw_hh = wgrads()
-        return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None, None, None
+        return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None, None, None, None
 
 
 class LSTMLayer(torch.autograd.Function):
@@ -1007,19 +1018,64 @@ class EmbeddingLookup(torch.autograd.Function):
     def backward(ctx, dout):
         (ids_c,) = ctx.saved_tensors
         rows, D, pad = ctx.meta
-        n = ids_c.numel()
-        dev = dout.device
         sink = grad_sink(ctx.param, (rows, D))
-        dw = sink if sink is not None else torch.empty((rows, D), dtype=torch.float32, device=dev)
-        nbytes = _lib.load().pv_embedding_bwd_ws_bytes(max(n, 1), D)
-        ws = workspace("emb_bwd", nbytes, torch.uint8, dev)
-        if dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= D and dout.stride(0) % 4 == 0:
-            g, ldg = dout, dout.stride(0)         # a column slice of a wider gradient (torch.cat backward): no copy
-        else:
-            g, ldg = dout.contiguous().view(-1, D), D
-        _lib.call("pv_embedding_bwd", _p(g), ldg, _p(ids_c), n, max(n, 1), max(n, 1), 0, 1, rows, D, pad,
-                  1 if sink is not None else 0, _p(dw), _p(ws), nbytes, _stream())
+        dw = embedding_backward(dout, ids_c, rows, D, pad, sink)
         return (None if sink is not None else dw), None, None
+
+
+def embedding_backward(dout, ids_c, rows, D, pad, sink):
+    """Table gradient of a lookup: stable sort + segmented sum, accumulated into `sink` when given (else returned)."""
+    n = ids_c.numel()
+    dev = dout.device
+    dw = sink if sink is not None else torch.empty((rows, D), dtype=torch.float32, device=dev)
+    nbytes = _lib.load().pv_embedding_bwd_ws_bytes(max(n, 1), D)
+    ws = workspace("emb_bwd", nbytes, torch.uint8, dev)
+    if dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= D and dout.stride(0) % 4 == 0:
+        g, ldg = dout, dout.stride(0)         # a column slice of a wider gradient (torch.cat backward): no copy
+    else:
+        g, ldg = dout.contiguous().view(-1, D), D
+    _lib.call("pv_embedding_bwd", _p(g), ldg, _p(ids_c), n, max(n, 1), max(n, 1), 0, 1, rows, D, pad,
+              1 if sink is not None else 0, _p(dw), _p(ws), nbytes, _stream())
+    return dw
+
+
+def embed_dropout_leaf(weight, ids, padding_idx, drop):
+    """Teacher-forced decoder input (decoders.py:174-175): dropout(embedding(ids)) as ONE value without autograd nodes,
+    plus the closure that takes dL/d(that value) to the table's gradient sink.  GRULayer hands the closure its dx inside a
+    postponed side-stream launch (defer_side_work): the sort and the segmented sum of the embedding gradient, which
+    nothing downstream waits for, then never stand between the recurrence's backward and the latent stack's.
+    Returns None when the table has no gradient sink (the ordinary autograd path is used then)."""
+    rows, D = weight.shape
+    sink = grad_sink(weight, (rows, D))
+    if sink is None or not torch.is_grad_enabled():
+        return None
+    pad = -1 if padding_idx is None else padding_idx
+    dropping = drop is not None and drop.training and drop.p > 0
+    with torch.no_grad():
+        ids_c = ids.contiguous()
+        n = ids_c.numel()
+        w = weight.contiguous()
+        x = torch.empty(tuple(ids.shape) + (D,), dtype=torch.float32, device=weight.device)
+        _lib.call("pv_embedding_gather", _p(w), rows, D, _p(ids_c), n, n, n, 0, 1, _p(x), D, None, 0, None, _stream())
+        p = site = mask = None
+        if dropping:
+            p, site, mask = drop.p, drop.next_site(), drop.mask
+            if mask is not None:
+                mask = mask.to(torch.uint8).contiguous()
+            y = torch.empty_like(x)
+            _drop_call(x.view(1, -1, D), y.view(1, -1, D), p, site, mask, (0, D))
+            x = y
+    Bq, Lq = ids.shape
+
+    def consume(dx):                       # dx [B, L, D], any strides
+        if dropping:
+            d2 = torch.empty((Bq, Lq, D), dtype=torch.float32, device=dx.device)
+            _drop_call(dx, d2, p, site, mask, (Lq * D, D))
+            dx = d2
+        embedding_backward(dx.reshape(-1, D) if dx.is_contiguous() else dx.contiguous().view(-1, D), ids_c, rows, D, pad,
+                           grad_sink(weight, (rows, D)))
+
+    return x, consume
 
 
 def embedding(weight, ids, padding_idx=None):
