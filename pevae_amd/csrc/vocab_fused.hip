@@ -50,6 +50,34 @@ struct Segs {                            // a workgroup's item range and how uni
 };
 __host__ __device__ __forceinline__ long seg_beg(long w, long N, int G) { return w * N / G; }
 
+// Which stream-K range a workgroup takes.  Ranges are contiguous in the (unit, item) space, so range k starts at item
+// phase(k) = seg_beg(k) mod `period` of its unit and walks the streamed operand cyclically from there.  Left in launch
+// order, the 32 workgroups of an XCD start at 32 phases spread over the whole operand (7 MB of h, 20 MB of W) and every
+// tile is fetched into that XCD's 4 MB L2 once per workgroup: FETCH_SIZE showed 1.13 GB per dW launch, 157 column tiles x
+// 7.2 MB.  Here the ranges are sorted by phase and dealt out in runs of G/8 to the XCDs (workgroups with equal blockIdx.x
+// % 8 share an XCD under round-robin dispatch): an XCD's workgroups then walk within period/8 items of each other and a
+// tile is fetched once per XCD and pass.  A permutation only: the split, the slabs and the fold order are unchanged, and
+// placement is speed, not correctness.  `scratch`: G + 1 ints of LDS, free again on return.
+__device__ __forceinline__ int phase_sorted_range(long N, int G, int period, int* scratch) {
+  if ((G & 7) || N < G || period <= 0) return blockIdx.x;
+  const int tid = threadIdx.x, want = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  for (int t = tid; t < G; t += blockDim.x) scratch[t] = (int)(seg_beg(t, N, G) % period);
+  __syncthreads();
+  for (int t = tid; t < G; t += blockDim.x) {
+    const int ph = scratch[t];
+    int rank = 0;
+    for (int u = 0; u < G; ++u) {
+      const int pu = scratch[u];
+      rank += (pu < ph || (pu == ph && u < t)) ? 1 : 0;
+    }
+    if (rank == want) scratch[G] = t;
+  }
+  __syncthreads();
+  const int k = scratch[G];
+  __syncthreads();
+  return k;
+}
+
 // ---- staging: wave w fills panel w (32 rows x 256 B) of a tile with 8 LDS-DMA pieces of 4 rows ------------------------
 // image: off(panel, row, chunk) = panel * 8192 + row * 256 + 16 * (chunk ^ swz(row)), swz(row) = ((row & 3) << 2) | ((row >> 2) & 3)
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, long ld, int row0, int max_row, char* buf, int w,
@@ -180,7 +208,8 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
   const int nlive = a.live ? min(a.T, *a.live) : a.T;
   const int NVI = (a.V + 31) / 32, NRG = (nlive + UNIT - 1) / UNIT;
   const long N = (long)NRG * NVI;
-  const long beg = seg_beg(blockIdx.x, N, G), end = seg_beg(blockIdx.x + 1, N, G);
+  const int rid = phase_sorted_range(N, G, NVI, (int*)smem);
+  const long beg = seg_beg(rid, N, G), end = seg_beg(rid + 1, N, G);
   const int rbase = 256 * r32, swh = (((r32 & 3) << 2) | ((r32 >> 2) & 3)) ^ hh;
   const TrAddr tr = make_tr(lane);
   int seg = 0;
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
       second_product<true>(tile, tr, 1, pf[1], O);
     }
     // ---- partial result of this segment: O^T as [hc][t] (128-byte runs), (m, l, target logit) per row -----------------
-    const long slab = (long)blockIdx.x * a.max_seg + seg;
+    const long slab = (long)rid * a.max_seg + seg;
     float* o = a.o_slab + slab * HD * UNIT + 32 * w + r32;
 #pragma unroll
     for (int c = 0; c < NCB; ++c)
@@ -410,7 +439,8 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
   const int nlive = a.live ? min(a.T, *a.live) : a.T;
   const int NCT = (a.V + UNIT - 1) / UNIT, NRI = (nlive + 31) / 32;
   const long N = (long)NCT * NRI;
-  const long beg = seg_beg(blockIdx.x, N, G), end = seg_beg(blockIdx.x + 1, N, G);
+  const int rid = phase_sorted_range(N, G, NRI, (int*)smem);
+  const long beg = seg_beg(rid, N, G), end = seg_beg(rid + 1, N, G);
   const int rbase = 256 * r32, swh = (((r32 & 3) << 2) | ((r32 >> 2) & 3)) ^ hh;
   const TrAddr tr = make_tr(lane);
   int seg = 0;
@@ -500,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
       second_product<false>(tile, tr, 0, pf[0], Z);
       second_product<false>(tile, tr, 1, pf[1], Z);
     }
-    const long slab = (long)blockIdx.x * a.max_seg + seg;
+    const long slab = (long)rid * a.max_seg + seg;
     float* z = a.z_slab + slab * UNIT * HD + r32;
 #pragma unroll
     for (int c = 0; c < NCB; ++c)

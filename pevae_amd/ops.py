@@ -215,7 +215,7 @@ def launch_after_recurrence():
 def join_side_work():
     """Launch postponed side work, then make the current stream wait for the side streams (before a persistent kernel
     that needs every CU, and at the end of the backward pass)."""
-    if not _SIDE:
+    if not _SIDE and not _DEFERRED and not _AFTER_RNN:
         return
     cur, st = _side_state()
     side = st["stream"]
