@@ -3,9 +3,9 @@ Plain-Python restatement of the reference's Yelp collation and vocabulary build,
   batch()        <- YELPDataLoader.batcher.__call__   models/dataset/data_loaders.py:649-715
   pad_to()       <- YELPDataLoader.batcher.pad_to     models/dataset/data_loaders.py:641-648
   build_vocab()  <- YelpCorpus._build_vocab           models/dataset/corpora.py:624-651
-Parity pinned by reading only: the reference's corpus classes import nltk / transformers tokenizers at module import and
-its pickles are absent, so no golden could be generated from it here ("parity unpinned" for this row; the restatement
-follows the cited lines literally)."""
+Pinned by tests/golden/yelp_data_path.json, which oracle/make_golden.py gen_yelp_data_path produced by running the
+reference's own corpus / loader code (imported with the nltk and numpy.lib.type_check stubs) on a synthetic review file:
+tests/test_data_path.py compares this restatement and pevae_amd.dataset with it list by list."""
 from collections import Counter
 
 import torch
