@@ -154,6 +154,14 @@ class DLSVAE(nn.Module):
     def forward(self, data_feed, mode=TEACH_FORCE, gen_type="greedy", eps=None):
         if self.training and self.config.dropout > 0:
             ops.rng_advance(self.x_embedding.weight.device)      # new dropout masks every step, also under graph replay
+        early_sn = self.latent_stack == "dls" and data_feed["user_ids"].is_cuda
+        if early_sn:
+            # all 105 power iterations (one launch group) beside the launches in front of the encoder recurrence, whose
+            # launch joins the side stream; first read by the pyramids behind it
+            if getattr(self, "_sn_modules", None) is None:
+                self._sn_modules, self._sn_cache = L.spectral_modules(self), {}
+            with ops.fork_side():
+                ops.spectral_prepass(self._sn_modules, self.training, cache=self._sn_cache)
         user = ops.embedding(self.user_embedding.weight, data_feed["user_ids"])          # :758
         item = ops.embedding(self.item_embedding.weight, data_feed["item_ids"])          # :759
         rating = ops.embedding(self.rating_embedding.weight, data_feed["ratings"].ge(3).long())   # :760
@@ -163,9 +171,11 @@ class DLSVAE(nn.Module):
         prior_h = ops.tanh(ops.linear(torch.cat([user, item, rating], -1), self.prior_fc.weight, self.prior_fc.bias))
         B = h.size(0)
         if self.latent_stack == "dls":
-            if getattr(self, "_sn_modules", None) is None:
-                self._sn_modules, self._sn_cache = L.spectral_modules(self), {}
-            ops.spectral_prepass(self._sn_modules, self.training, cache=self._sn_cache)    # all 105 power iterations, one launch
+            if not early_sn:
+                if getattr(self, "_sn_modules", None) is None:
+                    self._sn_modules, self._sn_cache = L.spectral_modules(self), {}
+                ops.spectral_prepass(self._sn_modules, self.training, cache=self._sn_cache)    # all 105 power iterations
+            ops.join_side_work()
             (z_pri, pri_state), (z_rec, rec_state) = L.pyramid_pair(self.pri_encoder, prior_h,         # :3529
                                                                     self.rec_encoder, h)               # :3530
             if self.use_mutual:                                                            # :3089 (DeN_VAE)

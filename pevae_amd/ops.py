@@ -212,6 +212,33 @@ def launch_after_recurrence():
             fn()
 
 
+class fork_side(object):
+    """Forward-time region on the side stream that is NOT joined on exit: the next join_side_work() (every persistent
+    recurrence launch makes one) orders the current stream after it.  For work whose results are first read behind such
+    a join: the spectral-norm pre-pass of the whole latent stack runs beside the embedding / projection launches in front
+    of the encoder recurrence."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled) and torch.cuda.is_available()
+
+    def __enter__(self):
+        if not self.enabled:
+            return self
+        cur, st = _side_state()
+        if cur == st["stream"]:
+            self.enabled = False
+            return self
+        st["stream"].wait_stream(cur)
+        self.ctx = torch.cuda.stream(st["stream"])
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def join_side_work():
     """Launch postponed side work, then make the current stream wait for the side streams (before a persistent kernel
     that needs every CU, and at the end of the backward pass)."""
