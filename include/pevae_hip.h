@@ -306,7 +306,7 @@ typedef struct pv_block_call {      /* one Block of a launch; arrays are in the 
   float* dx;                        /* [M][lddx] */
   long lddx;
   float* dY;                        /* scratch [M][grad_width] */
-  float* cpart;                     /* scratch 5 * cdiv(M,16) floats */
+  float* cpart;                     /* scratch 5 * 4 * cdiv(M,16) floats (one partial per member of a 4-workgroup cluster) */
   float* ppart;                     /* scratch cdiv(M,16) * part_width floats */
   float* dW[5];
   float* db[5];
@@ -314,10 +314,11 @@ typedef struct pv_block_call {      /* one Block of a launch; arrays are in the 
   float* dbeta;
 } pv_block_call;
 /* Up to PV_BLOCK_GROUP_MAX INDEPENDENT Blocks per launch (the two pyramids' Blocks of a level, or the three Blocks of a
- * DLS_Auto level, run side by side).  Forward: Blocks 256 / 512 wide are walked by clusters of 2 / 4 workgroups per
- * 16-row slab that split every layer's columns and hand their slices to each other through `save` (bounded waits;
- * pv_block_sync_error reports a wait that gave up).  Launches of pv_block_fwd on ONE device must not overlap each
- * other (they share the device's hand-off counters); stream order, as every caller here uses, is enough. */
+ * DLS_Auto level, run side by side).  Blocks 512 wide are walked by clusters of 4 workgroups per 16-row slab that split
+ * every layer's columns and hand their slices to each other through `save` (forward) / `dx` and `dY` (backward), with
+ * bounded waits (pv_block_sync_error reports one that gave up).  Launches of pv_block_fwd on ONE device must not overlap
+ * each other, nor launches of pv_block_bwd each other (each kind shares the device's hand-off counters); stream order,
+ * as every caller here uses, is enough. */
 int pv_block_fwd(const pv_block_call* calls, int n, void* stream);
 int pv_block_bwd(const pv_block_call* calls, int n, void* stream);
 /* pv_block_bwd in two launches: phase 1 = the dx chain (block_bwd_dx_kernel: dL/dx, dY, the per-workgroup partials),

@@ -271,6 +271,185 @@ __device__ __forceinline__ void wave_stage_params(const BlockDesc& d, const Part
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Single-workgroup slabs (every Block of the launch narrower than 512): 64-column wave tiles, a fifth *storer* wave that
+// writes the state the backward pass needs one layer behind, no hand-offs.  (Round-1 kernel; the cluster kernel below
+// also walks G = 1 Blocks, but its 32-column tiles and its LDS staging cost the small Blocks ~10 %.)
+// ---------------------------------------------------------------------------------------------------------------
+struct BlockFwdArgs1 {
+  const float* x;
+  long ldx;
+  int M;
+  BlockDesc d;      // d.W: the TRANSPOSED effective-layout copies W_i^T [in][out] (from pv_spectral_norm_multi)
+  float* save;      // [M][SaveLayout.width]
+  float* mean;      // [M]
+  float* rstd;      // [M]
+  float* out;       // [M][ldo]
+  long ldo;
+  int LD;           // LDS row stride (floats) = max width + 4
+};
+
+// Independent Blocks (the two pyramids' Blocks of one level, the three Blocks of a DLS_Auto level) share a launch:
+// blockIdx.y picks the Block, blockIdx.x its 16-row slab.  Each Block alone occupies 16 of the 256 CUs.
+struct BlockFwdGroup1 {
+  BlockFwdArgs1 a[PV_BLOCK_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(NT) void block_fwd_kernel(BlockFwdGroup1 grp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const BlockFwdArgs1& a = grp.a[blockIdx.y];
+  if ((int)blockIdx.x * RB >= a.M) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, q4 = lane >> 4;
+  const bool compute = w < 4;
+  const int Din = a.d.Din, mid = a.d.mid, Dout = a.d.Dout, LD = a.LD, M = a.M;
+  const int r0 = blockIdx.x * RB;
+  float* buf0 = lds;
+  float* buf1 = lds + RB * LD;
+  float* yb0 = lds + 2 * RB * LD;                 // the layer's pre-activation y, parked for the storer wave
+  float* yb1 = lds + 3 * RB * LD;
+  float* par = lds + 4 * RB * LD;
+  const SaveLayout L(Din, mid);
+  const PartLayout P(Din, mid, Dout);
+  const float* isg = par + P.width;
+  float* rowstat = par + P.width + 8;             // mean[16], rstd[16]
+  const size_t SW = L.width;
+  BSTAMP_DECL(par + P.width + 8 + 2 * RB)
+  BSTAMP(0, 0);
+#ifdef PV_BLOCK_STAMPS
+  if (threadIdx.x == 0) bst[14] = clock64();
+#endif
+
+  f32x4 ring[RD][4];
+  if (compute) {
+    ring_fill(wptr(a.d.W[0], Din, w * 64, c16, q4), Din / 16, ring);
+    // x rows: a0 = gelu(x) -> buf0 (all of a thread's loads are issued first: widths <= 512 -> at most 8 per thread)
+    const int nq = RB * Din / 4, per = Din / 4;
+    f32x4 xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(tid + u * NTC, nq - 1);
+      xv[u] = *(const f32x4*)(a.x + (size_t)min(r0 + i / per, M - 1) * a.ldx + (i % per) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * NTC;
+      if (i < nq) {
+        const f32x4 v = xv[u];
+        *(f32x4*)(buf0 + (i / per) * LD + (i % per) * 4) = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+      }
+    }
+  } else {
+    wave_stage_params(a.d, P, par, lane);
+  }
+  lds_barrier();
+  BSTAMP(0, 1);
+
+  // layers c1, c2, c3 (y -> yb, gelu(y) -> next input), c4 (y -> yb, x + y -> LayerNorm input), translate (-> out);
+  // the storer wave runs one layer behind: it writes out what the previous layer left in LDS.
+  for (int li = 0; li < 5; ++li) {
+    const int N = li == 0 || li == 3 ? Din : (li == 4 ? Dout : mid);
+    const int K = li == 0 || li == 1 || li == 4 ? Din : mid;
+    const int Nn = li == 0 || li == 1 ? mid : (li == 2 ? Din : Dout), Kn = li == 0 || li == 3 ? Din : mid;
+    const float* in = li == 4 ? buf1 : ((li & 1) ? buf1 : buf0);
+    float* outb = (li & 1) ? buf0 : buf1;
+    float* yb = (li & 1) ? yb1 : yb0;
+    if (compute) {
+      const float* Wn = li < 4 ? a.d.W[li + 1] : nullptr;
+      const int off_b = li == 0 ? P.b1 : li == 1 ? P.b2 : li == 2 ? P.b3 : li == 3 ? P.b4 : P.bt;
+      const float is = isg[li];
+      f32x4 xs[4];
+      dense16(in, LD, a.d.W[li], N, K, Wn, Nn, Kn, w, lane, ring,
+              [&](int n0) __attribute__((always_inline)) {
+                if (li != 3) return;                  // the residual input, requested before the k loop
+                const int col = min(n0 + 4 * c16, N - 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  xs[j] = *(const f32x4*)(a.x + (size_t)min(r0 + q4 * 4 + j, M - 1) * a.ldx + col);
+              },
+              [&](f32x4 (&acc)[4], int n0) __attribute__((always_inline)) {
+                const int col = n0 + 4 * c16;
+                if (col >= N) return;
+                const f32x4 bv = *(const f32x4*)(par + off_b + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const int row = q4 * 4 + j, gr = r0 + row;
+                  const f32x4 y = {acc[0][j] * is + bv[0], acc[1][j] * is + bv[1], acc[2][j] * is + bv[2],
+                                   acc[3][j] * is + bv[3]};
+                  if (li < 3) {
+                    *(f32x4*)(yb + row * LD + col) = y;
+                    *(f32x4*)(outb + row * LD + col) = f32x4{gelu_f(y[0]), gelu_f(y[1]), gelu_f(y[2]), gelu_f(y[3])};
+                  } else if (li == 3) {
+                    *(f32x4*)(yb + row * LD + col) = y;
+                    *(f32x4*)(buf0 + row * LD + col) = xs[j] + y;
+                  } else if (gr < M) {
+                    *(f32x4*)(a.out + (size_t)gr * a.ldo + col) = y;
+                  }
+                }
+              });
+    } else {
+      if (li == 0) {
+        wave_copy_out(buf0, LD, a.save + L.a0, SW, Din, r0, M, lane);
+      } else if (li < 4) {
+        // outputs of layer li - 1: y in the other yb, gelu(y) in this layer's input
+        const int pN = li == 1 ? Din : mid;
+        const int off_y = li == 1 ? L.y1 : li == 2 ? L.y2 : L.y3, off_a = li == 1 ? L.a1 : li == 2 ? L.a2 : L.a3;
+        wave_copy_out((li & 1) ? yb0 : yb1, LD, a.save + off_y, SW, pN, r0, M, lane);
+        wave_copy_out(in, LD, a.save + off_a, SW, pN, r0, M, lane);
+      } else {
+        wave_copy_out(buf1, LD, a.save + L.o, SW, Din, r0, M, lane);
+        if (lane < RB && r0 + lane < M) {
+          a.mean[r0 + lane] = rowstat[lane];
+          a.rstd[r0 + lane] = rowstat[RB + lane];
+        }
+      }
+    }
+    BSTAMP(0, 2 + 2 * li);
+    if (li == 4) break;
+    lds_barrier();
+    BSTAMP(0, 3 + 2 * li);
+    if (li == 3) {
+      if (compute) {
+        // LayerNorm of s = x + y4 (buf0; biased variance, two passes as nn.LayerNorm) -> buf1: 16 lanes per row, the
+        // wave's four rows side by side
+        const int row = w * 4 + q4;
+        const float* srow = buf0 + row * LD;
+        float sm = 0.f;
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 v = *(const f32x4*)(srow + c);
+          sm += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        const float mu = group16_sum(sm) / Din;
+        float q = 0.f;
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 v = *(const f32x4*)(srow + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q += (v[e] - mu) * (v[e] - mu);
+        }
+        const float rs = rsqrtf(group16_sum(q) / Din + a.d.eps);
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 v = *(const f32x4*)(srow + c), gm = *(const f32x4*)(par + P.dg + c), bt = *(const f32x4*)(par + P.dbe + c);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu) * rs * gm[e] + bt[e];
+          *(f32x4*)(buf1 + row * LD + c) = o;
+        }
+        if (c16 == 0) {
+          rowstat[row] = mu;
+          rowstat[RB + row] = rs;
+        }
+      } else {
+        wave_copy_out(yb1, LD, a.save + L.y4, SW, Din, r0, M, lane);
+      }
+      lds_barrier();
+      BSTAMP(0, 12);
+    }
+  }
+#ifdef PV_BLOCK_STAMPS
+  if (threadIdx.x == 0) bst[15] = clock64();
+#endif
+  BSTAMP_FLUSH(0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Forward: a CLUSTER of G workgroups (1, 2 or 4) shares one 16-row slab and splits the columns of every layer.
 //
 // A slab's whole Block on one CU costs 72 us of f32 MFMA and 52 us of weight streaming for the 512-wide Blocks (every
@@ -425,9 +604,8 @@ struct BlockFwdGroup {
   BlockFwdArgs a[PV_BLOCK_GROUP_MAX];
   int slab_stride;
 };
-struct BlockBwdGroup;
 
-__global__ __launch_bounds__(NT) void block_fwd_kernel(BlockFwdGroup grp) {
+__global__ __launch_bounds__(NT) void block_fwd_cluster_kernel(BlockFwdGroup grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BlockFwdArgs& a = grp.a[blockIdx.y];
   const int slab = blockIdx.x % grp.slab_stride, g = blockIdx.x / grp.slab_stride, G = a.G;
@@ -608,7 +786,7 @@ __global__ __launch_bounds__(NT) void block_fwd_kernel(BlockFwdGroup grp) {
   BSTAMP_FLUSH(0);
 }
 
-struct BlockBwdArgs {
+struct BlockBwdArgs1 {
   const float* dout;   // [M][lddo]   dL/d out
   long lddo;
   const float* x;      // [M][ldx]
@@ -628,13 +806,13 @@ struct BlockBwdArgs {
   int LD;
 };
 
-struct BlockBwdGroup {
-  BlockBwdArgs a[PV_BLOCK_GROUP_MAX];
+struct BlockBwdGroup1 {
+  BlockBwdArgs1 a[PV_BLOCK_GROUP_MAX];
 };
 
-__global__ __launch_bounds__(NT) void block_bwd_dx_kernel(BlockBwdGroup grp) {
+__global__ __launch_bounds__(NT) void block_bwd_dx_kernel(BlockBwdGroup1 grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const BlockBwdArgs& a = grp.a[blockIdx.y];
+  const BlockBwdArgs1& a = grp.a[blockIdx.y];
   if ((int)blockIdx.x * RB >= a.M) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, q4 = lane >> 4;
   const bool compute = w < 4;
@@ -827,6 +1005,278 @@ __global__ __launch_bounds__(NT) void block_bwd_dx_kernel(BlockBwdGroup grp) {
   if (tid < 5) a.cpart[tid * nwg + blockIdx.x] = cred[0][tid] + cred[1][tid] + cred[2][tid] + cred[3][tid];
 }
 
+struct BlockBwdArgs {
+  const float* dout;   // [M][lddo]   dL/d out
+  long lddo;
+  const float* x;      // [M][ldx]
+  long ldx;
+  const float* out;    // [M][ldo]    forward output (for the translate layer's spectral term)
+  long ldo;
+  int M;
+  BlockDesc d;         // d.W: weight_orig [out][in]
+  const float* save;
+  const float* mean;
+  const float* rstd;
+  float* dx;           // [M][lddx]
+  long lddx;
+  float* dY;           // [M][GradLayout.width]
+  float* cpart;        // [5][nwg * G]   partial <dy_i, y_i - b_i>, one per member
+  float* ppart;        // [nwg][PartLayout.width]
+  int LD;
+  int G;               // cluster size (block_cluster), as in the forward kernel
+  unsigned dx_bytes, dY_bytes;
+};
+
+struct BlockBwdGroup {
+  BlockBwdArgs a[PV_BLOCK_GROUP_MAX];
+  int slab_stride;
+};
+
+__device__ unsigned g_bwd_sync[PV_BLOCK_GROUP_MAX][SLAB_MAX][2];   // as g_fwd_sync
+
+// column sums over the workgroup's 16 rows of columns [beg, end) of an LDS image (rows past M hold zeros)
+__device__ __forceinline__ void wave_colsum_cols(const float* __restrict__ buf, int LD, int beg, int end, float* __restrict__ dst,
+                                                 int lane) {
+  for (int c = beg + lane * 4; c < end; c += 256) {
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < RB; ++r) sum += *(const f32x4*)(buf + r * LD + c);
+    *(f32x4*)(dst + c) = sum;
+  }
+}
+
+// The dx chain with the forward kernel's clusters: the members of a slab split the columns of every step's output.
+// The LayerNorm backward needs whole rows of do = dout W_t / sigma_t, and every later step whole rows of the dy before
+// it, so each step ends in a hand-off of the members' slices: do travels through the rows of `dx` (free until the last
+// step writes them), dy3 / dy2 / dy1 through the rows of `dY` where the weight-gradient GEMMs read them anyway.
+__global__ __launch_bounds__(NT) void block_bwd_dx_cluster_kernel(BlockBwdGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const BlockBwdArgs& a = grp.a[blockIdx.y];
+  const int slab = blockIdx.x % grp.slab_stride, g = blockIdx.x / grp.slab_stride, G = a.G;
+  if (g >= G || slab * RB >= a.M) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, q4 = lane >> 4;
+  const bool compute = w < 4;
+  const int Din = a.d.Din, mid = a.d.mid, Dout = a.d.Dout, LD = a.LD, M = a.M;
+  const int r0 = slab * RB, nwg = (a.M + RB - 1) / RB;
+  float* buf0 = lds;
+  float* buf1 = lds + RB * LD;
+  float* buf2 = lds + 2 * RB * LD;
+  float* sbuf = lds + 3 * RB * LD;                              // s = x + y4 (the LayerNorm input)
+  float* par = lds + 4 * RB * LD;
+  const SaveLayout L(Din, mid);
+  const GradLayout GL(Din, mid);
+  const PartLayout P(Din, mid, Dout);
+  const float* isg = par + P.width;
+  float* rowstat = par + P.width + 8;                           // mean[16], rstd[16]
+  float (*cred)[5] = (float (*)[5])(par + P.width + 8 + 2 * RB);   // [4 waves][5]: <dy_i, y_i - b_i>, i = c1..c4, translate
+  volatile int* flag = (volatile int*)(par + P.width + 8 + 2 * RB + 20);   // storer -> compute: LayerNorm column sums read
+  const size_t SW = L.width, GW = GL.width;
+  float* prow = a.ppart + (size_t)slab * P.width;
+  unsigned* ctr = &g_bwd_sync[blockIdx.y][slab][0];
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dx, 0, a.dx_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, a.dY_bytes, 0x00020000);
+  const int din_b = g * (Din / G), din_e = din_b + Din / G;     // this member's share of a Din-wide row
+
+  f32x2 ring[RD2][4];
+  if (compute) {
+    ring2_fill(wptr2(a.d.W[4], Din, din_b + w * TW, c16, q4), Dout / 16, ring);
+    // dL/dout rows -> buf0 (zero past M) with the translate layer's spectral term; s = x + y4 -> sbuf.  Loads first.
+    const int nqo = RB * Dout / 4, pero = Dout / 4, nqi = RB * Din / 4, peri = Din / 4;
+    f32x4 dv[8], ov[8], bv[8], xv[8], yv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(tid + u * NTC, nqo - 1), gr = min(r0 + i / pero, M - 1), c4 = (i % pero) * 4;
+      dv[u] = *(const f32x4*)(a.dout + (size_t)gr * a.lddo + c4);
+      ov[u] = *(const f32x4*)(a.out + (size_t)gr * a.ldo + c4);
+      bv[u] = *(const f32x4*)(a.d.bias[4] + c4);
+      const int k = min(tid + u * NTC, nqi - 1), gk = min(r0 + k / peri, M - 1), k4 = (k % peri) * 4;
+      xv[u] = *(const f32x4*)(a.x + (size_t)gk * a.ldx + k4);
+      yv[u] = *(const f32x4*)(a.save + (size_t)gk * SW + L.y4 + k4);
+    }
+    float c4s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * NTC;
+      if (i < nqo) {
+        const int row = i / pero;
+        f32x4 v = dv[u];
+        if (r0 + row >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c4s += v[e] * (ov[u][e] - bv[u][e]);
+        *(f32x4*)(buf0 + row * LD + (i % pero) * 4) = v;
+      }
+      if (i < nqi) *(f32x4*)(sbuf + (i / peri) * LD + (i % peri) * 4) = xv[u] + yv[u];
+    }
+    c4s = wave_sum(c4s);
+    if (lane == 0) cred[w][4] = g == 0 ? c4s : 0.f;             // every member holds all of dout: one of them counts it
+  } else {
+    wave_stage_params(a.d, P, par, lane);
+    if (lane < RB) {
+      const int grc = min(r0 + lane, M - 1);
+      rowstat[lane] = a.mean[grc];
+      rowstat[RB + lane] = a.rstd[grc];
+    }
+    if (lane == 0) *flag = 0;
+  }
+  lds_barrier();
+
+  // step 0: do = dout W_t / sigma_t -> buf1, then the LayerNorm backward (ds = dy4 -> buf2);
+  // steps 1..3: dy_i = (dy_{i+1} W_{i+1} / sigma_{i+1}) * gelu'(y_i) for y3, y2, y1 (buffers 2 -> 0 -> 1 -> 0);
+  // step 4: dx = ds + (dy1 W_1 / sigma_1) * gelu'(x), and the c4 spectral term (y4 - b4 = s - x - b4).
+  // The storer wave runs one step behind: column sums of this member's columns -> the slab's partial row of the bias /
+  // LayerNorm parameter gradients (and, for G = 1, the dy copies to dY; a cluster stores them in its hand-off).
+  for (int st = 0; st < 5; ++st) {
+    const int li = 4 - st;                                  // the linear whose weight this step multiplies by
+    const int N = st == 0 || st >= 3 ? Din : mid;
+    const int K = st == 0 ? Dout : (st == 1 || st == 4 ? Din : mid);
+    const int Nn = st == 0 || st == 1 ? mid : Din, Kn = st == 0 || st == 3 ? Din : mid;
+    const int Nw = N / G, nbeg = g * Nw, nend = nbeg + Nw;
+    const float* in = st == 0 ? buf0 : st == 1 ? buf2 : st == 2 ? buf0 : st == 3 ? buf1 : buf0;
+    float* outb = st == 0 ? buf1 : st == 1 ? buf0 : st == 2 ? buf1 : buf0;
+    if (compute) {
+      const float* Wn = st < 4 ? a.d.W[li - 1] : nullptr;
+      const int off_y = st == 1 ? L.y3 : st == 2 ? L.y2 : L.y1;
+      const int off_b = st == 1 ? P.b3 : st == 2 ? P.b2 : st == 3 ? P.b1 : P.b4;
+      // what the epilogue multiplies by gelu'(.): saved y_i (steps 1..3) or x (step 4), requested before the k loop
+      const float* pbase = st == 4 ? a.x : a.save + off_y;
+      const long pstride = st == 4 ? a.ldx : (long)SW;
+      const float is = isg[li];
+      float csum = 0.f;
+      f32x2 ys[4];
+      dense16s(in, LD, a.d.W[li], N, K, nbeg, nend, Wn, Nn, Kn, g * (Nn / G), w, lane, ring,
+               [&](int n0) __attribute__((always_inline)) {
+                 if (st == 0) return;
+                 const int col = min(n0 + 2 * c16, N - 2);
+#pragma unroll
+                 for (int j = 0; j < 4; ++j)
+                   ys[j] = *(const f32x2*)(pbase + (size_t)min(r0 + q4 * 4 + j, M - 1) * pstride + col);
+               },
+               [&](f32x4 (&acc)[2], int n0) __attribute__((always_inline)) {
+                 const int col = n0 + 2 * c16;
+                 if (col >= nend) return;
+                 if (st == 0) {
+#pragma unroll
+                   for (int j = 0; j < 4; ++j)
+                     *(f32x2*)(outb + (q4 * 4 + j) * LD + col) = f32x2{acc[0][j] * is, acc[1][j] * is};
+                   return;
+                 }
+                 if (st == 1)                                 // buf0 still feeds the storer's dgamma column sums
+                   while (*flag == 0) __builtin_amdgcn_s_sleep(1);
+                 const f32x2 bv = *(const f32x2*)(par + off_b + col);
+#pragma unroll
+                 for (int j = 0; j < 4; ++j) {
+                   const int row = q4 * 4 + j, gr = r0 + row;
+                   if (st < 4) {
+                     f32x2 dy = {0.f, 0.f};
+                     if (gr < M) {
+#pragma unroll
+                       for (int e = 0; e < 2; ++e) {
+                         dy[e] = acc[e][j] * is * gelu_df(ys[j][e]);
+                         csum += dy[e] * (ys[j][e] - bv[e]);
+                       }
+                     }
+                     *(f32x2*)(outb + row * LD + col) = dy;
+                   } else if (gr < M) {
+                     const f32x2 ds = *(const f32x2*)(buf2 + row * LD + col), sv = *(const f32x2*)(sbuf + row * LD + col);
+                     f32x2 r;
+#pragma unroll
+                     for (int e = 0; e < 2; ++e) {
+                       r[e] = ds[e] + acc[e][j] * is * gelu_df(ys[j][e]);
+                       csum += ds[e] * (sv[e] - ys[j][e] - bv[e]);
+                     }
+                     *(f32x2*)(a.dx + (size_t)gr * a.lddx + col) = r;
+                   }
+                 }
+               });
+      if (st > 0) {
+        csum = wave_sum(csum);
+        if (lane == 0) cred[w][st == 4 ? 3 : 3 - st] = csum;
+      }
+    } else {
+      if (st == 0) {
+        wave_colsum_cols(buf0, LD, g * (Dout / G), (g + 1) * (Dout / G), prow + P.bt, lane);
+      } else if (st == 1) {
+        wave_copy_cols(buf2, LD, a.dY + GL.d4, GW, din_b, din_e, r0, M, lane);
+        wave_colsum_cols(buf0, LD, din_b, din_e, prow + P.dg, lane);
+        wave_colsum_cols(buf1, LD, din_b, din_e, prow + P.dbe, lane);
+        wave_colsum_cols(buf2, LD, din_b, din_e, prow + P.b4, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *flag = 1;
+      } else {
+        // dy of the previous step sits in this step's input
+        const int pN = st == 4 ? Din : mid;
+        const int off_d = st == 2 ? GL.d3 : st == 3 ? GL.d2 : GL.d1, off_pb = st == 2 ? P.b3 : st == 3 ? P.b2 : P.b1;
+        const int pb = g * (pN / G), pe = pb + pN / G;
+        if (G == 1) wave_copy_cols(in, LD, a.dY + off_d, GW, pb, pe, r0, M, lane);
+        wave_colsum_cols(in, LD, pb, pe, prow + off_pb, lane);
+      }
+    }
+    lds_barrier();
+    if (G > 1 && st < 4) {
+      // hand-off of this step's output: do through the rows of dx, dy3 / dy2 / dy1 through dY (16-byte sc1 stores of this
+      // member's slice -> drained -> arrival -> the others' slices with sc1 loads; rows past M are zeros)
+      const __amdgpu_buffer_rsrc_t rs = st == 0 ? xrsrc : yrsrc;
+      const size_t rstride = st == 0 ? (size_t)a.lddx : GW;
+      const unsigned off_s = st == 0 ? 0u : (unsigned)(st == 1 ? GL.d3 : st == 2 ? GL.d2 : GL.d1);
+      const int per = Nw / 4, nq = RB * per;
+      for (int i = tid; i < nq; i += NT) {
+        const int row = i / per, col = nbeg + (i % per) * 4;
+        if (r0 + row < M)
+          st16_sc1(rs, (unsigned)(((size_t)(r0 + row) * rstride + off_s + col) * sizeof(float)), *(const f32x4*)(outb + row * LD + col));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+      if (tid == 0) cluster_arrive_wait(ctr, (unsigned)(G * (st + 1)));
+      lds_barrier();
+      const int pero = (N - Nw) / 4, nqo = RB * pero;
+      for (int i = tid; i < nqo; i += NT) {
+        const int row = i / pero, cc = (i % pero) * 4, col = cc < nbeg ? cc : cc + Nw;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + row < M) v = ld16_sc1(rs, (unsigned)(((size_t)(r0 + row) * rstride + off_s + col) * sizeof(float)));
+        *(f32x4*)(outb + row * LD + col) = v;
+      }
+      lds_barrier();
+    }
+    if (st == 0) {
+      if (compute) {
+        // LayerNorm backward: ds = rstd (g - mean(g) - xhat mean(g xhat)), g = do * gamma.  buf0 <- do * xhat (for
+        // dgamma), buf1 keeps do (for dbeta), buf2 <- ds = dy4 (also the residual branch of dx); whole rows in every member
+        const int row = w * 4 + q4;
+        const float mu = rowstat[row], rs = rowstat[RB + row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 sv = *(const f32x4*)(sbuf + row * LD + c), dv = *(const f32x4*)(buf1 + row * LD + c),
+                      gm = *(const f32x4*)(par + P.dg + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float gg = dv[e] * gm[e];
+            s1 += gg;
+            s2 += gg * ((sv[e] - mu) * rs);
+          }
+        }
+        s1 = group16_sum(s1) / Din;
+        s2 = group16_sum(s2) / Din;
+        for (int c = c16 * 4; c < Din; c += 64) {
+          const f32x4 sv = *(const f32x4*)(sbuf + row * LD + c), dv = *(const f32x4*)(buf1 + row * LD + c),
+                      gm = *(const f32x4*)(par + P.dg + c);
+          f32x4 dsv, dxh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (sv[e] - mu) * rs;
+            dsv[e] = rs * (dv[e] * gm[e] - s1 - xh * s2);       // rows past M: do = 0 -> ds = 0
+            dxh[e] = dv[e] * xh;
+          }
+          *(f32x4*)(buf0 + row * LD + c) = dxh;
+          *(f32x4*)(buf2 + row * LD + c) = dsv;
+        }
+      }
+      lds_barrier();
+    }
+  }
+  if (G > 1 && tid == 0) cluster_depart(ctr, (unsigned)G);
+  if (tid < 5) a.cpart[(size_t)tid * nwg * G + slab * G + g] = cred[0][tid] + cred[1][tid] + cred[2][tid] + cred[3][tid];
+}
+
 struct ParamReduceArgs {
   const float* ppart;    // [nwg][width]
   int nwg, width;
@@ -940,12 +1390,28 @@ int pv_block_fwd(const pv_block_call* calls, int n, void* stream) {
     if (a.G > gmax) gmax = a.G;
   }
   for (int b = n; b < PV_BLOCK_GROUP_MAX; ++b) g.a[b] = g.a[0];
+  if (gmax == 1) {                              // nothing to split: the single-workgroup kernel (64-column tiles)
+    BlockFwdGroup1 g1;
+    size_t smem1 = 0;
+    for (int b = 0; b < PV_BLOCK_GROUP_MAX; ++b) {
+      const BlockFwdArgs& a = g.a[b];
+      g1.a[b] = BlockFwdArgs1{a.x, a.ldx, a.M, a.d, a.save, a.mean, a.rstd, a.out, a.ldo, a.LD};
+      const size_t need = ((size_t)4 * RB * a.LD + PartLayout(a.d.Din, a.d.mid, a.d.Dout).width + 8 + 2 * RB + 32) * sizeof(float);
+      if (need > smem1) smem1 = need;
+    }
+    static size_t seen1 = 0;
+    int rc = set_lds(block_fwd_kernel, smem1, &seen1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(block_fwd_kernel, dim3(nslab, n), dim3(NT), smem1, (hipStream_t)stream, g1);
+    PV_LAUNCH_CHECK("block_fwd_kernel");
+    return PV_OK;
+  }
   g.slab_stride = round_up(nslab, 8);           // members of a cluster: equal blockIdx.x mod 8 -> one XCD
   static size_t seen = 0;
-  int rc = set_lds(block_fwd_kernel, smem, &seen);
+  int rc = set_lds(block_fwd_cluster_kernel, smem, &seen);
   if (rc) return rc;
-  hipLaunchKernelGGL(block_fwd_kernel, dim3(g.slab_stride * gmax, n), dim3(NT), smem, (hipStream_t)stream, g);
-  PV_LAUNCH_CHECK("block_fwd_kernel");
+  hipLaunchKernelGGL(block_fwd_cluster_kernel, dim3(g.slab_stride * gmax, n), dim3(NT), smem, (hipStream_t)stream, g);
+  PV_LAUNCH_CHECK("block_fwd_cluster_kernel");
   return PV_OK;
 }
 
@@ -968,7 +1434,7 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
   ParamReduceGroup pr;
   LinGroupItem it[5 * PV_BLOCK_GROUP_MAX];
   size_t smem = 0;
-  int nwg_max = 0, width_max = 0;
+  int nwg_max = 0, width_max = 0, gmax = 1;
   for (int b = 0; b < n; ++b) {
     const pv_block_call& c = calls[b];
     int rc = check_dims(c.M, c.Din, c.mid, c.Dout, "pv_block_bwd");
@@ -985,6 +1451,10 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
     a.dout = c.dout; a.lddo = c.lddo; a.x = c.x; a.ldx = c.ldx; a.out = c.out; a.ldo = c.ldo; a.M = c.M; a.save = c.save;
     a.mean = c.mean; a.rstd = c.rstd; a.dx = c.dx; a.lddx = c.lddx; a.dY = c.dY; a.cpart = c.cpart; a.ppart = c.ppart;
     a.LD = max3(c.Din, c.mid, c.Dout) + 4;
+    a.G = block_cluster(c.M, c.Din, c.mid, c.Dout);
+    a.dx_bytes = (unsigned)((size_t)c.M * c.lddx * sizeof(float));
+    a.dY_bytes = (unsigned)((size_t)c.M * GradLayout(c.Din, c.mid).width * sizeof(float));
+    if (a.G > gmax) gmax = a.G;
     const int nwg = cdiv(c.M, RB);
     const PartLayout P(c.Din, c.mid, c.Dout);
     const size_t need = ((size_t)4 * RB * a.LD + P.width + 8 + 2 * RB + 24 + 8) * sizeof(float);
@@ -1012,7 +1482,7 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
     for (int i = 0; i < 5; ++i) {
       PV_REQUIRE(c.dW[i] && c.u[i] && c.v[i], "pv_block_bwd: null weight-gradient argument %d", i);
       it[5 * b + i] = LinGroupItem{dys[i], 1, dyld[i], acts[i], SW, 1, c.dW[i], ins[i], outs[i], ins[i], c.M,
-                                   c.inv_sigma[i], c.accumulate, c.cpart + (size_t)i * nwg, nwg, c.u[i], c.v[i]};
+                                   c.inv_sigma[i], c.accumulate, c.cpart + (size_t)i * nwg * a.G, nwg * a.G, c.u[i], c.v[i]};
     }
   }
   for (int b = n; b < PV_BLOCK_GROUP_MAX; ++b) {
@@ -1020,11 +1490,23 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
     pr.r[b] = pr.r[0];
   }
   if (phase & 1) {
-    static size_t seen = 0;
-    int rc = set_lds(block_bwd_dx_kernel, smem, &seen);
+    static size_t seen = 0, seen_c = 0;
+    int rc = gmax == 1 ? set_lds(block_bwd_dx_kernel, smem, &seen) : set_lds(block_bwd_dx_cluster_kernel, smem, &seen_c);
     if (rc) return rc;
-    hipLaunchKernelGGL(block_bwd_dx_kernel, dim3(nwg_max, n), dim3(NT), smem, st, g);
-    PV_LAUNCH_CHECK("block_bwd_dx_kernel");
+    if (gmax == 1) {
+      BlockBwdGroup1 g1;
+      for (int b = 0; b < PV_BLOCK_GROUP_MAX; ++b) {
+        const BlockBwdArgs& a = g.a[b];
+        g1.a[b] = BlockBwdArgs1{a.dout, a.lddo, a.x, a.ldx, a.out, a.ldo, a.M, a.d, a.save, a.mean, a.rstd, a.dx, a.lddx, a.dY,
+                                a.cpart, a.ppart, a.LD};
+      }
+      hipLaunchKernelGGL(block_bwd_dx_kernel, dim3(nwg_max, n), dim3(NT), smem, st, g1);
+      PV_LAUNCH_CHECK("block_bwd_dx_kernel");
+    } else {
+      g.slab_stride = round_up(nwg_max, 8);
+      hipLaunchKernelGGL(block_bwd_dx_cluster_kernel, dim3(g.slab_stride * gmax, n), dim3(NT), smem, st, g);
+      PV_LAUNCH_CHECK("block_bwd_dx_cluster_kernel");
+    }
   }
   if (!(phase & 2)) return PV_OK;
   // the 5 n weight-gradient GEMMs in one launch, the bias / LayerNorm-parameter reductions riding on it

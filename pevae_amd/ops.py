@@ -1716,7 +1716,7 @@ class BlockGroupFn(torch.autograd.Function):
             nwg = (M + 15) // 16
             dx = torch.empty((M, din), dtype=torch.float32, device=dev)
             dY = torch.empty((M, gw), dtype=torch.float32, device=dev)
-            cpart = torch.empty(5 * nwg, dtype=torch.float32, device=dev)
+            cpart = torch.empty(5 * 4 * nwg, dtype=torch.float32, device=dev)      # (a cluster member each: pevae_hip.h)
             ppart = torch.empty((nwg, pw), dtype=torch.float32, device=dev)
             params = list(p_W) + list(p_bias) + [p_g, p_b]
             sinks = [grad_sink(p, tuple(p.shape)) for p in params]
