@@ -36,6 +36,7 @@ def parse():
                     help="BASELINE.json configs: yelp = configs[1]; movie = configs[2] (8k x 8k tables, decoder attention); "
                          "book = configs[3] (200k users, 100k items); mutual = configs[4] (--use_mutual + --do_pred)")
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps cycle through")
+    ap.add_argument("--force-split", type=int, default=0, help="run the N > 1 schedule (cut backward, three graphs) at N = 1")
     ap.add_argument("--overlap", type=int, default=1, help="N > 1: start the vocabulary gradient's all-reduce before the rest of the backward pass")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--graph", type=int, default=1, help="replay fwd+bwd / optimizer from HIP graphs")
@@ -108,7 +109,7 @@ def main():
     # N > 1: the backward pass is cut after the vocabulary projection so that its gradient's all-reduce can start early
     # (north star item 5).  N = 1: nothing is exchanged, so the backward pass stays whole and the vocabulary projection's
     # weight gradient leaves the critical path instead (ops.defer_after_recurrence: it runs beside the latent stack).
-    split = world > 1 and bool(args.overlap)
+    split = (world > 1 and bool(args.overlap)) or bool(args.force_split)
     model.split_backward = split
     # the flat gradient holds the SUM over ranks; 1/world is applied inside the guard / Adam kernels
     opt = FlatAdam(model.parameters(), lr=cfg.init_lr, max_norm=cfg.grad_clip, warmup_steps=cfg.warmup_steps,
