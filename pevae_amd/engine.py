@@ -110,6 +110,73 @@ def make_optimizer(model, config, phase2=False):
                     warmup_steps=getattr(config, "warmup_steps", 0), weight_decay=0.01 if phase2 else 0.0)
 
 
+class GraphedStep(object):
+    """zero_grad + forward + backward of one training batch replayed from a HIP graph (config.use_graph).
+
+    An eager step pays ~230 ctypes calls and as many launches' worth of host work; the device needs 3.5 ms for it.  The
+    first `warmup` batches of every (mode, phase, batch shape) run eagerly -- they are real steps: they allocate every
+    workspace and take the lazy paths once --, the next one is CAPTURED (torch.cuda.graph) on static copies of its
+    tensors and then replayed, and from then on a step is: copy the batch into the static tensors, one graph launch.
+    Everything that decides something stays where it was: the guards / clip / Adam run in optimizer.step() outside the
+    graph (the learning rate is a host value that changes at evaluations), the skip flag is read back as before.  New
+    dropout masks every replay: the generator's step counter lives in device memory and is advanced inside the graph;
+    torch's own generator (the uniform draws of DLS_Auto) is graph-safe.  The loss Pack handed back holds CLONES of the
+    static scalars (the next replay overwrites those).  Batches of another shape (a ragged last batch) or in GEN mode run
+    eagerly.  Everything -- warm-up, capture, replay and the eager fall-backs -- must run on ONE non-default stream
+    (autograd ties a node to the stream it was created on; the legacy default stream cannot take part in a capture):
+    train() enters `self.stream` for the whole loop."""
+
+    def __init__(self, model, warmup=2):
+        self.model, self.warmup = model, warmup
+        self.stream = torch.cuda.Stream()
+        self.seen, self.graphs = defaultdict(int), {}
+        self.pool = None
+
+    def invalidate(self):
+        """The set of trained parameters changed (freeze phase): every captured graph is stale."""
+        self.seen.clear()
+        self.graphs.clear()
+
+    @staticmethod
+    def _key(batch, mode, model):
+        sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+        return (mode, bool(getattr(model, "restarted", False)), sig)
+
+    def _eager(self, optimizer, batch, mode, batch_cnt):
+        optimizer.zero_grad()
+        loss = self.model(batch, mode=mode)
+        self.model.backward(batch_cnt, loss, step=batch_cnt)
+        return loss
+
+    def __call__(self, optimizer, batch, mode, batch_cnt):
+        tensors = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        if mode != TEACH_FORCE or not tensors or not all(v.is_cuda for v in tensors.values()):
+            return self._eager(optimizer, batch, mode, batch_cnt)
+        key = self._key(batch, mode, self.model)
+        entry = self.graphs.get(key)
+        if entry is None:
+            self.seen[key] += 1
+            if self.seen[key] <= self.warmup:
+                return self._eager(optimizer, batch, mode, batch_cnt)
+            import gc
+            gc.collect()                                   # no autograd graph of an eager step may be alive during capture
+            static = dict(batch)
+            static.update({k: v.clone() for k, v in tensors.items()})
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+                out = self._eager(optimizer, static, mode, batch_cnt)
+            if self.pool is None:
+                self.pool = graph.pool()
+            entry = self.graphs[key] = (graph, static, out)
+            from . import ops
+            ops.LAST_GRU_SYNC.clear()                      # (sync words of captured launches are rewritten by every replay)
+        graph, static, out = entry
+        for k, v in tensors.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return type(out)({k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in out.items()})
+
+
 def _check_recurrence():
     """A timed-out wait inside a persistent GRU / LSTM launch is reported through an error word only; read the words of
     the recent launches at every evaluation so that a run cannot continue on garbage states (one small read-back)."""
@@ -119,6 +186,19 @@ def _check_recurrence():
 
 
 def train(model, train_feed, valid_feed, config, max_evals=None, checkpoint=None, optimizer_factory=None, trace=None):
+    """main_pretrain.train (:148-371); see _train_loop.  config.use_graph (GPU only): the zero_grad + forward + backward
+    of every regular batch is replayed from a HIP graph (GraphedStep) and the whole loop runs on that object's stream."""
+    if getattr(config, "use_graph", False) and torch.cuda.is_available():
+        graphed = GraphedStep(model)
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.stream(graphed.stream):
+            history = _train_loop(model, train_feed, valid_feed, config, max_evals, checkpoint, optimizer_factory, trace, graphed)
+            graphed.stream.synchronize()
+        return history
+    return _train_loop(model, train_feed, valid_feed, config, max_evals, checkpoint, optimizer_factory, trace, None)
+
+
+def _train_loop(model, train_feed, valid_feed, config, max_evals, checkpoint, optimizer_factory, trace, graphed):
     """Runs until the reference's stop rule (done_epoch > 100, :184; five evaluations after the freeze phase add 100,
     :333-334) or `max_evals` evaluations.  Returns the history of (batch_cnt, valid_loss, lr) per evaluation.
     config fields used (the reference's names): init_lr, grad_clip, batch_size, teach_force_bound, freeze_step,
@@ -187,11 +267,14 @@ def train(model, train_feed, valid_feed, config, max_evals=None, checkpoint=None
             batch = train_feed.next_batch()
             if batch is None:
                 break
-            optimizer.zero_grad()
             model.steps = batch_cnt + len(pending)
             mode = TEACH_FORCE if done_epoch < config.teach_force_bound else GEN
-            loss = model(batch, mode=mode)
-            model.backward(batch_cnt, loss, step=batch_cnt)
+            if graphed is not None:
+                loss = graphed(optimizer, batch, mode, batch_cnt)
+            else:
+                optimizer.zero_grad()
+                loss = model(batch, mode=mode)
+                model.backward(batch_cnt, loss, step=batch_cnt)
             nstep += 1
             if freeze_step is not None and not model.restarted and batch_cnt + len(pending) >= freeze_step:
                 settle(True)
@@ -217,6 +300,8 @@ def train(model, train_feed, valid_feed, config, max_evals=None, checkpoint=None
                             p.requires_grad = False
                             p.grad = None
                     optimizer = factory(model, config, True)             # :257 get_freeze_optimizer (AdamW)
+                    if graphed is not None:
+                        graphed.invalidate()
                     learning_rate = config.init_lr
                     batch_cnt = 0
                     continue

@@ -65,6 +65,45 @@ def test_train_validate_freeze_phase(dev, tmp_path):
     assert all(h[2] <= cfg.init_lr for h in hist)
 
 
+def test_train_with_graph_replay(dev, tmp_path):
+    """config.use_graph: after two eager batches per (phase, shape) the zero_grad + forward + backward of a step is a
+    replayed HIP graph (engine.GraphedStep).  Same loop, same decisions: both phases are walked, the counters agree with
+    the eager run, the validation losses fall, a repeated run reproduces every number bit for bit (dropout 0, the
+    uniform draws of the DLS stack come from torch's graph-safe generator re-seeded the same way), and the graphed run's
+    losses agree with the eager run's to what a different random stream allows."""
+    from pevae_amd import engine
+    from pevae_amd.dataset import YELPDataLoader, build_vocab
+    from pevae_amd.dls_vae import DLSVAE, default_config
+    train_rows, valid_rows = _rows(192, 1, 60, 10), _rows(48, 2, 60, 10)
+    vocab, rev, _ = build_vocab((train_rows, valid_rows), 100)
+
+    def run(use_graph, tag):
+        cfg = default_config(vocab_size=len(vocab), embed_size=32, dec_cell_size=64, max_seq_len=12, n_user=30, n_item=20,
+                             latent_size=16, dropout=0.0, batch_size=32, init_lr=3e-3, grad_clip=5.0, seed=0,
+                             teach_force_bound=1000, freeze_step=12, ckpt_step=6, print_step=3, lr_decay_rate=0.8,
+                             improve_threshold=0.996, patient_increase=2.0, exp_name="t", fix_batch=False,
+                             latent_stack="dls", use_graph=use_graph)
+        torch.manual_seed(0)
+        random.seed(0)
+        np.random.seed(0)
+        model = DLSVAE(cfg).to(dev)
+        tf = YELPDataLoader("train", train_rows, cfg).attach(rev, dev)
+        vf = YELPDataLoader("valid", valid_rows, cfg).attach(rev, dev)
+        hist = engine.train(model, tf, vf, cfg, max_evals=4, checkpoint=os.path.join(str(tmp_path), tag + ".pt"))
+        torch.cuda.synchronize()
+        return hist, model
+
+    h_graph, m_graph = run(True, "g1")
+    h_again, _ = run(True, "g2")
+    h_eager, _ = run(False, "e")
+    assert len(h_graph) == 4 and m_graph.restarted
+    assert [h[0] for h in h_graph] == [h[0] for h in h_eager]            # evaluations at the same batch counts
+    assert h_graph[1][1] < h_graph[0][1]                                 # it learns
+    assert h_graph == h_again                                            # replay is deterministic
+    for (_, a, _), (_, b, _) in zip(h_graph, h_eager):
+        assert abs(a - b) <= 0.05 * abs(b), (h_graph, h_eager)
+
+
 def test_engine_skip_sequence_matches_reference_on_the_device(dev, tmp_path):
     """The real FlatAdam (guards and Adam on the device, skip flags read back asynchronously) under engine.train against
     the reference's control flow (oracle/ref_engine.py <- main_pretrain.py:148-371): the gradient norm of every step is
