@@ -14,7 +14,8 @@ import statistics
 import sys
 
 KERNELS = ["vocab_fwd_dh_kernel", "vocab_fwd_combine_kernel", "vocab_dw_kernel", "vocab_dw_reduce_kernel", "gemm_nt_kernel",
-           "gemm_nt_ct_kernel", "gru_fwd_kernel", "gru_bwd_kernel", "block_fwd_kernel", "block_bwd_dx_kernel",
+           "gemm_nt_ct_kernel", "gru_fwd_kernel", "gru_bwd_kernel", "block_fwd_kernel", "block_fwd_cluster_kernel",
+           "block_bwd_dx_kernel", "block_bwd_dx_cluster_kernel",
            "linear_f32_group_kernel", "gather_kernel", "segment_sum_kernel", "adam_kernel", "sumsq_kernel",
            "dls_level_fwd_kernel", "dls_level_bwd_kernel", "dropout_kernel", "cast_pack_vec4_kernel"]
 VOCAB = KERNELS[:4]
