@@ -341,6 +341,15 @@ int pv_dls_level_fwd(const float* Q, const float* Pr, const float* a2, const flo
 int pv_dls_level_bwd(const float* Q, const float* Pr, const float* eps, const float* d_ls, const float* d_out,
                      const float* g_kl, int B, int n, float ew, float cw, float* dQ, float* dPr, float* da2, float* dlay,
                      void* stream);
+/* pv_dls_level_fwd / _bwd that also form the NEXT level's Block inputs (:3289-3297) in the same launch: q_in [B][wn + n] =
+ * [a1n + a2n | ls], p_in = [a2n | t_mean] (t_mean = the first n columns of Pr); backward takes dq_in / dp_in (either may be
+ * NULL) and also emits da1n, da2n [B][wn].  q_in == NULL (da1n == NULL): exactly pv_dls_level_fwd (_bwd). */
+int pv_dls_level_next_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
+                          float ew, float cw, float* ls, float* out, float* kl, float* kl_part, const float* a1n,
+                          const float* a2n, int wn, float* q_in, float* p_in, void* stream);
+int pv_dls_level_next_bwd(const float* Q, const float* Pr, const float* eps, const float* d_ls, const float* d_out,
+                          const float* g_kl, int B, int n, float ew, float cw, float* dQ, float* dPr, float* da2, float* dlay,
+                          const float* dq_in, const float* dp_in, int wn, float* da1n, float* da2n, void* stream);
 int pv_dls_inputs_fwd(const float* a1, const float* a2, const float* ls, const float* lt, int B, int w, int e, float* q_in,
                       float* p_in, void* stream);
 int pv_dls_inputs_bwd(const float* dq, const float* dp, int B, int w, int e, float* da1, float* da2, float* dls, float* dlt,

@@ -68,6 +68,8 @@ SIGNATURES = {
     "pv_block_sync_error": (i32, [C.POINTER(i32)]),
     "pv_dls_level_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
     "pv_dls_level_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
+    "pv_dls_level_next_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "pv_dls_level_next_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "pv_dls_inputs_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "pv_dls_inputs_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "pv_lstm_geometry": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),

@@ -460,10 +460,21 @@ __global__ __launch_bounds__(256) void dls_level_fwd_kernel(const float* __restr
                                                              const float* __restrict__ a2, const float* __restrict__ eps,
                                                              const float* __restrict__ lay, int B, int n, float ew, float cw,
                                                              float* __restrict__ ls, float* __restrict__ out,
-                                                             float* __restrict__ part, int per_wg) {
+                                                             float* __restrict__ part, int per_wg,
+                                                             const float* __restrict__ a1n, const float* __restrict__ a2n, int wn,
+                                                             float* __restrict__ q_in, float* __restrict__ p_in) {
   __shared__ float red[256];
   float acc = 0.f;
   const int lo = blockIdx.x * per_wg, hi = min(B * n, lo + per_wg);
+  const int Wn = wn + n;
+  if (q_in) {            // the next level's inputs (:3289-3297): q_in = [a1' + a2' | ls], p_in = [a2' | t_mean]
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * wn; i += gridDim.x * 256) {
+      const int b = i / wn, c = i % wn;
+      const float x2 = a2n[i];
+      q_in[(size_t)b * Wn + c] = a1n[i] + x2;
+      p_in[(size_t)b * Wn + c] = x2;
+    }
+  }
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const int b = i / n, d = i % n;
     const float m = Q[(size_t)b * 2 * n + d], l = Q[(size_t)b * 2 * n + n + d];
@@ -471,6 +482,10 @@ __global__ __launch_bounds__(256) void dls_level_fwd_kernel(const float* __restr
     const float s = m + expf(l) * eps[i] + a2[i];
     ls[i] = s;
     out[i] = lay[i] + s;
+    if (q_in) {
+      q_in[(size_t)b * Wn + wn + d] = s;
+      p_in[(size_t)b * Wn + wn + d] = tm;
+    }
     const float diff = tm - m;
     acc += -0.5f + l - tl + 0.5f * (expf(2.f * tl) + diff * diff) * expf(-2.f * l);     // KL(t || q), log-sigma inputs
   }
@@ -488,18 +503,30 @@ __global__ void dls_level_bwd_kernel(const float* __restrict__ Q, const float* _
                                      const float* __restrict__ d_ls, const float* __restrict__ d_out,
                                      const float* __restrict__ g_kl, int B, int n, float ew, float cw,
                                      float* __restrict__ dQ, float* __restrict__ dPr, float* __restrict__ da2,
-                                     float* __restrict__ dlay) {
+                                     float* __restrict__ dlay, const float* __restrict__ dq_in, const float* __restrict__ dp_in,
+                                     int wn, float* __restrict__ da1n, float* __restrict__ da2n) {
   const float g = g_kl ? g_kl[0] / B : 0.f;
+  const int Wn = wn + n;
+  if (da1n) {            // through the next level's inputs: q_in = [a1' + a2' | ls], p_in = [a2' | t_mean]
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * wn; i += gridDim.x * blockDim.x) {
+      const int b = i / wn, c = i % wn;
+      const float gq = dq_in ? dq_in[(size_t)b * Wn + c] : 0.f, gp = dp_in ? dp_in[(size_t)b * Wn + c] : 0.f;
+      da1n[i] = gq;
+      da2n[i] = gq + gp;
+    }
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * n; i += gridDim.x * blockDim.x) {
     const int b = i / n, d = i % n;
     const size_t im = (size_t)b * 2 * n + d, il = im + n;
     const float m = Q[im], l = Q[il], tm = Pr[im], tl = Pr[il];
-    const float go = d_out ? d_out[i] : 0.f, gs = (d_ls ? d_ls[i] : 0.f) + go;
+    const float gls = (d_ls ? d_ls[i] : 0.f) + (da1n && dq_in ? dq_in[(size_t)b * Wn + wn + d] : 0.f);
+    const float gtm = da1n && dp_in ? dp_in[(size_t)b * Wn + wn + d] : 0.f;
+    const float go = d_out ? d_out[i] : 0.f, gs = gls + go;
     const float diff = tm - m, ip2 = expf(-2.f * l), e2t = expf(2.f * tl);
     // posterior (m, l) is "2" of KL(1 || 2), weight cw; prior (tm, tl) is "1", weight ew
     dQ[im] = gs + g * cw * (-diff * ip2);
     dQ[il] = gs * expf(l) * eps[i] + g * cw * (1.f - (e2t + diff * diff) * ip2);
-    dPr[im] = g * ew * (diff * ip2);
+    dPr[im] = gtm + g * ew * (diff * ip2);
     dPr[il] = g * ew * (-1.f + e2t * ip2);
     da2[i] = gs;
     dlay[i] = go;
@@ -546,14 +573,21 @@ extern "C" {
 
 int pv_dls_level_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
                      float ew, float cw, float* ls, float* out, float* kl, float* kl_part, void* stream) {
+  return pv_dls_level_next_fwd(Q, Pr, a2, eps, lay, B, n, ew, cw, ls, out, kl, kl_part, nullptr, nullptr, 0, nullptr, nullptr, stream);
+}
+
+int pv_dls_level_next_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
+                          float ew, float cw, float* ls, float* out, float* kl, float* kl_part, const float* a1n,
+                          const float* a2n, int wn, float* q_in, float* p_in, void* stream) {
   PV_REQUIRE(Q && Pr && a2 && eps && lay && ls && out && kl && kl_part && B > 0 && n > 0, "pv_dls_level_fwd: bad argument");
+  PV_REQUIRE(!q_in || (a1n && a2n && p_in && wn > 0), "pv_dls_level_next_fwd: the next level's inputs need a1n, a2n, p_in, wn");
   const long total = (long)B * n;
   PV_REQUIRE(total < (1l << 31), "pv_dls_level_fwd: B * n too large");
   int wgs = (int)((total + DLS_WG_ELEMS - 1) / DLS_WG_ELEMS);
   if (wgs > DLS_MAX_PART) wgs = DLS_MAX_PART;
   const int per = (int)((total + wgs - 1) / wgs);
   hipLaunchKernelGGL(dls_level_fwd_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, Q, Pr, a2, eps, lay, B, n, ew, cw, ls,
-                     out, kl_part, per);
+                     out, kl_part, per, a1n, a2n, wn, q_in, p_in);
   PV_LAUNCH_CHECK("dls_level_fwd_kernel");
   hipLaunchKernelGGL(dls_level_kl_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_part, wgs, (ew + cw) / B, kl);
   PV_LAUNCH_CHECK("dls_level_kl_kernel");
@@ -563,9 +597,17 @@ int pv_dls_level_fwd(const float* Q, const float* Pr, const float* a2, const flo
 int pv_dls_level_bwd(const float* Q, const float* Pr, const float* eps, const float* d_ls, const float* d_out,
                      const float* g_kl, int B, int n, float ew, float cw, float* dQ, float* dPr, float* da2, float* dlay,
                      void* stream) {
+  return pv_dls_level_next_bwd(Q, Pr, eps, d_ls, d_out, g_kl, B, n, ew, cw, dQ, dPr, da2, dlay, nullptr, nullptr, 0, nullptr,
+                               nullptr, stream);
+}
+
+int pv_dls_level_next_bwd(const float* Q, const float* Pr, const float* eps, const float* d_ls, const float* d_out,
+                          const float* g_kl, int B, int n, float ew, float cw, float* dQ, float* dPr, float* da2, float* dlay,
+                          const float* dq_in, const float* dp_in, int wn, float* da1n, float* da2n, void* stream) {
   PV_REQUIRE(Q && Pr && eps && dQ && dPr && da2 && dlay && B > 0 && n > 0, "pv_dls_level_bwd: bad argument");
-  hipLaunchKernelGGL(dls_level_bwd_kernel, dim3(grid_for((long)B * n, 256)), dim3(256), 0, (hipStream_t)stream, Q, Pr, eps,
-                     d_ls, d_out, g_kl, B, n, ew, cw, dQ, dPr, da2, dlay);
+  PV_REQUIRE(!da1n || (da2n && wn > 0), "pv_dls_level_next_bwd: the next level's input gradients need da2n and wn");
+  hipLaunchKernelGGL(dls_level_bwd_kernel, dim3(grid_for((long)B * (n > wn ? n : wn), 256)), dim3(256), 0, (hipStream_t)stream,
+                     Q, Pr, eps, d_ls, d_out, g_kl, B, n, ew, cw, dQ, dPr, da2, dlay, dq_in, dp_in, wn, da1n, da2n);
   PV_LAUNCH_CHECK("dls_level_bwd_kernel");
   return PV_OK;
 }

@@ -182,7 +182,7 @@ class DLSAuto(nn.Module):
             rkl = scaled(ops.cons_loss_sum([(output, rec_output)] + [(act1[-i - 1], act2[-i - 1]) for i in range(nl)]))
         else:
             rkl = scaled(ops.cons_loss(output, rec_output))
-        last_sample = last_t = None
+        last_sample = last_t = nxt = None
         if noise is None and not restarted and not getattr(cfg, "ost", False):
             # the uniform draws of every level (:3206-3207) in one launch
             a2s = [act2[-i - 1] for i in range(len(self.layers))]
@@ -196,6 +196,8 @@ class DLSAuto(nn.Module):
             train_branch = not restarted and not getattr(cfg, "ost", False)
             if last_sample is None:
                 q_in, p_in = a1 + a2, a2
+            elif train_branch and nxt is not None:
+                q_in, p_in = nxt                                     # formed by the previous level's DlsLevelNext launch
             elif train_branch:
                 q_in, p_in = ops.DlsInputs.apply(a1, a2, last_sample, last_t)
             else:
@@ -210,8 +212,15 @@ class DLSAuto(nn.Module):
                 mean, lv = res[2].chunk(2, -1)
             if train_branch:
                 eps = noise[i] if noise is not None else torch.rand(a2.shape, device=a2.device, dtype=a2.dtype)
-                # sample (:3292/:3299-3300), output (:3310) and ew * KL(t || q.detach) + cw * KL(t.detach || q) (:3305-3306)
-                last_sample, output, klw = ops.DlsLevel.apply(res[2], res[0], a2, eps, lay_out, float(ew), float(cw))
+                # sample (:3292/:3299-3300), output (:3310) and ew * KL(t || q.detach) + cw * KL(t.detach || q) (:3305-3306);
+                # all but the last level also form the next level's Block inputs (:3289-3297) in the same launch
+                if i + 1 < len(self.layers):
+                    last_sample, output, klw, q_n, p_n = ops.DlsLevelNext.apply(res[2], res[0], a2, eps, lay_out, float(ew),
+                                                                                float(cw), act1[-i - 2], act2[-i - 2])
+                    nxt = (q_n, p_n)
+                else:
+                    last_sample, output, klw = ops.DlsLevel.apply(res[2], res[0], a2, eps, lay_out, float(ew), float(cw))
+                    nxt = None
                 last_t = t_mean
                 rkl = rkl + klw if batched else rkl + klw + scaled(ops.cons_loss(a1, a2))          # :3307
             else:
