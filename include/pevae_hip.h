@@ -347,6 +347,11 @@ int pv_dls_level_bwd(const float* Q, const float* Pr, const float* eps, const fl
 int pv_dls_level_next_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
                           float ew, float cw, float* ls, float* out, float* kl, float* kl_part, const float* a1n,
                           const float* a2n, int wn, float* q_in, float* p_in, void* stream);
+/* ... and kl[0] = kl_add[0] + the level's KL term (kl_add != NULL): the running loss is carried through the levels without an
+ * add launch per level (the gradient of kl_add is the gradient of kl). */
+int pv_dls_level_next_add_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
+                              float ew, float cw, float* ls, float* out, float* kl, float* kl_part, const float* a1n,
+                              const float* a2n, int wn, float* q_in, float* p_in, const float* kl_add, void* stream);
 int pv_dls_level_next_bwd(const float* Q, const float* Pr, const float* eps, const float* d_ls, const float* d_out,
                           const float* g_kl, int B, int n, float ew, float cw, float* dQ, float* dPr, float* da2, float* dlay,
                           const float* dq_in, const float* dp_in, int wn, float* da1n, float* da2n, void* stream);

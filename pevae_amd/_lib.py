@@ -69,6 +69,7 @@ SIGNATURES = {
     "pv_dls_level_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
     "pv_dls_level_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
     "pv_dls_level_next_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "pv_dls_level_next_add_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "pv_dls_level_next_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "pv_dls_inputs_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "pv_dls_inputs_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),

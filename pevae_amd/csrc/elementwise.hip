@@ -447,13 +447,13 @@ namespace {
 // widest level (B * n = 131072).
 constexpr int DLS_WG_ELEMS = 2048, DLS_MAX_PART = 256;
 __global__ __launch_bounds__(64) void dls_level_kl_kernel(const float* __restrict__ part, int nparts, float scale,
-                                                          float* __restrict__ kl) {
+                                                          float* __restrict__ kl, const float* __restrict__ add) {
   float s = 0.f;
   for (int i0 = 0; i0 < nparts; i0 += 64) {                 // 64 partials per load, added in index order
     const float v = i0 + (int)threadIdx.x < nparts ? part[i0 + threadIdx.x] : 0.f;
     for (int k = 0; k < 64 && i0 + k < nparts; ++k) s += __shfl(v, k);
   }
-  if (threadIdx.x == 0) kl[0] = scale * s;
+  if (threadIdx.x == 0) kl[0] = add ? add[0] + scale * s : scale * s;      // (add: the running loss this term joins)
 }
 
 __global__ __launch_bounds__(256) void dls_level_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Pr,
@@ -579,6 +579,13 @@ int pv_dls_level_fwd(const float* Q, const float* Pr, const float* a2, const flo
 int pv_dls_level_next_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
                           float ew, float cw, float* ls, float* out, float* kl, float* kl_part, const float* a1n,
                           const float* a2n, int wn, float* q_in, float* p_in, void* stream) {
+  return pv_dls_level_next_add_fwd(Q, Pr, a2, eps, lay, B, n, ew, cw, ls, out, kl, kl_part, a1n, a2n, wn, q_in, p_in, nullptr,
+                                   stream);
+}
+
+int pv_dls_level_next_add_fwd(const float* Q, const float* Pr, const float* a2, const float* eps, const float* lay, int B, int n,
+                              float ew, float cw, float* ls, float* out, float* kl, float* kl_part, const float* a1n,
+                              const float* a2n, int wn, float* q_in, float* p_in, const float* kl_add, void* stream) {
   PV_REQUIRE(Q && Pr && a2 && eps && lay && ls && out && kl && kl_part && B > 0 && n > 0, "pv_dls_level_fwd: bad argument");
   PV_REQUIRE(!q_in || (a1n && a2n && p_in && wn > 0), "pv_dls_level_next_fwd: the next level's inputs need a1n, a2n, p_in, wn");
   const long total = (long)B * n;
@@ -589,7 +596,7 @@ int pv_dls_level_next_fwd(const float* Q, const float* Pr, const float* a2, cons
   hipLaunchKernelGGL(dls_level_fwd_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, Q, Pr, a2, eps, lay, B, n, ew, cw, ls,
                      out, kl_part, per, a1n, a2n, wn, q_in, p_in);
   PV_LAUNCH_CHECK("dls_level_fwd_kernel");
-  hipLaunchKernelGGL(dls_level_kl_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_part, wgs, (ew + cw) / B, kl);
+  hipLaunchKernelGGL(dls_level_kl_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_part, wgs, (ew + cw) / B, kl, kl_add);
   PV_LAUNCH_CHECK("dls_level_kl_kernel");
   return PV_OK;
 }

@@ -214,15 +214,20 @@ class DLSAuto(nn.Module):
                 eps = noise[i] if noise is not None else torch.rand(a2.shape, device=a2.device, dtype=a2.dtype)
                 # sample (:3292/:3299-3300), output (:3310) and ew * KL(t || q.detach) + cw * KL(t.detach || q) (:3305-3306);
                 # all but the last level also form the next level's Block inputs (:3289-3297) in the same launch
-                if i + 1 < len(self.layers):
-                    last_sample, output, klw, q_n, p_n = ops.DlsLevelNext.apply(res[2], res[0], a2, eps, lay_out, float(ew),
-                                                                                float(cw), act1[-i - 2], act2[-i - 2])
-                    nxt = (q_n, p_n)
+                more = i + 1 < len(self.layers)
+                if batched:
+                    # the running loss rides through the level kernels (rkl <- rkl + klw inside the launch)
+                    rkl_t = rkl if torch.is_tensor(rkl) else None
+                    last_sample, output, rkl_new, q_n, p_n = ops.DlsLevelNext.apply(
+                        res[2], res[0], a2, eps, lay_out, float(ew), float(cw), act1[-i - 2] if more else None,
+                        act2[-i - 2] if more else None, rkl_t)
+                    rkl = rkl_new if rkl_t is not None else rkl + rkl_new
+                    nxt = (q_n, p_n) if more else None
                 else:
                     last_sample, output, klw = ops.DlsLevel.apply(res[2], res[0], a2, eps, lay_out, float(ew), float(cw))
                     nxt = None
+                    rkl = rkl + klw + scaled(ops.cons_loss(a1, a2))                                  # :3307
                 last_t = t_mean
-                rkl = rkl + klw if batched else rkl + klw + scaled(ops.cons_loss(a1, a2))          # :3307
             else:
                 if self.training:
                     eps = noise[i] if noise is not None else torch.rand_like(t_lv)

@@ -1842,26 +1842,32 @@ class DlsLevel(torch.autograd.Function):
 
 
 class DlsLevelNext(torch.autograd.Function):
-    """DlsLevel plus the NEXT level's Block inputs in the same launch each way: (Q, Pr, a2, eps, lay, a1n, a2n) ->
-    (last_sample, output, kl term, q_in = [a1n + a2n | last_sample], p_in = [a2n | t_mean]).  Saves the DlsInputs launches
-    and, backward, the chunk / zero-fill / accumulate launches autograd spends on t_mean's second consumer."""
+    """DlsLevel plus, in the same launch each way, the NEXT level's Block inputs (a1n, a2n given) and the running loss
+    (rkl_in given): (Q, Pr, a2, eps, lay, a1n, a2n, rkl_in) -> (last_sample, output, rkl_in + kl term, q_in = [a1n + a2n |
+    last_sample], p_in = [a2n | t_mean]).  Saves the DlsInputs launches, the scalar add per level and, backward, the chunk /
+    zero-fill / accumulate launches autograd spends on t_mean's second consumer."""
 
     @staticmethod
-    def forward(ctx, Q, Pr, a2, eps, lay, ew, cw, a1n, a2n):
-        _need_cuda(Q, Pr, a2, eps, lay, a1n, a2n)
-        Q, Pr, a2, eps, lay, a1n, a2n = [t.contiguous() for t in (Q, Pr, a2, eps, lay, a1n, a2n)]
+    def forward(ctx, Q, Pr, a2, eps, lay, ew, cw, a1n, a2n, rkl_in):
+        _need_cuda(Q, Pr, a2, eps, lay, a1n, a2n, rkl_in)
+        Q, Pr, a2, eps, lay = [t.contiguous() for t in (Q, Pr, a2, eps, lay)]
         B, n = a2.shape
-        wn = a1n.shape[1]
         dev = Q.device
         ls = torch.empty((B, n), dtype=torch.float32, device=dev)
         out = torch.empty((B, n), dtype=torch.float32, device=dev)
         kl = torch.empty(1, dtype=torch.float32, device=dev)
-        q_in = torch.empty((B, wn + n), dtype=torch.float32, device=dev)
-        p_in = torch.empty((B, wn + n), dtype=torch.float32, device=dev)
-        _lib.call("pv_dls_level_next_fwd", _p(Q), _p(Pr), _p(a2), _p(eps), _p(lay), B, n, ew, cw, _p(ls), _p(out), _p(kl),
-                  _p(workspace("dls_level_kl_part", 256, torch.float32, dev)), _p(a1n), _p(a2n), wn, _p(q_in), _p(p_in), _stream())
+        wn, q_in, p_in = 0, None, None
+        if a1n is not None:
+            a1n, a2n = a1n.contiguous(), a2n.contiguous()
+            wn = a1n.shape[1]
+            q_in = torch.empty((B, wn + n), dtype=torch.float32, device=dev)
+            p_in = torch.empty((B, wn + n), dtype=torch.float32, device=dev)
+        add = None if rkl_in is None else rkl_in.detach().reshape(1).to(torch.float32)
+        _lib.call("pv_dls_level_next_add_fwd", _p(Q), _p(Pr), _p(a2), _p(eps), _p(lay), B, n, ew, cw, _p(ls), _p(out), _p(kl),
+                  _p(workspace("dls_level_kl_part", 256, torch.float32, dev)), _p(a1n), _p(a2n), wn, _p(q_in), _p(p_in), _p(add),
+                  _stream())
         ctx.save_for_backward(Q, Pr, eps)
-        ctx.w = (ew, cw, wn)
+        ctx.w = (ew, cw, wn, rkl_in is not None)
         ctx.set_materialize_grads(False)
         return ls, out, kl.view(()), q_in, p_in
 
@@ -1869,15 +1875,17 @@ class DlsLevelNext(torch.autograd.Function):
     def backward(ctx, d_ls, d_out, g_kl, dq_in, dp_in):
         Q, Pr, eps = ctx.saved_tensors
         B, n = eps.shape
-        ew, cw, wn = ctx.w
+        ew, cw, wn, has_add = ctx.w
         dQ, dPr = torch.empty_like(Q), torch.empty_like(Pr)
         da2, dlay = torch.empty_like(eps), torch.empty_like(eps)
-        da1n = torch.empty((B, wn), dtype=torch.float32, device=Q.device)
-        da2n = torch.empty((B, wn), dtype=torch.float32, device=Q.device)
+        da1n = da2n = None
+        if wn:
+            da1n = torch.empty((B, wn), dtype=torch.float32, device=Q.device)
+            da2n = torch.empty((B, wn), dtype=torch.float32, device=Q.device)
         c = lambda t: None if t is None else t.contiguous()
         _lib.call("pv_dls_level_next_bwd", _p(Q), _p(Pr), _p(eps), _p(c(d_ls)), _p(c(d_out)), _p(c(g_kl)), B, n, ew, cw, _p(dQ),
                   _p(dPr), _p(da2), _p(dlay), _p(c(dq_in)), _p(c(dp_in)), wn, _p(da1n), _p(da2n), _stream())
-        return dQ, dPr, da2, None, dlay, None, None, da1n, da2n
+        return dQ, dPr, da2, None, dlay, None, None, da1n, da2n, (g_kl if has_add else None)
 
 
 class DlsInputs(torch.autograd.Function):
