@@ -869,6 +869,7 @@ class GRULayer(torch.autograd.Function):
         LAST_GRU_SYNC.append((sync, NG, "pv_gru_fwd"))
         ctx.dims = (B, L, E, H, Hk, K3, Bpad, NG, Ep)
         ctx.params = (w_ih, w_hh)
+        ctx.bias_params = (b_ih, b_hh)
         ctx.has_h0 = h0 is not None
         ctx.sync = sync
         ctx.mark_non_differentiable(hseq)
@@ -934,6 +935,16 @@ class GRULayer(torch.autograd.Function):
             dw_ih = dw_hh = None
         else:
             dw_ih, dw_hh = wgrads()
+        # the bias gradients: with sinks, the two accumulation adds leave the critical path as well (autograd would run
+        # them as AccumulateGrad kernels right behind this node)
+        sb_ih, sb_hh = ctx.bias_params
+        k_ih, k_hh = grad_sink(sb_ih, (3 * H,)), grad_sink(sb_hh, (3 * H,))
+        if sinks and k_ih is not None and k_hh is not None and ASYNC_WGRAD:
+            def bias_adds(a=db_ih, b=db_hh):
+                k_ih.add_(a)
+                k_hh.add_(b)
+            defer_side_work(bias_adds, keep=(db_ih, db_hh))
+            db_ih = db_hh = None
         return dx, (dh0 if ctx.has_h0 else None), dw_ih, dw_hh, db_ih, db_hh, None, None, None, None
 
 
