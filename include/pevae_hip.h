@@ -140,6 +140,24 @@ int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float*
 int pv_vocab_argmax_noalloc(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H,
                             float inv_temp, int mask_col, int64_t* ids, float* logp, void* stream);
 size_t pv_vocab_argmax_noalloc_max_bytes(void);
+/* The whole free-running greedy decode in ONE persistent launch: the GEN branch of
+ * DecoderRNN.forward with gen_type 'greedy' (decoders.py:236-262) for a one-layer GRU decoder without attention -- per
+ * token embedding -> [cat latent] -> GRU step (base_modules.py:42) -> project + log_softmax (:191-193) -> [mask_unk
+ * :247-248] -> topk(1) (:252-254) -> next input; all L tokens for every row, no early exit at EOS (as the reference).
+ * gx_table [V][3H] fp32 = W_ih[:, :E] emb[v] + b_ih for every vocabulary entry (one pv_gemm_bf16_nt per decode);
+ * gx_const (optional) [B][3H] = W_ih[:, E:] latent[b]; whh_bf16 [3H][round_up(H,32)]; wproj_bf16 [V][ldwp] (zero K
+ * padding); h0 (optional) [B][H].  Out: seq [B][L] int64 emitted symbols, logp [B][L] their log-probabilities, hn [B][H]
+ * the state after the last step.  mask_col < 0: none.  workspace: pv_greedy_decode_ws_bytes(B, H, V, L) bytes, 256-byte
+ * aligned; its first word is an error flag (pv_greedy_decode_error: 1 = a bounded inter-workgroup wait timed out).
+ * Limits (PV_ERR_LIMIT): B <= 256, H <= 512, 8 (ceil(H/16) - 1) + ceil(B/32) workgroups <= CUs <= 256, and the
+ * per-workgroup share of W_proj (round_up(ceil(V / workgroups), 16) rows) + 48 rows of W_hh must fit 160 KiB of LDS
+ * (V <= 24 576 at H = 512 on 256 CUs).  The grid must be co-resident: nothing else may occupy the device's CUs. */
+size_t pv_greedy_decode_ws_bytes(int B, int H, int V, int L);
+int pv_greedy_decode(const float* gx_table, const float* gx_const, const void* whh_bf16, const float* bhh,
+                     const void* wproj_bf16, int ldwp, const float* bproj, const float* h0, int B, int H, int V, int L,
+                     int sos_id, int mask_col, float inv_temp, void* workspace, int64_t* seq, float* logp, float* hn,
+                     void* stream);
+int pv_greedy_decode_error(const void* workspace, int* flag);   /* host out-param; synchronises */
 /* Backward of the dense path: P = (dlogp - exp(logp) * rowsum(dlogp)) * inv_temp as bf16 [T][ldp] (+ dbias). */
 int pv_logsoftmax_bwd_bf16(const float* logp, const float* dlogp, int T, int V, float inv_temp, void* P, int ldp,
                            float* dbias, void* stream);

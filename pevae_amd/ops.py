@@ -758,6 +758,63 @@ def vocab_argmax(hid, weight, bias, inv_temp=1.0, mask_col=-1):
         return ids, logp
 
 
+LAST_DECODE_WS = []     # workspace of the most recent pv_greedy_decode launch, for greedy_decode_check()
+
+
+def greedy_decode(emb_weight, w_ih, w_hh, b_ih, b_hh, proj_weight, proj_bias, h0, L, sos_id, latent=None, inv_temp=1.0,
+                  mask_col=-1):
+    """All L tokens of a free-running greedy decode in one persistent launch (pv_greedy_decode; decoders.py:236-262 for a
+    one-layer GRU decoder without attention).  The input projection of every vocabulary entry is one GEMM per call
+    (gx_table = emb W_ih[:, :E]^T + b_ih), a latent input adds a per-row constant.  h0 [B,H] ->
+    (seq int64 [B,L], logp fp32 [B,L], h_n fp32 [B,H]); no gradient."""
+    with torch.no_grad():
+        _need_cuda(emb_weight, w_ih, w_hh, b_ih, b_hh, proj_weight, proj_bias, h0)
+        B, H = h0.shape
+        V, E = emb_weight.shape
+        dev = h0.device
+        Hk = round_up(H, 32)
+        Ep = round_up(E, 64)
+        emb_bf = pack_matrix(emb_weight, Ep)
+        if latent is None:
+            assert w_ih.shape[1] == E
+            wie_bf = pack_matrix(w_ih, Ep)
+        else:
+            Z = latent.shape[1]
+            assert w_ih.shape[1] == E + Z
+            wie_bf = pack_matrix(w_ih[:, :E].contiguous(), Ep)
+        table = gemm_nt(emb_bf, Ep, wie_bf, Ep, V, 3 * H, Ep, bias=b_ih.contiguous(),
+                        out=workspace("decode_gx_table", V * 3 * H, torch.float32, dev).view(V, 3 * H))
+        const = None
+        if latent is not None:
+            Zp = round_up(Z, 64)
+            lat_bf = cast_pack(latent.contiguous(), 1, B, B, Z, 0, Z, 1, Zp)
+            const = gemm_nt(lat_bf, Zp, pack_matrix(w_ih[:, E:].contiguous(), Zp), Zp, B, 3 * H, Zp)
+        whh_bf = pack_matrix(w_hh, Hk)
+        Hp = round_up(H, 64)
+        wp_bf = pack_matrix(proj_weight, Hp)
+        ws = workspace("greedy_decode", _lib.load().pv_greedy_decode_ws_bytes(B, H, V, L), torch.uint8, dev)
+        seq = torch.empty((B, L), dtype=torch.int64, device=dev)
+        logp = torch.empty((B, L), dtype=torch.float32, device=dev)
+        hn = torch.empty((B, H), dtype=torch.float32, device=dev)
+        join_side_work()                                   # the grid needs every CU
+        _lib.call("pv_greedy_decode", _p(table), _p(const), _p(whh_bf), _p(b_hh.contiguous()), _p(wp_bf), Hp,
+                  _p(proj_bias.contiguous()), _p(h0.contiguous()), B, H, V, L, int(sos_id), int(mask_col), float(inv_temp),
+                  _p(ws), _p(seq), _p(logp), _p(hn), _stream())
+        del LAST_DECODE_WS[:]
+        LAST_DECODE_WS.append(ws)
+        return seq, logp, hn
+
+
+def greedy_decode_check():
+    """Raise if the last pv_greedy_decode launch reported a timed-out inter-workgroup wait (synchronises the device)."""
+    while LAST_DECODE_WS:
+        ws = LAST_DECODE_WS.pop()
+        flag = C.c_int(0)
+        _lib.call("pv_greedy_decode_error", _p(ws), C.byref(flag))
+        if flag.value:
+            raise _lib.PevaeHipError("pv_greedy_decode: a bounded inter-workgroup wait timed out")
+
+
 class VocabLogProbDense(torch.autograd.Function):
     """Dense [T,V] log-softmax rows: the reference's DecoderRNN return value (decoders.py:193) for callers
     that want it as a tensor.  Costs the 4 B x T x V write the fused path avoids."""
@@ -815,6 +872,7 @@ def gru_check_all():
         sync, NG, tag = LAST_GRU_SYNC.pop()
         gru_check_sync(sync, NG, tag)
     block_check()
+    greedy_decode_check()
 
 
 def block_check():

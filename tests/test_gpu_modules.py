@@ -376,6 +376,86 @@ def test_decoder_gen_graphed_greedy(dev):
     assert len(dec._decode_graphs) == 1
 
 
+@pytest.mark.parametrize("mask_unk", [False, True])
+def test_decoder_gen_persistent_greedy_golden(dev, mask_unk):
+    """Opt-in persistent_decode (pv_greedy_decode: all tokens in one launch) on the reference's own greedy run: the emitted
+    symbols and lengths of the golden, the per-symbol log-probabilities and final state of the dense path."""
+    from pevae_amd.enc2dec import decoders as D
+    from pevae_amd import ops
+    g = load_golden("decoder_gen_greedy_maskunk" if mask_unk else "decoder_gen_greedy")
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb, mask_unk=mask_unk), g).to(dev)
+    dec.eval()
+    with torch.no_grad():
+        logp, hid, ret = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="greedy")
+        dec.persistent_decode = True
+        lp_p, hid_p, ret_p = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="greedy")
+    torch.cuda.synchronize()
+    ops.greedy_decode_check()
+    seq, seq_p = torch.cat(ret["sequence"], 1), torch.cat(ret_p["sequence"], 1)
+    assert torch.equal(seq, seq_p) and ret["length"] == ret_p["length"]
+    assert torch.equal(seq_p.cpu(), T(g["seq"])) and ret_p["length"] == [int(v) for v in g["length"]]
+    assert tuple(lp_p.shape) == (B, L) and tuple(hid_p.shape) == (1, B, H)
+    close(lp_p, logp.gather(2, seq.unsqueeze(-1)).squeeze(-1).cpu(), rtol=0, atol=1e-4)
+    close(hid_p, hid.cpu(), rtol=0, atol=1e-5)
+    close(hid_p, g["hid"], rtol=0, atol=3e-2)
+
+
+def _first_flip_is_a_near_tie(seq_a, seq_b, lp_a, margin):
+    """Rows of two greedy decodes may part only where the chosen symbol of one has (almost) the log-probability of the
+    other's: returns the number of rows that differ, asserting that at each row's first difference."""
+    diff = seq_a != seq_b
+    rows = diff.any(1).nonzero().view(-1)
+    for b in rows.tolist():
+        t = int(diff[b].float().argmax())
+        assert abs(float(lp_a[b, t, seq_a[b, t]] - lp_a[b, t, seq_b[b, t]])) < margin, (b, t)
+    return len(rows)
+
+
+@pytest.mark.parametrize("B,H,V,L,E,Z", [(256, 512, 20004, 50, 100, 0), (100, 512, 20004, 12, 100, 24),
+                                         (40, 96, 1000, 9, 20, 0), (70, 80, 333, 6, 12, 5)])
+def test_decoder_gen_persistent_greedy_sizes(dev, B, H, V, L, E, Z):
+    """pv_greedy_decode against the per-token path (dense log-probs, the reference's return value) at the BASELINE
+    decoder shape (compile-time K, 256 workgroups, 80 resident columns each), with a latent input and a ragged batch,
+    and at sizes that take the run-time-K kernel with zero-padded K and unit slices."""
+    from pevae_amd.enc2dec import decoders as D
+    from pevae_amd import ops
+    torch.manual_seed(3)
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    # a contractive recurrence at H = 512 (uniform(-0.3, 0.3) there is chaotic: summation-order noise of 1e-7 grows to 1e-1
+    # in 40 steps and the comparison would say nothing), with a projection strong enough for distinct top-2 symbols
+    dec = D.DecoderRNN(V, L, E + Z, H, 2, 3, 1, rnn_cell="gru", use_gpu=True, embedding=emb,
+                       init_range=0.3 if H < 128 else 0.04, mask_unk=True).to(dev)
+    dec.eval()
+    if H >= 128:
+        with torch.no_grad():
+            dec.project.weight.mul_(8.0)
+    h0 = torch.randn(1, B, H, device=dev) * 0.5
+    lat = torch.randn(B, Z, device=dev) if Z else None
+    ids = torch.zeros(B, L, dtype=torch.long, device=dev)
+    with torch.no_grad():
+        logp, hid, ret = dec(B, ids, h0, mode=D.GEN, gen_type="greedy", latent_variable=lat)
+        dec.persistent_decode = True
+        lp_p, hid_p, ret_p = dec(B, ids, h0, mode=D.GEN, gen_type="greedy", latent_variable=lat)
+        lp_p2, hid_p2, ret_p2 = dec(B, ids, h0, mode=D.GEN, gen_type="greedy", latent_variable=lat)
+    torch.cuda.synchronize()
+    ops.greedy_decode_check()
+    seq, seq_p = torch.cat(ret["sequence"], 1), torch.cat(ret_p["sequence"], 1)
+    assert torch.equal(seq_p, torch.cat(ret_p2["sequence"], 1)) and torch.equal(lp_p, lp_p2) and torch.equal(hid_p, hid_p2)
+    assert int(seq_p.min()) >= 0 and int(seq_p.max()) < V and not bool((seq_p == dec.unk_id).any())
+    assert len(torch.unique(seq_p)) > 3                          # not a degenerate decode
+    # the two paths sum in different orders: a bf16 rounding flip of a state element moves later logits by ~1e-2 (the
+    # module-level bf16 tolerance of this file)
+    flipped = _first_flip_is_a_near_tie(seq, seq_p, logp, 5e-2)
+    assert flipped <= max(1, B // 20), flipped
+    same = (seq == seq_p).all(1)
+    close(lp_p[same], logp.gather(2, seq.unsqueeze(-1)).squeeze(-1)[same].cpu(), rtol=0, atol=3e-2)
+    close(hid_p[0][same], hid[0][same].cpu(), rtol=0, atol=3e-2)
+    assert [ret_p["length"][b] for b in same.nonzero().view(-1).tolist()] == \
+        [ret["length"][b] for b in same.nonzero().view(-1).tolist()]
+
+
 def test_decoder_gen_sample_golden(dev):
     """`sample` decoding (decoders.py:255-256 -> base_modules.py:54-59) against the reference's own run: the Exp(1) draws
     behind torch.multinomial are part of the golden, so the drawn symbols can be compared token by token.  A symbol may

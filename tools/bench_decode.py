@@ -13,8 +13,9 @@ dec = D.DecoderRNN(V, L, E, H, 2, 3, 1, rnn_cell="gru", use_gpu=True, embedding=
 dec.eval()
 h0 = torch.randn(1, B, H, device=dev) * 0.1
 ids = torch.zeros(B, L, dtype=torch.long, device=dev)
-for fused, graphed in ((False, False), (True, False), (True, True)):
-    dec.fused_greedy, dec.graph_decode = fused, graphed
+from pevae_amd import ops
+for fused, graphed, persistent in ((False, False, False), (True, False, False), (True, True, False), (True, False, True)):
+    dec.fused_greedy, dec.graph_decode, dec.persistent_decode = fused, graphed, persistent
     with torch.no_grad():
         for _ in range(2):
             dec(B, ids, h0, mode=D.GEN, gen_type="greedy")
@@ -25,5 +26,6 @@ for fused, graphed in ((False, False), (True, False), (True, True)):
             outs, hid, ret = dec(B, ids, h0, mode=D.GEN, gen_type="greedy")
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-    print("fused_greedy=%s graph_decode=%s: %.2f ms per decode of %d x %d tokens (%.1f us/token step), mean length %.1f"
-          % (fused, graphed, dt * 1e3, B, L, dt * 1e6 / L, sum(ret["length"]) / B))
+        ops.gru_check_all()
+    print("fused_greedy=%s graph_decode=%s persistent_decode=%s: %.2f ms per decode of %d x %d tokens (%.1f us/token step), "
+          "mean length %.1f" % (fused, graphed, persistent, dt * 1e3, B, L, dt * 1e6 / L, sum(ret["length"]) / B))
