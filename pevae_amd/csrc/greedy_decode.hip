@@ -12,7 +12,8 @@
 //     gx_table[v] = W_ih[:, :E] emb[v] + b_ih; with a latent input, gx_const[b] = W_ih[:, E:] latent[b]), so a token's
 //     input projection is a row gather;
 //   * workgroup r has up to two roles.  GRU role (g, s): batch rows [32g, 32g+32) x hidden units [16s, 16s+16), its
-//     48 rows of W_hh resident in LDS, the fp32 state of its (row, unit) pairs in registers (one per thread).
+//     48 rows of W_hh resident in LDS, the fp32 state of its (row, unit) pairs in registers (one per thread); two waves
+//     multiply (16 rows each, all three gates), all threads do the gate math.
 //     Vocabulary role: columns [r NC, r NC + NC) of the projection, its NC rows of W_proj resident in LDS for the
 //     whole decode (80 rows at V = 20 004 on 256 CUs): W_proj is read from HBM once per decode, not once per token;
 //   * per token two chip-wide hand-offs: (A) every GRU workgroup has published its slice of h_t (bf16, 16-byte sc1
@@ -25,7 +26,11 @@
 //     payload stores have drained (vmcnt(0), barrier); a waiting wave loads all flags with one coalesced sc1 load per
 //     64 workgroups.  No read-modify-write anywhere, nothing to reset between tokens.  Every wait is wall-clock
 //     bounded and reports through the error word; after a failed wait a workgroup stops waiting, so the grid drains.
-//   * every published buffer has a slot per token (states [(L+1)][Bpad][Hk], records [L][Bpad][NV]): an address is
+//   * the published states are stored in MFMA A-fragment order -- [16-row tile][k-step][q4][row in tile][8 bf16], the
+//     1 KB a wave needs for one MFMA is one contiguous block -- because a row-major image makes every lane of a
+//     fragment load touch its own cache line (64 tag look-ups per instruction: measured 10 us per token for the 256 KB
+//     of a vocabulary phase, from any cache level);
+//   * every published buffer has a slot per token (states [(L+1)][Bpad][Hk], records [L][NV][Bpad]): an address is
 //     written once and only read after the hand-off that covers it.
 //
 // The grid must be co-resident (1 workgroup per CU; the entry point checks the CU count).  Placement is speed only:
@@ -61,8 +66,8 @@ struct DecodeArgs {
   const bf16_t* wp;        // [V][ldwp] bf16, columns >= H zero
   const float* bp;         // [V]
   const float* h0;         // optional [B][H]
-  bf16_t* hb;              // [(L+1)][Bpad][Hk]; slot 0 pre-filled
-  DecPart* part;           // [L][Bpad][NV]
+  bf16_t* hb;              // [(L+1)] slots of Bpad x Hk in MFMA-fragment order (see below); slot 0 pre-filled
+  DecPart* part;           // [L][NV][Bpad]
   u32* err;                // 1 word
   u32* flag_a;             // [nwg]: GRU workgroup r has published h of token flag_a[r] - 1
   u32* flag_b;             // [nwg]: vocabulary workgroup r has published the records of token flag_b[r] - 1
@@ -72,6 +77,7 @@ struct DecodeArgs {
   int L, B, H, Hk, Bpad, V, G, S, NV, NC, nwg, sos, mask_col, ldwp;
   float inv_temp;
   unsigned hb_bytes, part_bytes;
+  int dbg;                 // timing ablation bits (diagnostic build only, env PV_DECODE_DBG; results are wrong when set)
 };
 
 __device__ __forceinline__ u32 ld_relaxed(const u32* p) {
@@ -112,6 +118,63 @@ __device__ __forceinline__ void fold(float& m, float& s, float& best, int& idx, 
   }
 }
 
+// Diagnostic builds only.  -DPV_DECODE_ABLATE: the DBG bits switch parts of the kernel off (tools/decode_ablate.py; the
+// branches around the loads perturb the timing of everything else, so never together with the stamps).
+// -DPV_DECODE_STAMPS: wave 0 accumulates wall-clock (100 MHz) time per segment of a token into
+// words 576.. of the sync area (tools/decode_stamps.py).  Never compiled into the shipped library.
+#ifdef PV_DECODE_ABLATE
+#define DBG a.dbg
+#else
+#define DBG 0
+#endif
+#ifdef PV_DECODE_STAMPS
+#define STAMP(i)                                                    \
+  do {                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+    const unsigned long long now__ = wall_clock64();                \
+    stamp_acc[i] += (unsigned)(now__ - stamp_t);                    \
+    stamp_t = now__;                                                \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
+// all-reduce over the 16 lanes of a DPP row: xor 1, xor 2 (quad_perm), half-row mirror, row mirror
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  return fmaxf(v, dpp_f<0x140>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  return v + dpp_f<0x140>(v);
+}
+__device__ __forceinline__ int row16_min_int(int v) {
+  v = min(v, dpp_i<0xB1>(v));
+  v = min(v, dpp_i<0x4E>(v));
+  v = min(v, dpp_i<0x141>(v));
+  return min(v, dpp_i<0x140>(v));
+}
+
+// the (best, idx) half of fold(): all a workgroup needs to know the next input symbol
+__device__ __forceinline__ void fold_best(float& best, int& idx, float pb, int pi) {
+  if (pi >= 0 && (pb > best || (pb == best && (idx < 0 || pi < idx)))) {
+    best = pb;
+    idx = pi;
+  }
+}
+
 template <int AUX>
 __device__ __forceinline__ u32x4 ld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX);
@@ -128,7 +191,16 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
   const int c16 = lane & 15, q4 = lane >> 4;
   const int r = blockIdx.x, g = r & 7, s = r >> 3;
   const bool gru = g < a.G && s < a.S, voc = r < a.NV;
-  const int Hk = NKS_C ? NKS_C * 32 : a.Hk, NKS = Hk / 32, nch = Hk / 8, ldw = Hk * 2 + 16, H = a.H;
+  const int Hk = NKS_C ? NKS_C * 32 : a.Hk, NKS = Hk / 32, nch = Hk / 8, ldw = Hk * 2, H = a.H;
+  // LDS images of the weights: 16-byte chunk c of row n sits at chunk c ^ (n & mask) (conflict-free ds_read_b128 of the
+  // MFMA B fragments; a padded row stride is 2-way on the instruction's 16-lane groups).  Lane (c16, q4) reads chunk
+  // ks*4 + q4 of a row with (row & 15) == c16: byte offset (ks >> 2) * 256 + sw[ks & 3] within the row
+  int mask = 16;
+  while (nch % mask) mask >>= 1;
+  mask -= 1;
+  int sw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sw[j] = ((j * 4 + q4) ^ (c16 & mask)) * 16;
   char* whl = smem;                                   // [48][ldw]: W_hh slice (gate-major, 16 units each)
   char* wpl = whl + (size_t)(gru ? 48 * ldw : 0);     // [NC][ldw]: W_proj columns
   float* gh = (float*)(wpl + (size_t)(voc ? a.NC * ldw : 0));   // [3][32][16] fp32: W_hh h per gate
@@ -140,14 +212,14 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
       const int n = i / nch, ch = i % nch, gate = n / UNITS, unit = s * UNITS + n % UNITS;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (unit < H) v = *(const uint4*)(a.whh + (size_t)(gate * H + unit) * Hk + ch * 8);
-      *(uint4*)(whl + (size_t)n * ldw + ch * 16) = v;
+      *(uint4*)(whl + (size_t)n * ldw + ((ch ^ (n & mask)) * 16)) = v;
     }
   if (voc)
     for (int i = tid; i < a.NC * nch; i += NT) {
       const int n = i / nch, ch = i % nch, col = r * a.NC + n;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (col < a.V) v = *(const uint4*)(a.wp + (size_t)col * a.ldwp + ch * 8);
-      *(uint4*)(wpl + (size_t)n * ldw + ch * 16) = v;
+      *(uint4*)(wpl + (size_t)n * ldw + ((ch ^ (n & mask)) * 16)) = v;
     }
   if (tid == 0) {
     if (!gru) st_relaxed(a.flag_a + r, NEVER);
@@ -170,6 +242,10 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
   const int NCT = a.NC / 16;
   bool dead = false;                                  // wave 0 only: a wait has failed, stop waiting (the grid drains)
   __syncthreads();
+#ifdef PV_DECODE_STAMPS
+  unsigned stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_t = wall_clock64();
+#endif
 
   for (int t = 0; t <= a.L; ++t) {
     if (gru) {
@@ -177,34 +253,62 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
       if (t == 0) {
         if (tid < GROWS) tok[tid] = a.sos;
       } else {
-        if (w == 0 && !dead) {
+        if (w == 0 && !dead && !(DBG & 64)) {
           dead = !wait_all_ge(a.flag_b, a.nwg, (u32)t, a.err, lane);
         }
+        STAMP(0);
         __syncthreads();
-#pragma unroll 1
-        for (int rr = 0; rr < 4; ++rr) {
-          const int lr = w * 4 + rr, row = g * GROWS + lr;
+        // records of token t-1, [workgroup][row]: lane (row j = lane & 31, half = lane >> 5) of wave w folds workgroups
+        // 2 (w + 8 i) + half in ascending order, all loads in flight at once; halves, then waves, fold in a fixed order
+        {
+          const int j = lane & 31, half = lane >> 5;
           float m = -INFINITY, sm = 0.f, best = -INFINITY;
           int idx = -1;
-          const unsigned base = (unsigned)((((size_t)(t - 1) * a.Bpad + row) * a.NV) * sizeof(DecPart));
-          for (int k = lane; k < a.NV; k += 64) {       // ascending columns within a lane
-            const u32x4 v = ld16<LDAUX>(prs, base + k * (unsigned)sizeof(DecPart));
-            const f32x4 f = __builtin_bit_cast(f32x4, v);   // (bit_cast of a single vector ELEMENT miscompiles: whole vector)
-            fold(m, sm, best, idx, f[0], f[1], f[2], (int)v[3]);
+          u32x4 v[MAX_WGS / 16];
+          const unsigned base = (unsigned)((((size_t)(t - 1) * a.NV) * a.Bpad + g * GROWS + j) * sizeof(DecPart));
+          const unsigned kstep = (unsigned)(a.Bpad * sizeof(DecPart));
+#pragma unroll
+          for (int i = 0; i < MAX_WGS / 16; ++i) {
+            const int k = 2 * (w + 8 * i) + half;
+            if (k < a.NV && !(DBG & 16)) v[i] = ld16<LDAUX>(prs, base + k * kstep);
           }
 #pragma unroll
-          for (int off = 1; off < 64; off <<= 1)
-            fold(m, sm, best, idx, __shfl_xor(m, off), __shfl_xor(sm, off), __shfl_xor(best, off), __shfl_xor(idx, off));
-          if (lane == 0) {
-            tok[lr] = min(max(idx, 0), a.V - 1);
-            if (s == 0 && row < a.B) {
-              a.seq[(size_t)row * a.L + t - 1] = idx;
-              a.logp[(size_t)row * a.L + t - 1] = best - (m + __logf(sm));
+          for (int i = 0; i < MAX_WGS / 16; ++i) {
+            const int k = 2 * (w + 8 * i) + half;
+            if (k < a.NV && !(DBG & 16)) {
+              const f32x4 f = __builtin_bit_cast(f32x4, v[i]);   // (bit_cast of a single vector ELEMENT miscompiles)
+              if (s == 0) fold(m, sm, best, idx, f[0], f[1], f[2], (int)v[i][3]);   // slice 0 also writes the log-probability
+              else fold_best(best, idx, f[2], (int)v[i][3]);
             }
+          }
+          if (s == 0) fold(m, sm, best, idx, __shfl_xor(m, 32), __shfl_xor(sm, 32), __shfl_xor(best, 32), __shfl_xor(idx, 32));
+          else fold_best(best, idx, __shfl_xor(best, 32), __shfl_xor(idx, 32));
+          if (lane < 32) {
+            const u32x4 o = {__builtin_bit_cast(u32, m), __builtin_bit_cast(u32, sm), __builtin_bit_cast(u32, best), (u32)idx};
+            *(u32x4*)(gh + (w * GROWS + j) * 4) = o;           // gh is free until the GRU step
+          }
+        }
+        __syncthreads();
+        if (tid < GROWS) {
+          float m = -INFINITY, sm = 0.f, best = -INFINITY;
+          int idx = -1;
+#pragma unroll
+          for (int ww = 0; ww < NT / 64; ++ww) {
+            const u32x4 o = *(const u32x4*)(gh + (ww * GROWS + tid) * 4);
+            const f32x4 f = __builtin_bit_cast(f32x4, o);
+            if (s == 0) fold(m, sm, best, idx, f[0], f[1], f[2], (int)o[3]);
+            else fold_best(best, idx, f[2], (int)o[3]);
+          }
+          const int row = g * GROWS + tid;
+          tok[tid] = min(max(idx, 0), a.V - 1);
+          if (s == 0 && row < a.B) {
+            a.seq[(size_t)row * a.L + t - 1] = idx;
+            a.logp[(size_t)row * a.L + t - 1] = best - (m + __logf(sm));
           }
         }
       }
       __syncthreads();
+      STAMP(1);
       if (t == a.L) break;
       // ---- (2) one GRU step of the slice ------------------------------------------------------------------------
       float gx[3] = {0.f, 0.f, 0.f};
@@ -213,31 +317,39 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) gx[gt] = gp[gt * H] + gxc[gt];
       }
-      if (w < 6) {                                       // wave (mt, gate): 16 rows x 16 units of one gate, full K
-        const int mt = w & 1, gate = w >> 1;
-        const unsigned abase = (unsigned)((((size_t)t * a.Bpad + g * GROWS + mt * 16 + c16) * Hk + q4 * 8) * 2);
-        const char* bp = whl + (size_t)(gate * UNITS + c16) * ldw + q4 * 16;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      if (w < 2 && !(DBG & 32)) {                        // wave mt: 16 rows x 16 units, all three gates, full K
+        const int mt = w;
+        const unsigned abase = (unsigned)((size_t)t * a.Bpad * Hk * 2 + (size_t)(g * 2 + mt) * NKS * 1024 + lane * 16);
+        const char* bp = whl + (size_t)c16 * ldw;
+        f32x4 acc[3];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (NKS_C > 0) {
           u32x4 av[NKS_C];
 #pragma unroll
-          for (int ks = 0; ks < NKS_C; ++ks) av[ks] = ld16<LDAUX>(hrs, abase + ks * 64);
+          for (int ks = 0; ks < NKS_C; ++ks) av[ks] = ld16<LDAUX>(hrs, abase + ks * 1024);
 #pragma unroll
-          for (int ks = 0; ks < NKS_C; ks += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[ks]),
-                                                           __builtin_bit_cast(bf16x8, *(const uint4*)(bp + ks * 64)), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[ks + 1]),
-                                                           __builtin_bit_cast(bf16x8, *(const uint4*)(bp + ks * 64 + 64)), acc1, 0, 0, 0);
+          for (int ks = 0; ks < NKS_C; ++ks) {
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt)
+              acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, av[ks]),
+                  __builtin_bit_cast(bf16x8, *(const uint4*)(bp + (size_t)gt * UNITS * ldw + (ks >> 2) * 256 + sw[ks & 3])), acc[gt], 0, 0, 0);
           }
         } else {
           for (int ks = 0; ks < NKS; ++ks) {
-            const u32x4 av = ld16<LDAUX>(hrs, abase + ks * 64);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
-                                                           __builtin_bit_cast(bf16x8, *(const uint4*)(bp + ks * 64)), acc0, 0, 0, 0);
+            const u32x4 av = ld16<LDAUX>(hrs, abase + ks * 1024);
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt)
+              acc[gt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, av),
+                  __builtin_bit_cast(bf16x8, *(const uint4*)(bp + (size_t)gt * UNITS * ldw + (((ks * 4 + q4) ^ (c16 & mask)) * 16))), acc[gt], 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gh[(gate * GROWS + mt * 16 + q4 * 4 + j) * UNITS + c16] = acc0[j] + acc1[j];
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gh[(gt * GROWS + mt * 16 + q4 * 4 + j) * UNITS + c16] = acc[gt][j];
       }
       __syncthreads();
       {
@@ -249,37 +361,45 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
         tile[trow * UNITS + tun] = f2bf(hreg);
       }
       __syncthreads();
+      STAMP(2);
       if (tid < GROWS * 2) {                             // publish: 32 rows x 32 bytes, 16-byte write-through stores
-        const int row = tid >> 1, ch = tid & 1;
+        const int row = (tid >> 5) * 16 + (tid & 15), ch = (tid >> 4) & 1, k = s * UNITS + ch * 8;
         const u32x4 v = *(const u32x4*)(tile + row * UNITS + ch * 8);
-        const unsigned off = (unsigned)((((size_t)(t + 1) * a.Bpad + g * GROWS + row) * Hk + s * UNITS + ch * 8) * 2);
+        const unsigned off = (unsigned)((size_t)(t + 1) * a.Bpad * Hk * 2 + (size_t)((g * 2 + (tid >> 5)) * NKS + (k >> 5)) * 1024 +
+                                        ((k >> 3) & 3) * 256 + (tid & 15) * 16);
         __builtin_amdgcn_raw_buffer_store_b128(v, hrs, off, 0, AUX_SC1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 64) st_relaxed(a.flag_a + r, (u32)(t + 1));   // wave 1: wave 0's polls never queue behind this store
+      STAMP(3);
     } else if (t == a.L) {
       break;
     }
     if (voc) {
       // ---- (3) h_{t+1} of every row x the resident columns -------------------------------------------------------
-      if (w == 0 && !dead) {
+      if (w == 0 && !dead && !(DBG & 64)) {
         dead = !wait_all_ge(a.flag_a, a.nwg, (u32)(t + 1), a.err, lane);
       }
+      STAMP(4);
       __syncthreads();
       if (w * 32 < a.Bpad) {
         // lane c16 = i (< 8) of each 16-lane row keeps the running record of the row group's row i (row tile i >> 2,
         // accumulator element i & 3): 4 registers of state instead of 32 while the fragments are live
         float km = -INFINITY, ksum = 0.f, kb = -INFINITY;
         int ki = -1;
-        const unsigned abase = (unsigned)((((size_t)(t + 1) * a.Bpad + w * 32 + c16) * Hk + q4 * 8) * 2);
-        const unsigned astep = (unsigned)(16 * Hk * 2);      // second row tile
+        // which 32 rows this wave takes is rotated by the workgroup's index within its XCD: the CUs of an XCD would otherwise
+        // ask the L2 for the same lines in the same order at the same moment
+        const int wr = (w + (r >> 3)) % (a.Bpad / 32);
+        const unsigned abase = (unsigned)((size_t)(t + 1) * a.Bpad * Hk * 2 + (size_t)(wr * 2) * NKS * 1024 + lane * 16);
+        const unsigned astep = (unsigned)(NKS * 1024);       // second row tile
         u32x4 av[2][NKS_C > 0 ? NKS_C : 1];
         if constexpr (NKS_C > 0) {
+          if (!(DBG & 1))
 #pragma unroll
           for (int ks = 0; ks < NKS_C; ++ks) {
-            av[0][ks] = ld16<LDAUX>(hrs, abase + ks * 64);
-            av[1][ks] = ld16<LDAUX>(hrs, abase + astep + ks * 64);
+            av[0][ks] = ld16<LDAUX>(hrs, abase + ks * 1024);
+            av[1][ks] = ld16<LDAUX>(hrs, abase + astep + ks * 1024);
           }
         }
 #pragma unroll 1
@@ -287,44 +407,7 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
           f32x4 acc[2][CT];
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) acc[0][ct] = acc[1][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-          // tiles past the share's end read the last tile again (results unused): no branches around the MFMAs
-          int toff[CT];
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) toff[ct] = (min(c0 + ct, NCT - 1) * 16 + c16) * ldw + q4 * 16;
-          if constexpr (NKS_C > 0) {
-            uint4 fb[2][CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) fb[0][ct] = *(const uint4*)(wpl + toff[ct]);
-#pragma unroll
-            for (int ks = 0; ks < NKS_C; ++ks) {
-              const int cur = ks & 1, nxt = cur ^ 1;
-              if (ks + 1 < NKS_C) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) fb[nxt][ct] = *(const uint4*)(wpl + toff[ct] + (ks + 1) * 64);
-              }
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int ct = 0; ct < CT; ++ct) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, fb[cur][ct]);
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[0][ks]), b, acc[0][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[1][ks]), b, acc[1][ct], 0, 0, 0);
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          } else {
-            for (int ks = 0; ks < NKS; ++ks) {
-              const bf16x8 a0 = __builtin_bit_cast(bf16x8, ld16<LDAUX>(hrs, abase + ks * 64));
-              const bf16x8 a1 = __builtin_bit_cast(bf16x8, ld16<LDAUX>(hrs, abase + astep + ks * 64));
-#pragma unroll
-              for (int ct = 0; ct < CT; ++ct) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(wpl + toff[ct] + ks * 64));
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][ct], 0, 0, 0);
-              }
-            }
-          }
-          // this lane's columns of the chunk (ascending): scaled logits, max / sum-exp / best allowed column per row, then
-          // the 16 lanes of a row fold (butterfly) and lane i keeps row i
+          // this lane's columns of the chunk and their bias (requested before the MFMAs)
           float bv[CT];
           int colv[CT];
 #pragma unroll
@@ -334,6 +417,40 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
             bv[ct] = a.bp[ok ? colv[ct] : 0];
             if (!ok) colv[ct] = -1;
           }
+          // tiles past the share's end read the last tile again (results unused): no branches around the MFMAs
+          int toff[CT];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) toff[ct] = (min(c0 + ct, NCT - 1) * 16 + c16) * ldw;
+          if constexpr (NKS_C > 0) {
+            if (!(DBG & 2))
+#pragma unroll
+            for (int ks = 0; ks < NKS_C; ++ks) {
+              uint4 fb[CT];
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) fb[ct] = *(const uint4*)(wpl + toff[ct] + (ks >> 2) * 256 + sw[ks & 3]);
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, fb[ct]);
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[0][ks]), b, acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[1][ks]), b, acc[1][ct], 0, 0, 0);
+              }
+            }
+          } else {
+            for (int ks = 0; ks < NKS; ++ks) {
+              const bf16x8 a0 = __builtin_bit_cast(bf16x8, ld16<LDAUX>(hrs, abase + ks * 1024));
+              const bf16x8 a1 = __builtin_bit_cast(bf16x8, ld16<LDAUX>(hrs, abase + astep + ks * 1024));
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(wpl + toff[ct] + (((ks * 4 + q4) ^ (c16 & mask)) * 16)));
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][ct], 0, 0, 0);
+              }
+            }
+          }
+          STAMP(5);
+          // this lane's columns of the chunk (ascending): scaled logits, max / sum-exp / best allowed column per row, then
+          // the 16 lanes of a row fold (butterfly) and lane i keeps row i
+          if (!(DBG & 4))
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int mt = i >> 2, j = i & 3;
@@ -348,29 +465,39 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
                 bi = colv[ct];
               }
             }
+            // the 16 lanes of a row: max, sum-exp against the row's max, best value and its lowest column (DPP all-reduces)
+            mx = row16_max(mx);
             if (mx > -INFINITY) {
 #pragma unroll
               for (int ct = 0; ct < CT; ++ct) sc += __expf(x[ct] - mx);
             }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1)
-              fold(mx, sc, bst, bi, __shfl_xor(mx, off), __shfl_xor(sc, off), __shfl_xor(bst, off), __shfl_xor(bi, off));
+            sc = row16_sum(sc);
+            const float brow = row16_max(bst);
+            bi = row16_min_int((bst == brow && bi >= 0) ? bi : 0x7fffffff);
+            bi = bi == 0x7fffffff ? -1 : bi;
+            bst = brow;
             if (c16 == i) fold(km, ksum, kb, ki, mx, sc, bst, bi);
           }
         }
-        if (c16 < 8) {
-          const int row = w * 32 + (c16 >> 2) * 16 + q4 * 4 + (c16 & 3);
+        STAMP(6);
+        if (c16 < 8 && !(DBG & 8)) {
+          const int row = wr * 32 + (c16 >> 2) * 16 + q4 * 4 + (c16 & 3);
           const u32x4 v = {__builtin_bit_cast(u32, km), __builtin_bit_cast(u32, ksum), __builtin_bit_cast(u32, kb), (u32)ki};
-          const unsigned off = (unsigned)((((size_t)t * a.Bpad + row) * a.NV + r) * sizeof(DecPart));
+          const unsigned off = (unsigned)((((size_t)t * a.NV + r) * a.Bpad + row) * sizeof(DecPart));
           __builtin_amdgcn_raw_buffer_store_b128(v, prs, off, 0, AUX_SC1);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 64) st_relaxed(a.flag_b + r, (u32)(t + 1));
+      STAMP(7);
     }
   }
   if (live) a.hn[(size_t)brow * H + unit] = hreg;
+#ifdef PV_DECODE_STAMPS
+  if (tid == 0 && (r < 4 || r >= a.nwg - 4))
+    for (int i = 0; i < 8; ++i) a.err[576 + (r < 4 ? r : 8 - (a.nwg - r)) * 8 + i] = stamp_acc[i];
+#endif
 }
 
 // slot 0 of the published states = bf16(h0) (zero rows / columns of padding); flags and the error word cleared
@@ -380,7 +507,8 @@ __global__ void decode_init_kernel(const float* __restrict__ h0, int B, int H, i
   if (i < sync_words) sync[i] = 0;
   if (i < Bpad * Hk) {
     const int row = i / Hk, k = i % Hk;
-    hb[i] = f2bf(row < B && k < H && h0 ? h0[(size_t)row * H + k] : 0.f);
+    const size_t o = ((size_t)((row >> 4) * (Hk / 32) + (k >> 5)) * 4 + ((k >> 3) & 3)) * 128 + (row & 15) * 8 + (k & 7);
+    hb[o] = f2bf(row < B && k < H && h0 ? h0[(size_t)row * H + k] : 0.f);
   }
 }
 
@@ -415,7 +543,7 @@ int plan_decode(int B, int H, int V, int L, int cus, DecodePlan* p) {
   p->nwg = wg_gru > cdiv(V, 16) ? wg_gru : (cdiv(V, 16) < cus ? cdiv(V, 16) : cus);
   p->NV = p->nwg < cdiv(V, 16) ? p->nwg : cdiv(V, 16);
   p->NC = round_up(cdiv(V, p->NV), 16);
-  const size_t ldw = (size_t)p->Hk * 2 + 16;
+  const size_t ldw = (size_t)p->Hk * 2;
   p->lds = (48 + (size_t)p->NC) * ldw + 3 * GROWS * UNITS * 4 + GROWS * UNITS * 2 + GROWS * 4;
   if (p->lds > 160 * 1024 - 64) {
     pv_set_error("pv_greedy_decode: V=%d over %d workgroups is %d resident columns of %zu bytes: %zu bytes of LDS > 160 KiB",
@@ -484,6 +612,8 @@ int pv_greedy_decode(const float* gx_table, const float* gx_const, const void* w
   a.L = L, a.B = B, a.H = H, a.Hk = p.Hk, a.Bpad = p.Bpad, a.V = V, a.G = p.G, a.S = p.S, a.NV = p.NV, a.NC = p.NC;
   a.nwg = p.nwg, a.sos = sos_id, a.mask_col = mask_col, a.ldwp = ldwp, a.inv_temp = inv_temp;
   a.hb_bytes = (unsigned)p.hb_bytes, a.part_bytes = (unsigned)p.part_bytes;
+  static const int dbg = getenv("PV_DECODE_DBG") ? atoi(getenv("PV_DECODE_DBG")) : 0;
+  a.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
   if (p.Hk != p.S * UNITS) PV_HIP(hipMemsetAsync(a.hb, 0, p.hb_bytes, st));   // padding columns no slice ever writes
   const int n0 = p.Bpad * p.Hk > (int)(SYNC_BYTES / 4) ? p.Bpad * p.Hk : (int)(SYNC_BYTES / 4);
