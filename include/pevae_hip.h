@@ -181,10 +181,12 @@ int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float*
                float* hn, void* sync, int max_wgs, void* stream);
 /* Backward through time.  whhT_bf16 [H][K3] = W_hh^T.  Emits dgi_bf16 / dgh_bf16 [L][Bpad][K3] (gate
  * gradients w.r.t. the input / hidden pre-activations; GEMM operands for dW_ih, dx, dW_hh), dh0 [B][H],
- * db_ih / db_hh [3H].  dbias_part: 2*NG*4*H floats of scratch. */
+ * db_ih / db_hh [3H].  dbias_part: 2*NG*4*H floats of scratch.  dgx_bf16 (optional, same size as dgh_bf16): scratch for
+ * the inter-workgroup exchange of the gate gradients in MFMA-fragment order (faster steps); NULL exchanges through
+ * dgh_bf16 itself. */
 int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsaveT,
                const float* hall, const void* whhT_bf16, int L, int B, int H, int reverse, void* dgi_bf16,
-               void* dgh_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
+               void* dgh_bf16, void* dgx_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
                int max_wgs, void* stream);
 /* torch.nn.LSTM semantics (gate order i,f,g,o) for rnn_cell == 'lstm' (base_modules.py:42-47, encoders.py:59-62,
  * decoders.py:182): the same persistent kernels with four gates per unit.  xprojT [4H][ldx], whh_bf16 [4H][Hk],

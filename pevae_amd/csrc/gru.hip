@@ -462,7 +462,7 @@ struct GruBwdArgs {
   const float* hall;      // [(L+1)][Bpad][H] fp32 states in processing order (slot i = state before step i)
   const bf16_t* whhT;     // [H][K3] bf16: whhT[u][k] = W_hh[k][u], columns >= 3H zero
   bf16_t* dgi;            // [L][Bpad][K3] bf16: (dr, dz, dn)       rows >= B zero
-  bf16_t* dgh;            // [L][Bpad][K3] bf16: (dr, dz, dn * r)   exchange buffer
+  bf16_t* dgh;            // [L][Bpad][K3] bf16: (dr, dz, dn * r)   exchange buffer (when dgx is null) and GEMM operand
   float* dcarry;          // [B][H] fp32 scratch; ends as dL/dh0 (GRU) | dL/dc0 (LSTM: the directly carried gradient is dc)
   const float* call;      // LSTM only: [(L+1)][Bpad][H] fp32 cell states
   const float* dcn;       // LSTM only, optional [B][H]: dL/dc_n
@@ -474,6 +474,7 @@ struct GruBwdArgs {
   unsigned dg_bytes;
   u32* stamps;            // diagnostic build only
   const int* lens;        // LSTM only: rows frozen at t >= lens[b] (the GRU encodes a frozen step in its saved gates)
+  bf16_t* dgx;            // GRU, optional: the exchanged copy of dgh in MFMA A-fragment order (see FX below)
 };
 
 // Backward through time.  Per step: rec = dgh[previously handled step] @ W_hh (K = 3H, split over the 4
@@ -486,7 +487,12 @@ struct GruBwdArgs {
 // the recurrent term.
 // MT: 16-row MFMA tiles per row group (2: 32-row groups, 1: 16-row groups -- twice the workgroups, each fetching half
 // the exchanged bytes per step; the step is bound by that fetch).
-template <int UT, int NKS_C, int NGT, int MT>
+// FX: the exchanged gate gradients travel through a.dgx, an image in MFMA A-fragment order -- [t][16-row tile][k-step]
+// [q4][row in tile][8 bf16], the 1 KB a wave needs for one MFMA is one contiguous block -- and the row-major dgh (the
+// operand of the dW_hh GEMM) is written after the arrival, with the copies nobody waits for.  A fragment load from the
+// row-major image touches 16 rows x 64 bytes, one cache-line look-up per lane group: the step's fetch of the group's
+// 48 KB took 2.4 us that way (stamps), against 0.7 us at the L2 -> CU rate.
+template <int UT, int NKS_C, int NGT, int MT, bool FX>
 __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   constexpr int U = UT * 16, RW = MT * 16, NTILE = MT * UT;
   constexpr bool LSTM = NGT == 4;
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   int boff[UT];
 #pragma unroll
   for (int j = 0; j < UT; ++j) boff[j] = (j * 16 + c16) * K3 * 2 + ((((w & 3) * 4 + q4) ^ (c16 & mask)) * 16);
-  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dgh, 0, a.dg_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(FX ? a.dgx : a.dgh), 0, a.dg_bytes, 0x00020000);
   const bool single = a.NG <= a.G;
   float carry[4] = {0.f, 0.f, 0.f, 0.f};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -602,7 +608,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < UT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned abase = (unsigned)((((size_t)tprev * a.Bpad + row0 + c16) * K3 + q4 * 8) * 2);
+        const unsigned abase = FX ? (unsigned)(((size_t)tprev * (a.Bpad >> 4) + (row0 >> 4)) * NKS * 1024 + lane * 16)
+                                  : (unsigned)((((size_t)tprev * a.Bpad + row0 + c16) * K3 + q4 * 8) * 2);
         for (int ks0 = w; ks0 < NKS; ks0 += 48) {           // wave w takes k-steps w, w+4, ... (12 per pass)
           u32x4 av[12][MT];
 #pragma unroll
@@ -611,7 +618,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
 #pragma unroll
               for (int i = 0; i < MT; ++i)
                 av[kk][i] = __builtin_amdgcn_raw_buffer_load_b128(
-                    grsrc, abase + (unsigned)(i * 16 * K3 * 2) + (ks0 + kk * 4) * 64, 0, AUX_SC1);
+                    grsrc, FX ? abase + (unsigned)((i * NKS + ks0 + kk * 4) * 1024) : abase + (unsigned)(i * 16 * K3 * 2) + (ks0 + kk * 4) * 64,
+                    0, AUX_SC1);
             }
 #pragma unroll
           for (int kk = 0; kk < 12; ++kk) {
@@ -713,10 +721,18 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
       // (d) publish dgh (write-through), drain, barrier, arrive; then the copies nobody waits for
       constexpr int NCH = RW * NGT * U / 8;                // 16-byte chunks per image
       for (int c = tid; c < NCH; c += 256) {
-        const int row = c / (NGT * U / 8), rem = c % (NGT * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
-        const u32x4 v = *(const u32x4*)(tgh + row * NGT * U + gt * U + ch * 8);
-        const unsigned off = (unsigned)((((size_t)t * a.Bpad + row0 + row) * K3 + gt * H + u0 + ch * 8) * 2);
-        __builtin_amdgcn_raw_buffer_store_b128(v, grsrc, off, 0, AUX_SC1);
+        if constexpr (FX) {                                 // row fastest: 16 consecutive threads fill 256 contiguous bytes
+          const int row = c % RW, rem = c / RW, gt = rem / (U / 8), ch = rem % (U / 8), k = gt * H + u0 + ch * 8;
+          const u32x4 v = *(const u32x4*)(tgh + row * NGT * U + gt * U + ch * 8);
+          const unsigned off = (unsigned)((((size_t)t * (a.Bpad >> 4) + ((row0 + row) >> 4)) * NKS + (k >> 5)) * 1024 +
+                                          ((k >> 3) & 3) * 256 + ((row0 + row) & 15) * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, grsrc, off, 0, AUX_SC1);
+        } else {
+          const int row = c / (NGT * U / 8), rem = c % (NGT * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
+          const u32x4 v = *(const u32x4*)(tgh + row * NGT * U + gt * U + ch * 8);
+          const unsigned off = (unsigned)((((size_t)t * a.Bpad + row0 + row) * K3 + gt * H + u0 + ch * 8) * 2);
+          __builtin_amdgcn_raw_buffer_store_b128(v, grsrc, off, 0, AUX_SC1);
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP(6);
@@ -729,6 +745,9 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
           const int row = c / (3 * U / 8), rem = c % (3 * U / 8), gt = rem / (U / 8), ch = rem % (U / 8);
           const uint4 v = *(const uint4*)(tgi + row * 3 * U + gt * U + ch * 8);
           *(uint4*)(a.dgi + ((size_t)t * a.Bpad + row0 + row) * K3 + gt * H + u0 + ch * 8) = v;
+          if constexpr (FX)
+            *(uint4*)(a.dgh + ((size_t)t * a.Bpad + row0 + row) * K3 + gt * H + u0 + ch * 8) =
+                *(const uint4*)(tgh + row * 3 * U + gt * U + ch * 8);
         }
       }
       if (!single) {
@@ -954,8 +973,8 @@ int rnn_fwd(int ngt, const float* xprojT, long ldx, const void* whh_bf16, const 
 
 int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float* dhn, const float* dcn,
             const float* gsaveT, const float* hall, const float* call, const void* whhT_bf16, int L, int B, int H,
-            int reverse, void* dgi_bf16, void* dgh_bf16, float* dh0, float* dc0, float* dbias_part, float* db_ih,
-            float* db_hh, const int* lengths, void* sync, int max_wgs, void* stream) {
+            int reverse, void* dgi_bf16, void* dgh_bf16, void* dgx_bf16, float* dh0, float* dc0, float* dbias_part,
+            float* db_ih, float* db_hh, const int* lengths, void* sync, int max_wgs, void* stream) {
   int Hk, K3, Bpad, NG;
   int rc = rnn_geometry(ngt, B, H, &Hk, &K3, &Bpad, &NG);
   if (rc) return rc;
@@ -996,15 +1015,23 @@ int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float*
   if (K3 != ngt * H || Bpad != B) {
     if (dgi_bf16) PV_HIP(hipMemsetAsync(dgi_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
     PV_HIP(hipMemsetAsync(dgh_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
+    if (dgx_bf16) PV_HIP(hipMemsetAsync(dgx_bf16, 0, (size_t)L * Bpad * K3 * 2, st));
   }
   GruBwdArgs a{dout, dout_sb, dout_st, dhn, gsaveT, hall, (const bf16_t*)whhT_bf16, (bf16_t*)dgi_bf16,
                (bf16_t*)dgh_bf16, ngt == 4 ? dc0 : dh0, call, dcn, dh0, dbias_part, counters, err, L, B, H, K3, Bpad,
-               NGk, G, S, reverse, xmap, (unsigned)dg_bytes, (u32*)sync + 64, lengths};
+               NGk, G, S, reverse, xmap, (unsigned)dg_bytes, (u32*)sync + 64, lengths, (bf16_t*)dgx_bf16};
+  PV_REQUIRE(!dgx_bf16 || (ngt == 3 && ((uintptr_t)dgx_bf16 & 15) == 0), "pv_gru_bwd: dgx_bf16 is a GRU-only, 16-byte aligned buffer");
 #define PV_GRU_LAUNCH_B5(UTv, NKv, NGv, MTv)                                                            \
   do {                                                                                                  \
     static size_t seen = 0;                                                                             \
-    if ((rc = ensure_lds(gru_bwd_kernel<UTv, NKv, NGv, MTv>, smem, &seen))) return rc;                  \
-    hipLaunchKernelGGL((gru_bwd_kernel<UTv, NKv, NGv, MTv>), dim3(grid), dim3(256), smem, st, a);       \
+    if (NGv == 3 && a.dgx) {                                                                            \
+      static size_t seen_x = 0;                                                                         \
+      if ((rc = ensure_lds(gru_bwd_kernel<UTv, NKv, 3, MTv, true>, smem, &seen_x))) return rc;          \
+      hipLaunchKernelGGL((gru_bwd_kernel<UTv, NKv, 3, MTv, true>), dim3(grid), dim3(256), smem, st, a); \
+      break;                                                                                            \
+    }                                                                                                   \
+    if ((rc = ensure_lds(gru_bwd_kernel<UTv, NKv, NGv, MTv, false>, smem, &seen))) return rc;           \
+    hipLaunchKernelGGL((gru_bwd_kernel<UTv, NKv, NGv, MTv, false>), dim3(grid), dim3(256), smem, st, a); \
   } while (0)
 #define PV_GRU_LAUNCH_B4(UTv, NKv, NGv)                     \
   do {                                                      \
@@ -1050,10 +1077,10 @@ int pv_lstm_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float
 
 int pv_gru_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* gsaveT,
                const float* hall, const void* whhT_bf16, int L, int B, int H, int reverse, void* dgi_bf16,
-               void* dgh_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
+               void* dgh_bf16, void* dgx_bf16, float* dh0, float* dbias_part, float* db_ih, float* db_hh, void* sync,
                int max_wgs, void* stream) {
   return rnn_bwd(3, dout, dout_sb, dout_st, dhn, nullptr, gsaveT, hall, nullptr, whhT_bf16, L, B, H, reverse, dgi_bf16,
-                 dgh_bf16, dh0, nullptr, dbias_part, db_ih, db_hh, nullptr, sync, max_wgs, stream);
+                 dgh_bf16, dgx_bf16, dh0, nullptr, dbias_part, db_ih, db_hh, nullptr, sync, max_wgs, stream);
 }
 
 int pv_lstm_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn, const float* dcn,
@@ -1061,7 +1088,7 @@ int pv_lstm_bwd(const float* dout, long dout_sb, long dout_st, const float* dhn,
                 int reverse, void* dg_bf16, float* dh0, float* dc0, float* dbias_part, float* db_ih, float* db_hh,
                 const int* lengths, void* sync, int max_wgs, void* stream) {
   return rnn_bwd(4, dout, dout_sb, dout_st, dhn, dcn, gsaveT, hall, call, whhT_bf16, L, B, H, reverse, nullptr, dg_bf16,
-                 dh0, dc0, dbias_part, db_ih, db_hh, lengths, sync, max_wgs, stream);
+                 nullptr, dh0, dc0, dbias_part, db_ih, db_hh, lengths, sync, max_wgs, stream);
 }
 
 }  // extern "C"

@@ -858,6 +858,7 @@ class VocabLogProbDense(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------
 
 GRU_MAX_WGS = 0     # 0 = one workgroup per CU of the current device
+GRU_FRAGMENT_EXCHANGE = os.environ.get("PEVAE_GRU_DGX", "1") != "0"
 import collections
 
 # (sync buffer, NG, tag) of the most recent launches, for gru_check_all() (tests, smoke, bench, engine evaluations):
@@ -942,6 +943,8 @@ class GRULayer(torch.autograd.Function):
         whhT = transpose_to_bf16(w_hh.contiguous(), 3 * H, H, H, K3)
         dgi = torch.empty((L * Bpad, K3), dtype=BF16, device=dev)
         dgh = torch.empty((L * Bpad, K3), dtype=BF16, device=dev)
+        # the copy of dgh the workgroups exchange, in MFMA-fragment order (scratch of the kernel; PEVAE_GRU_DGX=0: none)
+        dgx = workspace("gru_dgx", L * Bpad * K3, BF16, dev) if GRU_FRAGMENT_EXCHANGE else None
         dh0 = torch.empty((B, H), dtype=torch.float32, device=dev)
         dbp = workspace("gru_dbias_part", 2 * NG * 4 * H, torch.float32, dev)
         db_ih = torch.empty(3 * H, dtype=torch.float32, device=dev)
@@ -954,7 +957,7 @@ class GRULayer(torch.autograd.Function):
         with timed("gru_bwd"):
             _lib.call("pv_gru_bwd", _p(dout), 0 if dout is None else dout.stride(0),
                       0 if dout is None else dout.stride(1), _p(dhn_c), _p(gsave), _p(hall), _p(whhT), L, B, H, 0,
-                      _p(dgi), _p(dgh), _p(dh0), _p(dbp), _p(db_ih), _p(db_hh), _p(sync), GRU_MAX_WGS, _stream())
+                      _p(dgi), _p(dgh), _p(dgx), _p(dh0), _p(dbp), _p(db_ih), _p(db_hh), _p(sync), GRU_MAX_WGS, _stream())
         LAST_GRU_SYNC.append((sync, NG, "pv_gru_bwd"))
         launch_after_recurrence()
         Tt = L * Bpad
