@@ -67,7 +67,7 @@ struct DecodeArgs {
   const float* bp;         // [V]
   const float* h0;         // optional [B][H]
   bf16_t* hb;              // [(L+1)] slots of Bpad x Hk in MFMA-fragment order (see below); slot 0 pre-filled
-  DecPart* part;           // [L][NV][Bpad]
+  DecPart* part;           // two images of [L][NV][Bpad] x 8 bytes: (best, column) records, then (max, sum-exp) records
   u32* err;                // 1 word
   u32* flag_a;             // [nwg]: GRU workgroup r has published h of token flag_a[r] - 1
   u32* flag_b;             // [nwg]: vocabulary workgroup r has published the records of token flag_b[r] - 1
@@ -76,7 +76,7 @@ struct DecodeArgs {
   float* hn;               // [B][H]
   int L, B, H, Hk, Bpad, V, G, S, NV, NC, nwg, sos, mask_col, ldwp;
   float inv_temp;
-  unsigned hb_bytes, part_bytes;
+  unsigned hb_bytes, part_bytes, part_b;   // part_b: byte offset of the (max, sum-exp) records inside `part`
   int dbg;                 // timing ablation bits (diagnostic build only, env PV_DECODE_DBG; results are wrong when set)
 };
 
@@ -165,6 +165,16 @@ __device__ __forceinline__ int row16_min_int(int v) {
   v = min(v, dpp_i<0x4E>(v));
   v = min(v, dpp_i<0x141>(v));
   return min(v, dpp_i<0x140>(v));
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// the (m, s) half of fold(): only the emitted symbol's log-probability needs it
+__device__ __forceinline__ void fold_ms(float& m, float& s, float pm, float ps) {
+  const float mn = fmaxf(m, pm);
+  s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (pm == -INFINITY ? 0.f : ps * __expf(pm - mn));
+  m = mn;
 }
 
 // the (best, idx) half of fold(): all a workgroup needs to know the next input symbol
@@ -258,53 +268,47 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
         }
         STAMP(0);
         __syncthreads();
-        // records of token t-1, [workgroup][row]: lane (row j = lane & 31, half = lane >> 5) of wave w folds workgroups
-        // 2 (w + 8 i) + half in ascending order, all loads in flight at once; halves, then waves, fold in a fixed order
+        // (best, column) records of token t-1, [workgroup][row], 8 bytes each: lane (row j = lane & 31, half = lane >> 5)
+        // of wave w folds workgroups 2 (w + 8 i) + half, all loads in flight at once; halves, then waves, through LDS
         {
           const int j = lane & 31, half = lane >> 5;
-          float m = -INFINITY, sm = 0.f, best = -INFINITY;
+          float best = -INFINITY;
           int idx = -1;
-          u32x4 v[MAX_WGS / 16];
-          const unsigned base = (unsigned)((((size_t)(t - 1) * a.NV) * a.Bpad + g * GROWS + j) * sizeof(DecPart));
-          const unsigned kstep = (unsigned)(a.Bpad * sizeof(DecPart));
+          u32x2 v[MAX_WGS / 16];
+          const unsigned base = (unsigned)((((size_t)(t - 1) * a.NV) * a.Bpad + g * GROWS + j) * 8);
+          const unsigned kstep = (unsigned)(a.Bpad * 8);
 #pragma unroll
           for (int i = 0; i < MAX_WGS / 16; ++i) {
             const int k = 2 * (w + 8 * i) + half;
-            if (k < a.NV && !(DBG & 16)) v[i] = ld16<LDAUX>(prs, base + k * kstep);
+            if (k < a.NV && !(DBG & 16)) v[i] = __builtin_amdgcn_raw_buffer_load_b64(prs, base + k * kstep, 0, LDAUX);
           }
 #pragma unroll
           for (int i = 0; i < MAX_WGS / 16; ++i) {
             const int k = 2 * (w + 8 * i) + half;
             if (k < a.NV && !(DBG & 16)) {
-              const f32x4 f = __builtin_bit_cast(f32x4, v[i]);   // (bit_cast of a single vector ELEMENT miscompiles)
-              if (s == 0) fold(m, sm, best, idx, f[0], f[1], f[2], (int)v[i][3]);   // slice 0 also writes the log-probability
-              else fold_best(best, idx, f[2], (int)v[i][3]);
+              const f32x2 f = __builtin_bit_cast(f32x2, v[i]);   // (bit_cast of a single vector ELEMENT miscompiles)
+              fold_best(best, idx, f[0], (int)v[i][1]);
             }
           }
-          if (s == 0) fold(m, sm, best, idx, __shfl_xor(m, 32), __shfl_xor(sm, 32), __shfl_xor(best, 32), __shfl_xor(idx, 32));
-          else fold_best(best, idx, __shfl_xor(best, 32), __shfl_xor(idx, 32));
+          fold_best(best, idx, __shfl_xor(best, 32), __shfl_xor(idx, 32));
           if (lane < 32) {
-            const u32x4 o = {__builtin_bit_cast(u32, m), __builtin_bit_cast(u32, sm), __builtin_bit_cast(u32, best), (u32)idx};
-            *(u32x4*)(gh + (w * GROWS + j) * 4) = o;           // gh is free until the GRU step
+            const u32x2 o = {__builtin_bit_cast(u32, best), (u32)idx};
+            *(u32x2*)(gh + (w * GROWS + j) * 2) = o;           // gh is free until the GRU step
           }
         }
         __syncthreads();
         if (tid < GROWS) {
-          float m = -INFINITY, sm = 0.f, best = -INFINITY;
+          float best = -INFINITY;
           int idx = -1;
 #pragma unroll
           for (int ww = 0; ww < NT / 64; ++ww) {
-            const u32x4 o = *(const u32x4*)(gh + (ww * GROWS + tid) * 4);
-            const f32x4 f = __builtin_bit_cast(f32x4, o);
-            if (s == 0) fold(m, sm, best, idx, f[0], f[1], f[2], (int)o[3]);
-            else fold_best(best, idx, f[2], (int)o[3]);
+            const u32x2 o = *(const u32x2*)(gh + (ww * GROWS + tid) * 2);
+            const f32x2 f = __builtin_bit_cast(f32x2, o);
+            fold_best(best, idx, f[0], (int)o[1]);
           }
           const int row = g * GROWS + tid;
           tok[tid] = min(max(idx, 0), a.V - 1);
-          if (s == 0 && row < a.B) {
-            a.seq[(size_t)row * a.L + t - 1] = idx;
-            a.logp[(size_t)row * a.L + t - 1] = best - (m + __logf(sm));
-          }
+          if (s == 0 && row < a.B) a.seq[(size_t)row * a.L + t - 1] = idx;
         }
       }
       __syncthreads();
@@ -383,14 +387,39 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
       }
       STAMP(4);
       __syncthreads();
-      if (w * 32 < a.Bpad) {
-        // lane c16 = i (< 8) of each 16-lane row keeps the running record of the row group's row i (row tile i >> 2,
-        // accumulator element i & 3): 4 registers of state instead of 32 while the fragments are live
-        float km = -INFINITY, ksum = 0.f, kb = -INFINITY;
-        int ki = -1;
-        // which 32 rows this wave takes is rotated by the workgroup's index within its XCD: the CUs of an XCD would otherwise
-        // ask the L2 for the same lines in the same order at the same moment
-        const int wr = (w + (r >> 3)) % (a.Bpad / 32);
+      // lane c16 = i (< 8) of each 16-lane row keeps the running record of the wave's row i (row tile i >> 2, accumulator
+      // element i & 3): a few registers of state while the fragments are live.  The symbol needs only (best, column): that
+      // record is published first; max / sum-exp (the log-probability's normaliser: 40 exponentials and twice the
+      // reductions per lane) follow AFTER the hand-off when the share is one chunk, from the accumulators still in
+      // registers, and are folded once, after the last token.
+      float km = -INFINITY, ksum = 0.f, kb = -INFINITY;
+      int ki = -1;
+      // which 32 rows this wave takes is rotated by the workgroup's index within its XCD
+      const int wr = (w + (r >> 3)) % (a.Bpad / 32);
+      const bool vwave = w * 32 < a.Bpad, defer = NCT <= CT;
+      f32x4 acc[2][CT];
+      float bv[CT];
+      int colv[CT];
+      auto sumexp = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int mt = i >> 2, j = i & 3;
+          float x[CT], mx = -INFINITY, sc = 0.f;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            x[ct] = colv[ct] >= 0 ? (acc[mt][ct][j] + bv[ct]) * a.inv_temp : -INFINITY;
+            mx = fmaxf(mx, x[ct]);
+          }
+          mx = row16_max(mx);
+          if (mx > -INFINITY) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) sc += __expf(x[ct] - mx);
+          }
+          sc = row16_sum(sc);
+          if (c16 == i) fold_ms(km, ksum, mx, sc);
+        }
+      };
+      if (vwave) {
         const unsigned abase = (unsigned)((size_t)(t + 1) * a.Bpad * Hk * 2 + (size_t)(wr * 2) * NKS * 1024 + lane * 16);
         const unsigned astep = (unsigned)(NKS * 1024);       // second row tile
         u32x4 av[2][NKS_C > 0 ? NKS_C : 1];
@@ -404,12 +433,9 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
         }
 #pragma unroll 1
         for (int c0 = 0; c0 < NCT; c0 += CT) {
-          f32x4 acc[2][CT];
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) acc[0][ct] = acc[1][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
           // this lane's columns of the chunk and their bias (requested before the MFMAs)
-          float bv[CT];
-          int colv[CT];
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             colv[ct] = r * a.NC + (c0 + ct) * 16 + c16;
@@ -448,52 +474,101 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
             }
           }
           STAMP(5);
-          // this lane's columns of the chunk (ascending): scaled logits, max / sum-exp / best allowed column per row, then
-          // the 16 lanes of a row fold (butterfly) and lane i keeps row i
+          // this lane's columns of the chunk (ascending): best allowed scaled logit and its column per row; the 16 lanes of
+          // a row reduce with DPP (lowest column among equal values) and lane i keeps row i
           if (!(DBG & 4))
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int mt = i >> 2, j = i & 3;
-            float x[CT], mx = -INFINITY, bst = -INFINITY, sc = 0.f;
+            float bst = -INFINITY;
             int bi = -1;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-              x[ct] = colv[ct] >= 0 ? (acc[mt][ct][j] + bv[ct]) * a.inv_temp : -INFINITY;
-              mx = fmaxf(mx, x[ct]);
-              if (colv[ct] >= 0 && colv[ct] != a.mask_col && x[ct] > bst) {   // ascending: the first maximum stays
-                bst = x[ct];
+              const float x = (acc[mt][ct][j] + bv[ct]) * a.inv_temp;
+              if (colv[ct] >= 0 && colv[ct] != a.mask_col && x > bst) {   // ascending: the first maximum stays
+                bst = x;
                 bi = colv[ct];
               }
             }
-            // the 16 lanes of a row: max, sum-exp against the row's max, best value and its lowest column (DPP all-reduces)
-            mx = row16_max(mx);
-            if (mx > -INFINITY) {
-#pragma unroll
-              for (int ct = 0; ct < CT; ++ct) sc += __expf(x[ct] - mx);
-            }
-            sc = row16_sum(sc);
             const float brow = row16_max(bst);
             bi = row16_min_int((bst == brow && bi >= 0) ? bi : 0x7fffffff);
-            bi = bi == 0x7fffffff ? -1 : bi;
-            bst = brow;
-            if (c16 == i) fold(km, ksum, kb, ki, mx, sc, bst, bi);
+            if (c16 == i) fold_best(kb, ki, brow, bi == 0x7fffffff ? -1 : bi);
           }
+          if (!defer) sumexp();
         }
         STAMP(6);
         if (c16 < 8 && !(DBG & 8)) {
           const int row = wr * 32 + (c16 >> 2) * 16 + q4 * 4 + (c16 & 3);
-          const u32x4 v = {__builtin_bit_cast(u32, km), __builtin_bit_cast(u32, ksum), __builtin_bit_cast(u32, kb), (u32)ki};
-          const unsigned off = (unsigned)((((size_t)t * a.NV + r) * a.Bpad + row) * sizeof(DecPart));
-          __builtin_amdgcn_raw_buffer_store_b128(v, prs, off, 0, AUX_SC1);
+          const u32x2 v = {__builtin_bit_cast(u32, kb), (u32)ki};
+          __builtin_amdgcn_raw_buffer_store_b64(v, prs, (unsigned)((((size_t)t * a.NV + r) * a.Bpad + row) * 8), 0, AUX_SC1);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 64) st_relaxed(a.flag_b + r, (u32)(t + 1));
+      if (vwave) {                                           // nobody waits for these
+        if (defer) sumexp();
+        if (c16 < 8) {
+          const int row = wr * 32 + (c16 >> 2) * 16 + q4 * 4 + (c16 & 3);
+          const u32x2 v = {__builtin_bit_cast(u32, km), __builtin_bit_cast(u32, ksum)};
+          __builtin_amdgcn_raw_buffer_store_b64(v, prs, a.part_b + (unsigned)((((size_t)t * a.NV + r) * a.Bpad + row) * 8), 0,
+                                                AUX_SC1);
+        }
+      }
       STAMP(7);
     }
   }
   if (live) a.hn[(size_t)brow * H + unit] = hreg;
+  // ---- (4) log-probabilities of the emitted symbols: once every record of every token is there, unit (t, 32 rows) folds
+  //      its 256 (best, column) and (max, sum-exp) records; units are dealt over all workgroups
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (voc && tid == 64) st_relaxed(a.flag_b + r, (u32)(a.L + 1));
+  if (w == 0 && !dead && !(DBG & 64)) dead = !wait_all_ge(a.flag_b, a.nwg, (u32)(a.L + 1), a.err, lane);
+  __syncthreads();
+  const int nrb = a.Bpad / GROWS;
+  for (int u = r; u < a.L * nrb; u += a.nwg) {
+    const int tt = u / nrb, rb = u % nrb, j = lane & 31, half = lane >> 5;
+    float m = -INFINITY, sm = 0.f, best = -INFINITY;
+    int idx = -1;
+    u32x2 va[MAX_WGS / 16], vb[MAX_WGS / 16];
+    const unsigned base = (unsigned)((((size_t)tt * a.NV) * a.Bpad + rb * GROWS + j) * 8);
+    const unsigned kstep = (unsigned)(a.Bpad * 8);
+#pragma unroll
+    for (int i = 0; i < MAX_WGS / 16; ++i) {
+      const int k = 2 * (w + 8 * i) + half;
+      if (k < a.NV) {
+        va[i] = __builtin_amdgcn_raw_buffer_load_b64(prs, base + k * kstep, 0, LDAUX);
+        vb[i] = __builtin_amdgcn_raw_buffer_load_b64(prs, a.part_b + base + k * kstep, 0, LDAUX);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAX_WGS / 16; ++i) {
+      const int k = 2 * (w + 8 * i) + half;
+      if (k < a.NV) {
+        const f32x2 fa = __builtin_bit_cast(f32x2, va[i]), fb = __builtin_bit_cast(f32x2, vb[i]);
+        fold(m, sm, best, idx, fb[0], fb[1], fa[0], (int)va[i][1]);
+      }
+    }
+    fold(m, sm, best, idx, __shfl_xor(m, 32), __shfl_xor(sm, 32), __shfl_xor(best, 32), __shfl_xor(idx, 32));
+    if (lane < 32) {
+      const u32x4 o = {__builtin_bit_cast(u32, m), __builtin_bit_cast(u32, sm), __builtin_bit_cast(u32, best), (u32)idx};
+      *(u32x4*)(gh + (w * GROWS + j) * 4) = o;
+    }
+    __syncthreads();
+    if (tid < GROWS) {
+      m = -INFINITY, sm = 0.f, best = -INFINITY, idx = -1;
+#pragma unroll
+      for (int ww = 0; ww < NT / 64; ++ww) {
+        const u32x4 o = *(const u32x4*)(gh + (ww * GROWS + tid) * 4);
+        const f32x4 f = __builtin_bit_cast(f32x4, o);
+        fold(m, sm, best, idx, f[0], f[1], f[2], (int)o[3]);
+      }
+      const int row = rb * GROWS + tid;
+      if (row < a.B) a.logp[(size_t)row * a.L + tt] = best - (m + __logf(sm));
+    }
+    __syncthreads();
+  }
 #ifdef PV_DECODE_STAMPS
   if (tid == 0 && (r < 4 || r >= a.nwg - 4))
     for (int i = 0; i < 8; ++i) a.err[576 + (r < 4 ? r : 8 - (a.nwg - r)) * 8 + i] = stamp_acc[i];
@@ -611,7 +686,7 @@ int pv_greedy_decode(const float* gx_table, const float* gx_const, const void* w
   a.hn = hn;
   a.L = L, a.B = B, a.H = H, a.Hk = p.Hk, a.Bpad = p.Bpad, a.V = V, a.G = p.G, a.S = p.S, a.NV = p.NV, a.NC = p.NC;
   a.nwg = p.nwg, a.sos = sos_id, a.mask_col = mask_col, a.ldwp = ldwp, a.inv_temp = inv_temp;
-  a.hb_bytes = (unsigned)p.hb_bytes, a.part_bytes = (unsigned)p.part_bytes;
+  a.hb_bytes = (unsigned)p.hb_bytes, a.part_bytes = (unsigned)p.part_bytes, a.part_b = (unsigned)(p.part_bytes / 2);
   static const int dbg = getenv("PV_DECODE_DBG") ? atoi(getenv("PV_DECODE_DBG")) : 0;
   a.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
