@@ -19,9 +19,11 @@
 //   * per token two chip-wide hand-offs: (A) every GRU workgroup has published its slice of h_t (bf16, 16-byte sc1
 //     stores) -> vocabulary phase: each wave multiplies 32 batch rows by the resident columns (A fragments straight
 //     from the published states, B fragments from LDS), reduces max / sum-exp / best allowed column over its columns
-//     and publishes one 16-byte record per (row, workgroup); (B) every vocabulary workgroup has published its records
-//     -> each GRU workgroup folds the records of its 32 rows in ascending column order (lowest column wins ties, as a
-//     left-to-right scan would), which gives the emitted symbol, its log-probability and the next input row.
+//     and publishes one 8-byte (best value, column) record per (row, workgroup); (B) every vocabulary workgroup has
+//     published its records -> each GRU workgroup folds the records of its 32 rows (lowest column wins ties, as a
+//     left-to-right scan would), which gives the emitted symbol = the next input row.  The (max, sum-exp) record that
+//     only the symbol's log-probability needs is computed AFTER the hand-off, from the accumulators still in
+//     registers, and all log-probabilities are folded once, after the last token, by every workgroup in parallel.
 //   * hand-off = per-workgroup flags, not counters: a workgroup stores the token number into its own word after its
 //     payload stores have drained (vmcnt(0), barrier); a waiting wave loads all flags with one coalesced sc1 load per
 //     64 workgroups.  No read-modify-write anywhere, nothing to reset between tokens.  Every wait is wall-clock
