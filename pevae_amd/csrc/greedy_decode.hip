@@ -88,8 +88,10 @@ __device__ __forceinline__ u32 ld_relaxed(const u32* p) {
 __device__ __forceinline__ void st_relaxed(u32* p, u32 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
+// v_rcp_f32 (1 ulp), not the correctly rounded division sequence __frcp_rn expands to (10 instructions per reciprocal:
+// a third of the gate phase of a recurrence step)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
 // The whole wave waits until every flag is >= want.  false: timed out or another workgroup already reported.
 __device__ __forceinline__ bool wait_all_ge(const u32* flags, int n, u32 want, u32* err, int lane) {

@@ -101,8 +101,10 @@ __device__ __forceinline__ int swz_mask_for(int nchunks) {
   return m - 1;
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
+// v_rcp_f32 (1 ulp), not the correctly rounded division sequence __frcp_rn expands to (10 instructions per reciprocal:
+// a third of the gate phase of a recurrence step)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
 // Diagnostic build only (-DPV_GRU_STAMPS): wave 0 accumulates wall-clock (100 MHz) time per segment of the
 // step into words 64.. of the sync buffer.  Never compiled into the shipped library.
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
           *(float4*)(sg + (3 * U + lu) * RW + lr) = make_float4(hn[0], hn[1], hn[2], hn[3]);
         }
       }
+      STAMP(9);
       __syncthreads();
       STAMP(5);
       // (e) publish h_step: one 16-byte write-through store per thread, drain, barrier, one arrival.

@@ -14,7 +14,7 @@ w_hh = torch.randn(3 * H, H, device=dev) * 0.05
 b = torch.zeros(3 * H, device=dev)
 h0 = torch.randn(B, H, device=dev) * 0.1
 names = ["prefetch issue", "poll", "barrier", "A loads landed", "mfma", "gates+tile+barrier", "publish+drain",
-         "barrier+arrive", "deferred stores issue"]
+         "barrier+arrive", "deferred stores issue", "gates+tile (before the barrier)"]
 for save in (True, False):
     for _ in range(5):
         with torch.no_grad():
@@ -25,5 +25,5 @@ for save in (True, False):
     print("save =", save)
     for wg in range(16):
         print("  wg", wg, " ".join("%s=%.2f" % (n, words[wg, i].item() / 100.0 / L) for i, n in enumerate(names)),
-              "| sum us/step %.2f" % (words[wg, :9].sum().item() / 100.0 / L))
+              "| sum us/step %.2f" % (words[wg, :10].sum().item() / 100.0 / L))
     ops.LAST_GRU_SYNC.clear()
