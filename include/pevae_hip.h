@@ -131,6 +131,15 @@ int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const
 size_t pv_vocab_argmax_ws_bytes(int T, int V);
 int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H, float inv_temp,
                     int mask_col, void* workspace, int64_t* ids, float* logp, void* stream);
+/* `sample` decoding without a [T][V] tensor (decoders.py:255-256 -> base_modules.py:54-59: torch.multinomial(exp(log-probs), 1),
+ * one draw per row): ids[t] = arg-max over columns != mask_col of (scaled logit - log q) with q ~ Exp(1) -- the sampler
+ * torch itself uses for one draw -- and logp[t] = the drawn symbol's log-softmax value.  noise_q (optional, [T][noise_ld]
+ * fp32): the q draws (parity tests hand the same draws to the dense path / the reference); NULL: Philox keyed by
+ * (rng_state {seed, step}, site, row, column).  workspace: pv_vocab_sample_ws_bytes(T, V). */
+size_t pv_vocab_sample_ws_bytes(int T, int V);
+int pv_vocab_sample(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H, float inv_temp,
+                    int mask_col, const float* noise_q, long noise_ld, const void* rng_state, int site,
+                    void* workspace, int64_t* ids, float* logp, void* stream);
 /* No counterpart in the reference: pv_vocab_argmax for callers that cannot allocate or pass a workspace (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  The per-slab partials live in a device array
  * built into the library (one copy per GPU, pv_vocab_argmax_noalloc_max_bytes() = 4 MiB, held until the process ends);

@@ -13,24 +13,6 @@
 
 namespace {
 
-struct RngState {        // 16 bytes of device memory
-  unsigned long long seed;
-  unsigned long long step;
-};
-
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                              uint32_t (&out)[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 // keep decisions of the 4 logical elements 4*q .. 4*q+3 of call site `site` at the state's current step
 __device__ __forceinline__ void keep4(const RngState& st, uint32_t site, unsigned long long q, uint32_t thresh, bool (&keep)[4]) {
   uint32_t r[4];

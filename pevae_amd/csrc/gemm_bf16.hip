@@ -396,17 +396,103 @@ struct EpiArgmax {
   }
 };
 
+// `sample` decoding (decoders.py:255-256 -> base_modules.py:54-59, torch.multinomial(exp(log-probs), 1)) without a [B, V]
+// tensor: one draw from softmax(x) IS arg-max_v (x_v - log q_v) with q_v ~ Exp(1) (the sampler torch uses for one draw
+// per row: arg-max of p / q), so the sampling step is the greedy epilogue on perturbed logits.  q comes from `noise`
+// ([T][noise_ld], parity tests: the same draws go to the dense path / the reference) or from Philox keyed by (seed,
+// step, site, row, column).  The record's `best` is the perturbed value (compared across slabs); the unperturbed
+// logit of that column goes to `xbest` for the emitted symbol's log-probability.
+struct EpiSample {
+  const float* bias;
+  ArgPart* part;            // [nslab][Tpad]
+  float* xbest;             // [nslab][Tpad]
+  const float* noise;
+  long noise_ld;
+  const RngState* rng;
+  uint32_t site;
+  int T, V, Tpad, mask_col;
+  float inv_temp;
+  struct Pre {
+    float bv[4];
+  };
+  __device__ Pre prefetch(int row0, int col0, int lane) const {
+    Pre p;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) p.bv[ni] = bias[min(col0 + ni * 16 + (lane & 15), V - 1)];
+    return p;
+  }
+  __device__ void operator()(f32x4 (&acc)[4][4], const Pre& pre, int row0, int col0, int w, int lane, char* smem, int split) const {
+    if (col0 >= V) return;
+    const int c16 = lane & 15, q4 = lane >> 4;
+    ArgPart mine{0.f, 0.f, 0.f, -1};
+    float mine_x = 0.f;
+    RngState st{0, 0};
+    if (!noise) st = *rng;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mi = r >> 2, j = r & 3, row = row0 + mi * 16 + q4 * 4 + j;
+      float x[4], mx = -INFINITY, bst = -INFINITY, bx = 0.f;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int col = col0 + ni * 16 + c16;
+        x[ni] = col < V ? (acc[mi][ni][j] + pre.bv[ni]) * inv_temp : -INFINITY;
+        mx = fmaxf(mx, x[ni]);
+        if (col < V && col != mask_col && row < T) {
+          float q;
+          if (noise) {
+            q = noise[(size_t)row * noise_ld + col];
+          } else {
+            uint32_t rnd[4];
+            philox4x32_10((uint32_t)col, (uint32_t)row, site, (uint32_t)st.step ^ (uint32_t)(st.step >> 32) * 0x9E3779B9u,
+                          (uint32_t)st.seed, (uint32_t)(st.seed >> 32), rnd);
+            q = -__logf(((float)(rnd[0] >> 8) + 0.5f) * (1.0f / 16777216.0f));     // Exp(1), u in (0, 1)
+          }
+          const float xs = x[ni] - __logf(q);
+          if (xs > bst) {                                      // ascending columns: the first maximum wins
+            bst = xs;
+            bx = x[ni];
+            bi = col;
+          }
+        }
+      }
+      const float m = row16_max(mx), b = row16_max(bst);
+      float sacc = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) sacc += __expf(x[ni] - m);
+      sacc = row16_sum(sacc);
+      int cand = (bst == b && b > -INFINITY) ? bi : 0x7fffffff;   // lowest column among the lanes that hold the maximum
+      cand = min(cand, dpp_movi<0xB1>(cand));
+      cand = min(cand, dpp_movi<0x4E>(cand));
+      cand = min(cand, dpp_movi<0x141>(cand));
+      cand = min(cand, dpp_movi<0x140>(cand));
+      const float xw = row16_max((bi == cand && cand != 0x7fffffff) ? bx : -INFINITY);
+      if (c16 == r) {
+        mine = ArgPart{m, sacc, b, cand == 0x7fffffff ? -1 : cand};
+        mine_x = xw;
+      }
+    }
+    const int row = row0 + (c16 >> 2) * 16 + q4 * 4 + (c16 & 3);
+    if (row < Tpad) {
+      part[(size_t)(col0 >> 6) * Tpad + row] = mine;
+      xbest[(size_t)(col0 >> 6) * Tpad + row] = mine_x;
+    }
+  }
+};
+
 // 16 threads per row, 16 rows per workgroup: thread (row r, chunk c) folds slabs c, c+16, ... in ascending order, then
 // the 16 chunk results of a row are folded in chunk order through LDS.  Fixed order (run-to-run identical); among equal
 // maxima the smallest column wins, as a left-to-right scan would choose.  (One thread per row walking all 313 slabs of
 // the Yelp vocabulary in a dependent chain took 89 us per decoded token -- a third of the greedy decode.)
-__global__ __launch_bounds__(256) void vocab_argmax_reduce_kernel(const ArgPart* __restrict__ part, int T, int Tpad, int nslab,
-                                                                   int64_t* __restrict__ ids, float* __restrict__ logp) {
-  __shared__ float sm_m[256], sm_s[256], sm_b[256];
+// xbest (sampling): the chosen column's unperturbed logit per record; NULL (greedy): the record's `best` is that logit.
+__global__ __launch_bounds__(256) void vocab_argmax_reduce_kernel(const ArgPart* __restrict__ part, const float* __restrict__ xbest,
+                                                                   int T, int Tpad, int nslab, int64_t* __restrict__ ids,
+                                                                   float* __restrict__ logp) {
+  __shared__ float sm_m[256], sm_s[256], sm_b[256], sm_x[256];
   __shared__ int sm_i[256];
   const int r = threadIdx.x & 15, c = threadIdx.x >> 4;
   const int row = min(blockIdx.x * 16 + r, Tpad - 1);
-  float m = -INFINITY, s = 0.f, best = -INFINITY;
+  float m = -INFINITY, s = 0.f, best = -INFINITY, xb = 0.f;
   int idx = -1;
   for (int k = c; k < nslab; k += 16) {
     const ArgPart p = part[(size_t)k * Tpad + row];
@@ -416,11 +502,13 @@ __global__ __launch_bounds__(256) void vocab_argmax_reduce_kernel(const ArgPart*
     if (p.idx >= 0 && (p.best > best || (p.best == best && (idx < 0 || p.idx < idx)))) {
       best = p.best;
       idx = p.idx;
+      xb = xbest ? xbest[(size_t)k * Tpad + row] : p.best;
     }
   }
   sm_m[threadIdx.x] = m;
   sm_s[threadIdx.x] = s;
   sm_b[threadIdx.x] = best;
+  sm_x[threadIdx.x] = xb;
   sm_i[threadIdx.x] = idx;
   __syncthreads();
   if (c != 0 || blockIdx.x * 16 + r >= T) return;
@@ -433,10 +521,11 @@ __global__ __launch_bounds__(256) void vocab_argmax_reduce_kernel(const ArgPart*
     if (pi >= 0 && (pb > best || (pb == best && (idx < 0 || pi < idx)))) {
       best = pb;
       idx = pi;
+      xb = sm_x[k * 16 + r];
     }
   }
   ids[blockIdx.x * 16 + r] = idx;
-  logp[blockIdx.x * 16 + r] = best - (m + logf(s));
+  logp[blockIdx.x * 16 + r] = xb - (m + logf(s));
 }
 
 constexpr int EPI_LD = 144;            // bytes per staged 64-element bf16 row (128 + 16 pad)
@@ -1034,8 +1123,32 @@ int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float*
   EpiArgmax e{bias, (ArgPart*)workspace, T, V, Tpad, mask_col, inv_temp};
   rc = launch(g, e, st, "pv_vocab_argmax");
   if (rc) return rc;
-  hipLaunchKernelGGL(vocab_argmax_reduce_kernel, dim3(cdiv(T, 16)), dim3(256), 0, st, (const ArgPart*)workspace, T, Tpad,
-                     nslab, ids, logp);
+  hipLaunchKernelGGL(vocab_argmax_reduce_kernel, dim3(cdiv(T, 16)), dim3(256), 0, st, (const ArgPart*)workspace,
+                     (const float*)nullptr, T, Tpad, nslab, ids, logp);
+  PV_LAUNCH_CHECK("vocab_argmax_reduce_kernel");
+  return PV_OK;
+}
+
+size_t pv_vocab_sample_ws_bytes(int T, int V) {
+  return pv_vocab_argmax_ws_bytes(T, V) + (size_t)cdiv(V, 64) * round_up(T, 64) * sizeof(float);
+}
+
+int pv_vocab_sample(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H, float inv_temp,
+                    int mask_col, const float* noise_q, long noise_ld, const void* rng_state, int site,
+                    void* workspace, int64_t* ids, float* logp, void* stream) {
+  int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_sample");
+  if (rc) return rc;
+  PV_REQUIRE(bias && workspace && ids && logp, "pv_vocab_sample: null argument");
+  PV_REQUIRE(noise_q ? noise_ld >= V : rng_state != nullptr, "pv_vocab_sample: needs noise_q with noise_ld >= V, or rng_state");
+  const int Tpad = round_up(T, 64), nslab = cdiv(V, 64);
+  hipStream_t st = (hipStream_t)stream;
+  float* xbest = (float*)((char*)workspace + pv_vocab_argmax_ws_bytes(T, V));
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 1, 0, nullptr, nullptr};
+  EpiSample e{bias, (ArgPart*)workspace, xbest, noise_q, noise_ld, (const RngState*)rng_state, (uint32_t)site, T, V, Tpad, mask_col, inv_temp};
+  rc = launch(g, e, st, "pv_vocab_sample");
+  if (rc) return rc;
+  hipLaunchKernelGGL(vocab_argmax_reduce_kernel, dim3(cdiv(T, 16)), dim3(256), 0, st, (const ArgPart*)workspace,
+                     (const float*)xbest, T, Tpad, nslab, ids, logp);
   PV_LAUNCH_CHECK("vocab_argmax_reduce_kernel");
   return PV_OK;
 }

@@ -16,6 +16,7 @@ from .base_modules import BaseRNN
 TEACH_FORCE = "teacher_forcing"
 TEACH_GEN = "teacher_gen"
 GEN = "gen"
+SAMPLE_SITE = 0x5A000000        # Philox call sites of the fused sampling step (dropout sites count up from 0)
 
 
 class Attention(nn.Module):
@@ -294,19 +295,30 @@ class DecoderRNN(BaseRNN):
             decoder_outputs = DeferredLogProbs(output, w, b, 1.0 / self.softmax_temperature, hid_bf16, layout, drop)
         else:
             step_outputs, cum_sum = [], None
-            fused = getattr(self, "fused_greedy", False) and gen_type == 'greedy'
+            fused = getattr(self, "fused_greedy", False) and gen_type in ('greedy', 'sample')
+            if fused and gen_type == 'sample' and getattr(self, "sample_noise", None) is None:
+                ops.rng_advance(dev)                 # a new decode draws new symbols; token di is call site SAMPLE_SITE + di
             # the projection / recurrence weights are packed to bf16 once for the whole decode, not once per token
             with ops.packed_weights():
                 for di in range(self.max_length):
                     if fused:
-                        # opt-in (self.fused_greedy = True): arg-max fused into the projection GEMM, no [B,V] log-probs; the
+                        # opt-in (self.fused_greedy = True): arg-max (or the multinomial draw of gen_type 'sample') fused into
+                        # the projection GEMM, no [B,V] log-probs; the
                         # returned decoder_outputs is then [B, L] = log-probability of each emitted symbol (a deviation from
                         # the reference's [B, L, V] return value, for callers that only consume ret_dict['sequence'])
                         output, decoder_hidden, step_attn, _ = self._hidden_states(decoder_input, decoder_hidden,
                                                                                    attn_context, latent_variable)
                         w, b = self._out_weights()
-                        symbols, lp = ops.vocab_argmax(output.reshape(-1, output.shape[-1]), w, b,
-                                                       1.0 / self.softmax_temperature, self.unk_id if self.mask_unk else -1)
+                        if gen_type == 'sample':     # torch.multinomial as arg-max of p / q, q ~ Exp(1), fused the same way
+                            noise = getattr(self, "sample_noise", None)
+                            symbols, lp = ops.vocab_sample(output.reshape(-1, output.shape[-1]), w, b,
+                                                           1.0 / self.softmax_temperature,
+                                                           self.unk_id if self.mask_unk else -1,
+                                                           noise=None if noise is None else noise[di], site=SAMPLE_SITE + di)
+                        else:
+                            symbols, lp = ops.vocab_argmax(output.reshape(-1, output.shape[-1]), w, b,
+                                                           1.0 / self.softmax_temperature,
+                                                           self.unk_id if self.mask_unk else -1)
                         symbols = symbols.view(-1, 1)
                         step_outputs.append(lp.view(-1, 1))
                         if self.use_attention:

@@ -758,6 +758,25 @@ def vocab_argmax(hid, weight, bias, inv_temp=1.0, mask_col=-1):
         return ids, logp
 
 
+def vocab_sample(hid, weight, bias, inv_temp=1.0, mask_col=-1, noise=None, site=0):
+    """One multinomial draw per row of hid [T,H] from softmax((hid W^T + b) * inv_temp) (decoders.py:255-256 ->
+    base_modules.py:54-59) without a [T,V] tensor: arg-max of (scaled logit - log q), q ~ Exp(1).  noise [T,V]: the q draws
+    (parity tests); None: Philox from ops.rng_state (advance it with ops.rng_advance between decodes) and `site`.
+    -> (ids int64 [T], logp fp32 [T] = log-probability of the drawn symbol); no gradient."""
+    with torch.no_grad():
+        _need_cuda(hid, weight, bias)
+        T, H, V, Hp, h_bf, ldh, w_bf = _vocab_operands(hid, weight)
+        dev = weight.device
+        ws = workspace("vocab_sample", _lib.load().pv_vocab_sample_ws_bytes(T, V), torch.uint8, dev)
+        ids = torch.empty(T, dtype=torch.int64, device=dev)
+        logp = torch.empty(T, dtype=torch.float32, device=dev)
+        nq = None if noise is None else noise.to(torch.float32).contiguous()
+        _lib.call("pv_vocab_sample", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias.contiguous()), T, V, Hp, inv_temp, int(mask_col),
+                  _p(nq), 0 if nq is None else nq.stride(0), _p(rng_state(dev)), int(site), _p(ws), _p(ids), _p(logp),
+                  _stream())
+        return ids, logp
+
+
 LAST_DECODE_WS = []     # workspace of the most recent pv_greedy_decode launch, for greedy_decode_check()
 
 

@@ -490,6 +490,58 @@ def test_decoder_gen_sample_golden(dev):
     assert int(a.min()) >= 0 and int(a.max()) < V and not torch.equal(a, b2)
 
 
+def test_decoder_gen_fused_sample(dev):
+    """Opt-in fused sampling step (pv_vocab_sample: the multinomial draw as arg-max of scaled logit - log q inside the
+    projection GEMM, no [B,V] tensor).  (1) With the golden's Exp(1) draws: the symbols of the reference's own run, the
+    per-symbol log-probabilities of the dense path.  (2) Generator mode (Philox): the empirical distribution of 16 384
+    draws from one row follows softmax of that row, another call site or step draws differently, mask_unk never appears."""
+    from pevae_amd.enc2dec import decoders as D
+    from pevae_amd import ops
+    g = load_golden("decoder_gen_sample")
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb), g).to(dev)
+    dec.eval()
+    dec.sample_noise = T(g["q"], dev)
+    with torch.no_grad():
+        logp, _, ret = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="sample")
+        dec.fused_greedy = True
+        lp_f, _, ret_f = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="sample")
+    seq, seq_f, want = torch.cat(ret["sequence"], 1).cpu(), torch.cat(ret_f["sequence"], 1).cpu(), T(g["seq"])
+    score = T(g["logp"]) - torch.log(T(g["q"])).transpose(0, 1)            # log(p / q) of the reference, [B, L, V]
+    exact = 0
+    for b in range(B):
+        for t in range(L):
+            if seq_f[b, t] != want[b, t]:
+                top2 = score[b, t].topk(2)[0]
+                assert float(top2[0] - top2[1]) < 3e-2, (b, t)
+                break
+        else:
+            exact += 1
+            assert ret_f["length"][b] == int(g["length"][b])
+    assert exact >= B - 1
+    same = (seq == seq_f).all(1)
+    assert int(same.sum()) >= B - 1 and tuple(lp_f.shape) == (B, L)
+    close(lp_f[same], logp.gather(2, torch.cat(ret["sequence"], 1).unsqueeze(-1)).squeeze(-1)[same].cpu(), rtol=0, atol=1e-4)
+    # generator mode on one distribution repeated 16 384 times
+    torch.manual_seed(11)
+    n, H2, V2 = 16384, 64, 50
+    hid = (torch.randn(1, H2, device=dev) * 0.7).repeat(n, 1)
+    w, bias = torch.randn(V2, H2, device=dev) * 0.3, torch.randn(V2, device=dev) * 0.2
+    ids, lp = ops.vocab_sample(hid, w, bias, inv_temp=0.8, mask_col=7, site=123)
+    ids2, _ = ops.vocab_sample(hid, w, bias, inv_temp=0.8, mask_col=7, site=124)
+    ops.rng_advance(dev)
+    ids3, _ = ops.vocab_sample(hid, w, bias, inv_temp=0.8, mask_col=7, site=123)
+    assert not torch.equal(ids, ids2) and not torch.equal(ids, ids3) and not bool((ids == 7).any())
+    logits = (hid[:1].to(torch.bfloat16).float() @ w.to(torch.bfloat16).float().t() + bias) * 0.8
+    logsm = torch.log_softmax(logits, -1)[0]
+    p = torch.softmax(logits[0].index_fill(0, torch.tensor([7], device=dev), -float("inf")), -1)   # the masked column is never drawn
+    freq = torch.bincount(ids, minlength=V2).float() / n
+    sigma = torch.sqrt(p * (1 - p) / n)
+    assert float(((freq - p).abs() / (sigma + 1e-4)).max()) < 5.0
+    close(lp, logsm[ids].cpu(), rtol=0, atol=2e-3)                            # log-probability under the UNMASKED softmax
+
+
 def test_decoder_gen_beam_golden(dev):
     """`beam` decoding (decoders.py:257-270, :307-328) against the golden built from the reference's forward_step under its
     beam rule (floor-division back pointers; see oracle/make_golden.py gen_decoder_sample_beam): raw beam symbols, the
