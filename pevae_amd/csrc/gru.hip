@@ -962,7 +962,8 @@ int rnn_fwd(int ngt, const float* xprojT, long ldx, const void* whh_bf16, const 
     PV_HIP(hipMemsetAsync(hall, 0, (size_t)Bpad * H * sizeof(float), st));      // slot 0 rows >= B are read as states
     if (ngt == 4) PV_HIP(hipMemsetAsync(call, 0, (size_t)Bpad * H * sizeof(float), st));
   }
-  hipLaunchKernelGGL(gru_pack_h0_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, h0, B, H, Hk, (bf16_t*)hseq_bf16, hn, hall,
+  const int sync_words = (int)(pv_gru_sync_bytes(B) / sizeof(u32));       // the grid must cover them too (small B * H)
+  hipLaunchKernelGGL(gru_pack_h0_kernel, dim3(cdiv(B * H > sync_words ? B * H : sync_words, 256)), dim3(256), 0, st, h0, B, H, Hk, (bf16_t*)hseq_bf16, hn, hall,
                      (u32*)sync, (int)(pv_gru_sync_bytes(B) / sizeof(u32)));
   PV_LAUNCH_CHECK("gru_pack_h0_kernel");
   if (ngt == 4) {
@@ -1044,7 +1045,8 @@ int rnn_bwd(int ngt, const float* dout, long dout_sb, long dout_st, const float*
   u32* err = (u32*)sync + NG;
   u32* counters = err + 1;
   {
-    const long n_state = (long)B * H, n_part = (long)2 * NG * 4 * H, n = n_state > n_part ? n_state : n_part;
+    const long n_state = (long)B * H, n_part = (long)2 * NG * 4 * H, n_sync = (long)(pv_gru_sync_bytes(B) / sizeof(u32));
+    const long n = n_state > n_part ? (n_state > n_sync ? n_state : n_sync) : (n_part > n_sync ? n_part : n_sync);
     hipLaunchKernelGGL(rnn_bwd_zero_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (u32*)sync,
                        (int)(pv_gru_sync_bytes(B) / sizeof(u32)), dh0, ngt == 4 ? dc0 : nullptr, n_state, dbias_part, n_part);
     PV_LAUNCH_CHECK("rnn_bwd_zero_kernel");
