@@ -581,6 +581,30 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     const int t = a.reverse ? a.L - 1 - ti : ti;         // time index of that step
     for (int rg = g; rg < a.NG; rg += a.G) {
       const int row0 = rg * RW, rbase = row0 + mt * 16 + q4 * 4;
+      // (b) wait for the group's gate gradients of the previously handled step and REQUEST this wave's fragments of them
+      //     first; the step's own operands (a) are requested behind them: the poll is then not queued behind a dozen HBM
+      //     loads (vmcnt retires in order), and those loads' latency passes under the MFMAs instead of in front of the wait
+      const int tprev = a.reverse ? a.L - 1 - (ti + 1) : ti + 1;
+      const unsigned abase = FX ? (unsigned)(((size_t)tprev * (a.Bpad >> 4) + (row0 >> 4)) * NKS * 1024 + lane * 16)
+                                : (unsigned)((((size_t)tprev * a.Bpad + row0 + c16) * K3 + q4 * 8) * 2);
+      u32x4 av[12][MT];                                      // wave w takes k-steps w, w+4, ... (12 per pass)
+      if (step > 0) {
+        if (a.flags) {
+          if (w == 0) wait_flags_ge(a.flags + rg * FLAG_STRIDE, a.S, (u32)step, a.err, lane);
+        } else if (tid == 0) wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
+        STAMP(1);
+        __syncthreads();
+        STAMP(2);
+#pragma unroll
+        for (int kk = 0; kk < 12; ++kk)
+          if (w + kk * 4 < NKS) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+              av[kk][i] = __builtin_amdgcn_raw_buffer_load_b128(
+                  grsrc, FX ? abase + (unsigned)((i * NKS + w + kk * 4) * 1024) : abase + (unsigned)(i * 16 * K3 * 2) + (w + kk * 4) * 64,
+                  0, AUX_SC1);
+          }
+      }
       // (a) independent of the exchange: saved gates / states / upstream gradients of this lane's 4 rows.  Everything is
       //     loaded unconditionally from clamped (always valid) addresses and masked where it is used: loads under
       //     data-dependent branches made the compiler wait for each one at the branch merge -- five serial round trips,
@@ -626,35 +650,27 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
           __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0) inside the branch (see the forward kernel)
         }
       }
-      // (b) recurrent term from the previously handled step: dgh[prev] @ W_hh  (K = 3H)
+      // recurrent term from the previously handled step: dgh[prev] @ W_hh  (K = 3H)
       float rec[4] = {0.f, 0.f, 0.f, 0.f};
       STAMP(0);
       if (step > 0) {
-        if (a.flags) {
-          if (w == 0) wait_flags_ge(a.flags + rg * FLAG_STRIDE, a.S, (u32)step, a.err, lane);
-        } else if (tid == 0) wait_ge(a.counters + rg, (u32)(a.S * step), a.err);
-        STAMP(1);
-        __syncthreads();
-        STAMP(2);
-        const int tprev = a.reverse ? a.L - 1 - (ti + 1) : ti + 1;
         f32x4 acc[MT][UT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < UT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned abase = FX ? (unsigned)(((size_t)tprev * (a.Bpad >> 4) + (row0 >> 4)) * NKS * 1024 + lane * 16)
-                                  : (unsigned)((((size_t)tprev * a.Bpad + row0 + c16) * K3 + q4 * 8) * 2);
-        for (int ks0 = w; ks0 < NKS; ks0 += 48) {           // wave w takes k-steps w, w+4, ... (12 per pass)
-          u32x4 av[12][MT];
+        for (int ks0 = w; ks0 < NKS; ks0 += 48) {
+          if (ks0 != w) {                                   // later passes (K > 1536): load here
 #pragma unroll
-          for (int kk = 0; kk < 12; ++kk)
-            if (ks0 + kk * 4 < NKS) {
+            for (int kk = 0; kk < 12; ++kk)
+              if (ks0 + kk * 4 < NKS) {
 #pragma unroll
-              for (int i = 0; i < MT; ++i)
-                av[kk][i] = __builtin_amdgcn_raw_buffer_load_b128(
-                    grsrc, FX ? abase + (unsigned)((i * NKS + ks0 + kk * 4) * 1024) : abase + (unsigned)(i * 16 * K3 * 2) + (ks0 + kk * 4) * 64,
-                    0, AUX_SC1);
-            }
+                for (int i = 0; i < MT; ++i)
+                  av[kk][i] = __builtin_amdgcn_raw_buffer_load_b128(
+                      grsrc, FX ? abase + (unsigned)((i * NKS + ks0 + kk * 4) * 1024) : abase + (unsigned)(i * 16 * K3 * 2) + (ks0 + kk * 4) * 64,
+                      0, AUX_SC1);
+              }
+          }
 #pragma unroll
           for (int kk = 0; kk < 12; ++kk) {
             const int ks = ks0 + kk * 4;
