@@ -234,8 +234,9 @@ def gru_ref(x, h0, w_ih, w_hh, b_ih, b_hh, emulate_bf16):
 
 # (6, 12, 20, 96) and (3, 9, 10, 48): several unit slices per row group with fewer state elements than sync words -- the
 # arrival flags of the launch must be zeroed all the same (a recycled sync buffer holds the previous launch's step counts)
+# (544, 3, 16, 512): more row groups than co-resident workgroups in both kernels (a workgroup walks several groups per step)
 @pytest.mark.parametrize("B,L,E,H", [(4, 7, 12, 16), (37, 5, 20, 32), (6, 12, 20, 96), (3, 9, 10, 48), (64, 6, 100, 128),
-                                     (256, 4, 100, 512)])
+                                     (256, 4, 100, 512), (544, 3, 16, 512)])
 def test_gru_layer(dev, B, L, E, H):
     from pevae_amd import ops
     torch.manual_seed(3)
