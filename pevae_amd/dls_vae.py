@@ -15,6 +15,7 @@ states (H -> H/16, activations kept), DLS_Auto latent fusion over the three deep
 x_init_connector = Block(H/4, H/2) -> Block(H/2, H) into the decoder state; rkl_weight fixed at 1 (the reference's
 adaptive rkl_weight, :3564-3567, uses attributes that are never defined).  oracle/ref_step.py holds the same composition on the CPU oracle modules.
 """
+import os
 from argparse import Namespace
 
 import torch
@@ -24,6 +25,8 @@ from . import criterions, dls_latent as L, nn_lib, ops
 from .enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
 from .enc2dec.encoders import EncoderRNN
 from .utils import Pack
+
+PREPARE_ON_SIDE = os.environ.get("PEVAE_PREPARE_ON_SIDE", "1") == "1"      # DLSVAE._prepare_on_side
 
 # vocab = [<pad>, <unk>, <sys>, <usr>] + words by frequency (corpora.py:649).  <s> and </s> open and close every
 # sentence (corpora.py:620), so on a real corpus they are the two most frequent words: ids 4 and 5.  The model takes
@@ -154,6 +157,8 @@ class DLSVAE(nn.Module):
     def forward(self, data_feed, mode=TEACH_FORCE, gen_type="greedy", eps=None):
         if self.training and self.config.dropout > 0:
             ops.rng_advance(self.x_embedding.weight.device)      # new dropout masks every step, also under graph replay
+        if data_feed["user_ids"].is_cuda and mode == TEACH_FORCE and PREPARE_ON_SIDE:
+            self._prepare_on_side(data_feed)
         early_sn = self.latent_stack == "dls" and data_feed["user_ids"].is_cuda
         if early_sn:
             # all 105 power iterations (one launch group) beside the launches in front of the encoder recurrence, whose
@@ -221,6 +226,28 @@ class DLSVAE(nn.Module):
             diff = self._rating(user, item) - data_feed["ratings"]                         # main_pretrain.py:891-893
             pack["rating_mse"] = ops.mean(diff * diff)
         return pack
+
+    def _prepare_on_side(self, data_feed):
+        """What the decoder half of the step needs and the inputs of the step already determine, made on the side stream
+        beside the embedding / encoder launches (joined by the encoder recurrence's launch): the bf16 operand copies of
+        the vocabulary projection and of the decoder's recurrence weights, and -- for the teacher-forced fused path -- the
+        targets in operand row order with their live-row partition.  Consumed once by ops.pack_matrix /
+        DeferredLogProbs.token_nll; anything left over is dropped at the next call."""
+        ops.clear_prepared()
+        dec = self.x_decoder
+        rnn = dec.rnn
+        if rnn.cell != "gru" or rnn.num_layers != 1 or rnn.bidirectional:
+            return
+        labels = data_feed["ans_ids"]
+        B, Ld = labels.shape[0], labels.shape[1]
+        H = rnn.hidden_size
+        Hk, _K3, Bpad, _NG = ops.gru_geometry(B, H)
+        w_ih, w_hh, _b1, _b2 = rnn.layer_weights(0, 0)
+        with ops.fork_side():
+            ops.prepack_weights([(dec._out_weights()[0], ops.round_up(H, 64)), (w_hh, Hk),
+                                 (w_ih, ops.round_up(w_ih.shape[1], 64))])
+            if not (self.config.use_attention) and torch.is_grad_enabled():
+                ops.precompact_targets(labels, (Ld, B, Bpad), self.pad_id)
 
     def _rating(self, user, item):
         x = torch.cat([user, item], -1)

@@ -83,13 +83,17 @@ class DeferredLogProbs(object):
         B, L, H = self.hid.shape
         if self.hid_bf16 is not None or (self.drop is not None and self.layout is not None):
             Lh, Bh, Bpad = self.layout
-            tgt = labels.reshape(B, L).t()
-            if Bpad != B:
-                pad = torch.full((L, Bpad - B), ignore_index, dtype=labels.dtype, device=labels.device)
-                tgt = torch.cat([tgt, pad], dim=1)
-            tgt = tgt.contiguous().view(-1)
+            pre = ops.take_precompact(labels, tuple(self.layout), ignore_index)      # made at the start of the forward pass
+            if pre is not None:
+                tgt, pre = pre[0], (pre[1], pre[2])
+            else:
+                tgt = labels.reshape(B, L).t()
+                if Bpad != B:
+                    pad = torch.full((L, Bpad - B), ignore_index, dtype=labels.dtype, device=labels.device)
+                    tgt = torch.cat([tgt, pad], dim=1)
+                tgt = tgt.contiguous().view(-1)
             nll, _ = ops.VocabNLL.apply(self.hid, self.weight, self.bias, tgt, self.inv_temp, ignore_index,
-                                        self.hid_bf16, self.layout, self.drop)
+                                        self.hid_bf16, self.layout, self.drop, pre)
         elif self.drop is not None:
             tgt = labels.reshape(-1)
             nll, _ = ops.VocabNLL.apply(self.hid, self.weight, self.bias, tgt, self.inv_temp, ignore_index, None, None,

@@ -324,10 +324,59 @@ class packed_weights(object):
         return False
 
 
+_PREPACK = {}           # (data_ptr, shape, ld) -> bf16 operand made ahead of its use on the side stream (prepack_weights)
+_PRECOMPACT = {}        # see precompact_targets()
+
+
+def clear_prepared():
+    _PREPACK.clear()
+    _PRECOMPACT.clear()
+
+
+def prepack_weights(pairs):
+    """Make the bf16 operand copies of weight matrices now -- the caller runs this under fork_side() at the start of a
+    forward pass, beside the first launches -- for pack_matrix() to hand out ONCE later in the same pass (the projection
+    weight alone is a 61 MB pass in front of the vocabulary kernels otherwise).  The consumer must sit behind a
+    join_side_work(); entries that nobody asked for are dropped by the next clear_prepared()."""
+    for w, ld in pairs:
+        R, Cc = w.shape
+        _PREPACK[(w.data_ptr(), R, Cc, tuple(w.stride()), ld)] = cast_pack(w.contiguous(), 1, R, R, Cc, 0, Cc, 1, ld)
+
+
+def precompact_targets(labels, layout, ignore_index):
+    """The vocabulary kernels' target vector in operand row order (time-major, padded to Bpad rows per step, with
+    `layout` = (L, B, Bpad); else flat) and the stable partition of its live rows (pv_vocab_compact): both depend on the
+    labels alone, so they are made at the start of the forward pass on the side stream.  -> key for take_precompact()."""
+    B, L = labels.shape[0], labels.shape[1]
+    if layout is not None:
+        Lh, Bh, Bpad = layout
+        tgt = labels.reshape(B, L).t()
+        if Bpad != B:
+            tgt = torch.cat([tgt, torch.full((L, Bpad - B), ignore_index, dtype=labels.dtype, device=labels.device)], dim=1)
+        tgt = tgt.contiguous().view(-1)
+    else:
+        tgt = labels.reshape(-1).contiguous()
+    T = tgt.numel()
+    perm = count = None
+    if SKIP_IGNORED_TOKENS and ignore_index >= 0:
+        perm = torch.empty(T, dtype=torch.int64, device=tgt.device)
+        count = torch.empty(1, dtype=torch.int32, device=tgt.device)
+        _lib.call("pv_vocab_compact", _p(tgt), T, ignore_index, _p(perm), _p(count), _stream())
+    _PRECOMPACT[(labels.data_ptr(), labels._version, tuple(labels.shape), layout, ignore_index)] = (tgt, perm, count)
+
+
+def take_precompact(labels, layout, ignore_index):
+    return _PRECOMPACT.pop((labels.data_ptr(), labels._version, tuple(labels.shape), layout, ignore_index), None)
+
+
 def pack_matrix(w, ld=None):
     """fp32 [R,C] contiguous -> bf16 [R][ld] (ld = round_up(C,64) by default)."""
     R, Cc = w.shape
     ld = round_up(Cc, 64) if ld is None else ld
+    if _PREPACK:
+        hit = _PREPACK.pop((w.data_ptr(), R, Cc, tuple(w.stride()), ld), None)
+        if hit is not None:
+            return hit
     if _PACK_CACHE is not None:
         key = (w.data_ptr(), R, Cc, tuple(w.stride()), ld)
         hit = _PACK_CACHE.get(key)
@@ -544,7 +593,7 @@ class VocabNLL(torch.autograd.Function):
     memory (static launch geometry, graph-capturable).  PEVAE_VOCAB_DENSE=1 computes every row like the reference."""
 
     @staticmethod
-    def forward(ctx, hid, weight, bias, target, inv_temp, ignore_index, hid_bf16, layout, drop=None):
+    def forward(ctx, hid, weight, bias, target, inv_temp, ignore_index, hid_bf16, layout, drop=None, pre=None):
         # hid: fp32 [T,H] -- or, with `hid_bf16` ([L*Bpad, ld] time-major bf16 rows from the GRU kernel) and
         # layout=(L,B,Bpad), the batch-first [B,L,H] tensor the gradient is returned for.  `target` follows
         # the row order of the bf16 operand.
@@ -576,11 +625,15 @@ class VocabNLL(torch.autograd.Function):
         perm = count = None
         ctx.fused = False
         if FUSED_VOCAB and any(ctx.needs_input_grad[:3]) and _lib.load().pv_vocab_fused_supported(Hp):
-            return VocabNLL._forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf)
+            return VocabNLL._forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf,
+                                           pre)
         if SKIP_IGNORED_TOKENS and ignore_index >= 0:
-            perm = torch.empty(T, dtype=torch.int64, device=dev)
-            count = torch.empty(1, dtype=torch.int32, device=dev)
-            _lib.call("pv_vocab_compact", _p(target), T, ignore_index, _p(perm), _p(count), _stream())
+            if pre is not None and pre[0] is not None:
+                perm, count = pre
+            else:
+                perm = torch.empty(T, dtype=torch.int64, device=dev)
+                count = torch.empty(1, dtype=torch.int32, device=dev)
+                _lib.call("pv_vocab_compact", _p(target), T, ignore_index, _p(perm), _p(count), _stream())
             h_c = torch.empty((T, Hp), dtype=BF16, device=dev)
             t_c = torch.empty(T, dtype=torch.int64, device=dev)
             _lib.call("pv_vocab_gather", _p(h_bf), ldh, _p(target), _p(perm), T, Hp, _p(h_c), Hp, _p(t_c), _stream())
@@ -610,14 +663,17 @@ class VocabNLL(torch.autograd.Function):
         return nll, lse
 
     @staticmethod
-    def _forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf):
+    def _forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf, pre=None):
         dev = weight.device
         perm = count = t_c = None
         t32 = torch.empty(T, dtype=torch.int32, device=dev)
         if SKIP_IGNORED_TOKENS and ignore_index >= 0:
-            perm = torch.empty(T, dtype=torch.int64, device=dev)
-            count = torch.empty(1, dtype=torch.int32, device=dev)
-            _lib.call("pv_vocab_compact", _p(target), T, ignore_index, _p(perm), _p(count), _stream())
+            if pre is not None and pre[0] is not None:      # (perm, count) made ahead by precompact_targets()
+                perm, count = pre
+            else:
+                perm = torch.empty(T, dtype=torch.int64, device=dev)
+                count = torch.empty(1, dtype=torch.int32, device=dev)
+                _lib.call("pv_vocab_compact", _p(target), T, ignore_index, _p(perm), _p(count), _stream())
             h_c = torch.empty((T, Hp), dtype=BF16, device=dev)
             t_c = torch.empty(T, dtype=torch.int64, device=dev)
             _lib.call("pv_vocab_gather32", _p(h_bf), ldh, _p(target), _p(perm), T, Hp, _p(h_c), Hp, _p(t_c), _p(t32), _stream())
@@ -685,12 +741,12 @@ class VocabNLL(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dnll, _dlse):
         if dnll is None:
-            return (None,) * 9
+            return (None,) * 10
         if ctx.fused:
             dH, dW, dbias = VocabNLL._backward_fused(ctx, dnll)
             T, H, V, Hp, ldh, inv_temp, ignore_index = ctx.dims
             dev = dH.device
-            return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None)
+            return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None, None)
         if ctx.compact:
             h_bf, w_bf, bias, target, lse, perm, count = ctx.saved_tensors
         else:
@@ -715,7 +771,7 @@ class VocabNLL(torch.autograd.Function):
             dH_c = dH
             dH = torch.empty((T, H), dtype=torch.float32, device=dev)
             _lib.call("pv_scatter_rows_f32", _p(dH_c), H, _p(perm), _p(count), T, H, _p(dH), H, _stream())
-        return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None)
+        return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None, None)
 
     @staticmethod
     def _finish_dh(ctx, dH, H, dev):
