@@ -1,6 +1,7 @@
 """Diagnostic: time of one persistent greedy decode with parts of the kernel switched off (PV_DECODE_DBG bits: 1 vocab A
 loads, 2 vocab MFMAs, 4 epilogue math, 8 record stores, 16 reduce loads, 32 GRU MFMAs, 64 all waits; results are wrong
-with any bit set).  Usage: PV_DECODE_DBG=<bits> python tools/decode_ablate.py"""
+with any bit set; the bits exist only in the ablation build: make -C pevae_amd/csrc ablate).
+Usage: PEVAE_HIP_LIB=pevae_amd/lib/libpevae_hip_ablate.so PV_DECODE_DBG=<bits> python tools/decode_ablate.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
