@@ -237,6 +237,12 @@ int pv_masked_sum(const float* x, const int64_t* mask, int64_t ignore, long n, f
  * backward, gscale[t] = dnll[perm ? perm[t] : t] * (target[t] != ignore): one launch each for what was a chain of
  * fill / compare / cast / gather / multiply kernels behind criterions.py:55-64. */
 int pv_masked_sum_bwd(const int64_t* mask, int64_t ignore, const float* g, long n, float* dx, void* stream);
+/* NLLEntropy(avg_type 'seq') and Perplexity of one step (criterions.py:64 loss / batch_size; :137 exp(loss / n_words)) from
+ * sums2 = {sum of the token NLL, number of live tokens} (pv_masked_sum): out2 = {total / batch, exp(total / count)} in one
+ * launch; backward: dsums2 = {g_nll / batch + g_ppl * ppl / count, 0} (either gradient may be NULL). */
+int pv_nll_head_fwd(const float* sums2, int batch, float* out2, void* stream);
+int pv_nll_head_bwd(const float* sums2, const float* out2, const float* g_nll, const float* g_ppl, int batch, float* dsums2,
+                    void* stream);
 int pv_vocab_gscale(const float* dnll, const int64_t* perm, const int64_t* target, int64_t ignore, int T, float* gscale,
                     void* stream);
 /* dense-input NLL (criterions.py:57-63 on a materialised log-prob tensor): out[t] = -logp[t][target[t]] */

@@ -90,6 +90,8 @@ SIGNATURES = {
     "pv_masked_sum_bwd": (i32, [vp, i64, vp, lng, vp, vp]),
     "pv_vocab_gscale": (i32, [vp, vp, vp, i64, i32, vp, vp]),
     "pv_masked_sum": (i32, [vp, vp, i64, lng, vp, vp]),
+    "pv_nll_head_fwd": (i32, [vp, i32, vp, vp]),
+    "pv_nll_head_bwd": (i32, [vp, vp, vp, vp, i32, vp, vp]),
     "pv_pick_nll_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "pv_pick_nll_bwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "pv_reparam_kl_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -3,11 +3,15 @@
 NLLEntropy / Perplexity accept either a dense log-prob tensor (reference behaviour) or the decoder's
 `DeferredLogProbs`, in which case the fused vocab GEMM + online-softmax + NLL kernel is used and the [B,L,V]
 tensor is never built."""
+import os
+
 import torch
 from torch.nn.modules.loss import _Loss
 
 from . import ops
 from .enc2dec.decoders import DeferredLogProbs
+
+FUSED_HEAD = os.environ.get("PEVAE_NLL_HEAD", "1") == "1"      # ops.NllHead: 'seq' NLL and perplexity in one launch
 
 
 def _token_nll(net_output, labels, padding_idx):
@@ -36,6 +40,8 @@ class NLLEntropy(_Loss):
 
     def forward(self, net_output, labels):
         batch_size = net_output.size(0)
+        if self.avg_type == 'seq' and isinstance(net_output, DeferredLogProbs) and FUSED_HEAD:
+            return net_output.loss_head(labels, self.padding_idx)[0]
         total, count = _token_nll(net_output, labels, self.padding_idx)
         if self.avg_type is None:
             return total
@@ -56,6 +62,8 @@ class Perplexity(_Loss):
             raise NotImplementedError("pevae_amd Perplexity: per-word loss weights are not supported")
 
     def forward(self, net_output, labels):
+        if isinstance(net_output, DeferredLogProbs) and FUSED_HEAD:
+            return net_output.loss_head(labels, self.padding_idx)[1]
         total, count = _token_nll(net_output, labels, self.padding_idx)
         return torch.exp(total / count)
 

@@ -712,6 +712,22 @@ int pv_vocab_gscale(const float* dnll, const int64_t* perm, const int64_t* targe
   return PV_OK;
 }
 
+// NLLEntropy(avg_type 'seq') and Perplexity of one step from the pair {sum of the token NLL, live tokens} in one launch
+// each way (criterions.py:64 loss / batch, :137 exp(loss / n_words)): out2 = {total / batch, exp(total / count)};
+// backward: d total = g_nll / batch + g_ppl * ppl / count (count carries no gradient).
+static __global__ void nll_head_fwd_kernel(const float* __restrict__ sums, float inv_batch, float* __restrict__ out2) {
+  const float total = sums[0], count = sums[1];
+  out2[0] = total * inv_batch;
+  out2[1] = __expf(total / count);
+}
+static __global__ void nll_head_bwd_kernel(const float* __restrict__ sums, const float* __restrict__ out2, const float* __restrict__ g_nll,
+                                    const float* __restrict__ g_ppl, float inv_batch, float* __restrict__ dsums) {
+  float d = g_nll ? g_nll[0] * inv_batch : 0.f;
+  if (g_ppl) d += g_ppl[0] * out2[1] / sums[1];
+  dsums[0] = d;
+  dsums[1] = 0.f;
+}
+
 int pv_masked_sum(const float* x, const int64_t* mask, int64_t ignore, long n, float* out2, void* stream) {
   PV_REQUIRE(x && out2 && n >= 0, "pv_masked_sum: bad argument");
   hipLaunchKernelGGL(masked_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, mask, ignore, n, out2);
@@ -757,6 +773,22 @@ int pv_colsum_f32(const float* X, int R, long ld, int n, float* out, int accumul
   hipLaunchKernelGGL(colsum_f32_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, X, R, ld, n, out,
                      accumulate);
   PV_LAUNCH_CHECK("colsum_f32_kernel");
+  return PV_OK;
+}
+
+int pv_nll_head_fwd(const float* sums2, int batch, float* out2, void* stream) {
+  PV_REQUIRE(sums2 && out2 && batch > 0, "pv_nll_head_fwd: bad argument");
+  hipLaunchKernelGGL(nll_head_fwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums2, 1.0f / (float)batch, out2);
+  PV_LAUNCH_CHECK("nll_head_fwd_kernel");
+  return PV_OK;
+}
+
+int pv_nll_head_bwd(const float* sums2, const float* out2, const float* g_nll, const float* g_ppl, int batch, float* dsums2,
+                    void* stream) {
+  PV_REQUIRE(sums2 && out2 && dsums2 && batch > 0, "pv_nll_head_bwd: bad argument");
+  hipLaunchKernelGGL(nll_head_bwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums2, out2, g_nll, g_ppl,
+                     1.0f / (float)batch, dsums2);
+  PV_LAUNCH_CHECK("nll_head_bwd_kernel");
   return PV_OK;
 }
 

@@ -116,6 +116,20 @@ class DeferredLogProbs(object):
             hit = self._nll_cache[key] = ops.MaskedSum.apply(nll, tgt, ignore_index)
         return hit[0], hit[1]
 
+    def loss_head(self, labels, ignore_index):
+        """(NLLEntropy avg_type 'seq', Perplexity) of these labels as device scalars, one launch for both (ops.NllHead);
+        the two criterions of a step ask for one each."""
+        key = ("head", labels.data_ptr(), labels._version, tuple(labels.shape), ignore_index)
+        hit = self._nll_cache.get(key)
+        if hit is None:
+            skey = ("sums", labels.data_ptr(), labels._version, tuple(labels.shape), ignore_index)
+            sums = self._nll_cache.get(skey)
+            if sums is None:
+                nll, tgt = self.token_nll(labels, ignore_index)
+                sums = self._nll_cache[skey] = ops.MaskedSum.apply(nll, tgt, ignore_index)
+            hit = self._nll_cache[key] = ops.NllHead.apply(sums, self.hid.shape[0])
+        return hit
+
     # -- dense fallback: behaves like the reference's tensor ---------------------------------------------------
     def materialize(self):
         if self._dense is None:

@@ -1578,6 +1578,32 @@ class MaskedSum(torch.autograd.Function):
         return dx.view(shape), None, None
 
 
+class NllHead(torch.autograd.Function):
+    """(NLLEntropy 'seq', Perplexity) of one step from MaskedSum's pair {sum of token NLL, live tokens}: total / batch and
+    exp(total / count) (criterions.py:64, :137) in ONE launch, and one launch back -- the stock form is three scalar
+    launches forward (div, div, exp) and three backward (div, and the zero-fill + copy of indexing the pair)."""
+
+    @staticmethod
+    def forward(ctx, sums, batch):
+        _need_cuda(sums)
+        out = torch.empty(2, dtype=torch.float32, device=sums.device)
+        _lib.call("pv_nll_head_fwd", _p(sums), int(batch), _p(out), _stream())
+        ctx.save_for_backward(sums, out)
+        ctx.batch = int(batch)
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_nll, g_ppl):
+        sums, out = ctx.saved_tensors
+        if g_nll is None and g_ppl is None:
+            return None, None
+        d = torch.empty(2, dtype=torch.float32, device=sums.device)
+        _lib.call("pv_nll_head_bwd", _p(sums), _p(out), _p(None if g_nll is None else g_nll.contiguous()),
+                  _p(None if g_ppl is None else g_ppl.contiguous()), ctx.batch, _p(d), _stream())
+        return d, None
+
+
 def sum(x):
     return MaskedSum.apply(x, None, 0)[0]
 

@@ -667,3 +667,23 @@ def test_gemm_transposed_store_exact(dev):
         ops.gemm_nt_ct(A.to(dev).to(torch.bfloat16), K, Bm.to(dev).to(torch.bfloat16), K, M, N, K, bias.to(dev), out)
         assert torch.equal(out[:, :M].cpu(), (A @ Bm.t() + bias).t())
         assert float((out[:, M:] - 9.0).abs().max()) == 0.0 if ld > M else True
+
+
+def test_nll_head_matches_the_scalar_ops(dev):
+    """ops.NllHead: {total / batch, exp(total / count)} and its gradient against the stock scalar arithmetic
+    (criterions.py:64 and :137)."""
+    from pevae_amd import ops
+    sums = torch.tensor([5231.75, 7050.0], device=dev, requires_grad=True)
+    ref = sums.detach().clone().requires_grad_()
+    nll, ppl = ops.NllHead.apply(sums, 256)
+    nll_r, ppl_r = ref[0] / 256, torch.exp(ref[0] / ref[1])
+    np.testing.assert_allclose(float(nll), float(nll_r), rtol=1e-6)
+    np.testing.assert_allclose(float(ppl), float(ppl_r), rtol=1e-5)
+    (3.0 * nll + 0.5 * ppl).backward()
+    (3.0 * nll_r + 0.5 * ppl_r).backward()
+    np.testing.assert_allclose(float(sums.grad[0]), float(ref.grad[0]), rtol=1e-5)
+    assert float(sums.grad[1]) == 0.0          # the token count carries no gradient (a constant of the batch)
+    sums.grad = None
+    nll2, _ = ops.NllHead.apply(sums, 256)
+    nll2.backward()                            # only one of the two outputs used
+    np.testing.assert_allclose(float(sums.grad[0]), 1.0 / 256, rtol=1e-6)
