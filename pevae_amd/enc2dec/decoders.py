@@ -6,6 +6,8 @@ to the fused MFMA GEMM + online-softmax + NLL kernel that never builds the logit
 (`.materialize()`, indexing, torch functions) builds the dense tensor with the same GEMM core, so other callers
 still see reference behaviour.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -16,6 +18,7 @@ from .base_modules import BaseRNN
 TEACH_FORCE = "teacher_forcing"
 TEACH_GEN = "teacher_gen"
 GEN = "gen"
+SUMS_ONLY = os.environ.get("PEVAE_VOCAB_SUMS_ONLY", "1") == "1"     # DeferredLogProbs._sums
 SAMPLE_SITE = 0x5A000000        # Philox call sites of the fused sampling step (dropout sites count up from 0)
 
 
@@ -74,12 +77,14 @@ class DeferredLogProbs(object):
         self._nll_cache = {}
 
     # -- what the criterions use -------------------------------------------------------------------------
-    def token_nll(self, labels, ignore_index):
-        """(nll_tok, n_valid): per-token -log p[label] (0 where label == ignore_index) without the logits."""
+    def token_nll(self, labels, ignore_index, sums_only=False):
+        """(nll_tok, targets in row order): per-token -log p[label] (0 where label == ignore_index) without the logits.
+        sums_only: the caller only wants {sum, live count}; where the fused kernels run, the first result is then that pair
+        already (third result True) and the per-token vector is never put back into the caller's row order."""
         key = (labels.data_ptr(), labels._version, tuple(labels.shape), ignore_index)
         hit = self._nll_cache.get(key)
         if hit is not None:
-            return hit
+            return hit + (False,)
         B, L, H = self.hid.shape
         if self.hid_bf16 is not None or (self.drop is not None and self.layout is not None):
             Lh, Bh, Bpad = self.layout
@@ -93,27 +98,33 @@ class DeferredLogProbs(object):
                     tgt = torch.cat([tgt, pad], dim=1)
                 tgt = tgt.contiguous().view(-1)
             nll, _ = ops.VocabNLL.apply(self.hid, self.weight, self.bias, tgt, self.inv_temp, ignore_index,
-                                        self.hid_bf16, self.layout, self.drop, pre)
+                                        self.hid_bf16, self.layout, self.drop, pre, sums_only)
         elif self.drop is not None:
             tgt = labels.reshape(-1)
             nll, _ = ops.VocabNLL.apply(self.hid, self.weight, self.bias, tgt, self.inv_temp, ignore_index, None, None,
-                                        self.drop)
+                                        self.drop, None, sums_only)
         else:
             tgt = labels.reshape(-1)
             nll, _ = ops.VocabNLL.apply(self.hid.reshape(B * L, H), self.weight, self.bias, tgt, self.inv_temp,
-                                        ignore_index, None, None)
+                                        ignore_index, None, None, None, None, sums_only)
+        if sums_only and nll.numel() == 2 and tgt.numel() != 2:
+            return nll, tgt, True
         res = (nll, tgt)
         self._nll_cache[key] = res
-        return res
+        return res + (False,)
+
+    def _sums(self, labels, ignore_index):
+        key = ("sums", labels.data_ptr(), labels._version, tuple(labels.shape), ignore_index)
+        hit = self._nll_cache.get(key)
+        if hit is None:
+            out, tgt, is_sums = self.token_nll(labels, ignore_index, sums_only=SUMS_ONLY)
+            hit = self._nll_cache[key] = out if is_sums else ops.MaskedSum.apply(out, tgt, ignore_index)
+        return hit
 
     def token_nll_sums(self, labels, ignore_index):
         """(sum of the token NLL, number of non-ignored tokens) as device scalars; NLLEntropy and Perplexity of one step
         ask for the same pair, which is reduced once."""
-        key = ("sums", labels.data_ptr(), labels._version, tuple(labels.shape), ignore_index)
-        hit = self._nll_cache.get(key)
-        if hit is None:
-            nll, tgt = self.token_nll(labels, ignore_index)
-            hit = self._nll_cache[key] = ops.MaskedSum.apply(nll, tgt, ignore_index)
+        hit = self._sums(labels, ignore_index)
         return hit[0], hit[1]
 
     def loss_head(self, labels, ignore_index):
@@ -122,12 +133,7 @@ class DeferredLogProbs(object):
         key = ("head", labels.data_ptr(), labels._version, tuple(labels.shape), ignore_index)
         hit = self._nll_cache.get(key)
         if hit is None:
-            skey = ("sums", labels.data_ptr(), labels._version, tuple(labels.shape), ignore_index)
-            sums = self._nll_cache.get(skey)
-            if sums is None:
-                nll, tgt = self.token_nll(labels, ignore_index)
-                sums = self._nll_cache[skey] = ops.MaskedSum.apply(nll, tgt, ignore_index)
-            hit = self._nll_cache[key] = ops.NllHead.apply(sums, self.hid.shape[0])
+            hit = self._nll_cache[key] = ops.NllHead.apply(self._sums(labels, ignore_index), self.hid.shape[0])
         return hit
 
     # -- dense fallback: behaves like the reference's tensor ---------------------------------------------------

@@ -593,7 +593,7 @@ class VocabNLL(torch.autograd.Function):
     memory (static launch geometry, graph-capturable).  PEVAE_VOCAB_DENSE=1 computes every row like the reference."""
 
     @staticmethod
-    def forward(ctx, hid, weight, bias, target, inv_temp, ignore_index, hid_bf16, layout, drop=None, pre=None):
+    def forward(ctx, hid, weight, bias, target, inv_temp, ignore_index, hid_bf16, layout, drop=None, pre=None, sums_only=False):
         # hid: fp32 [T,H] -- or, with `hid_bf16` ([L*Bpad, ld] time-major bf16 rows from the GRU kernel) and
         # layout=(L,B,Bpad), the batch-first [B,L,H] tensor the gradient is returned for.  `target` follows
         # the row order of the bf16 operand.
@@ -626,7 +626,7 @@ class VocabNLL(torch.autograd.Function):
         ctx.fused = False
         if FUSED_VOCAB and any(ctx.needs_input_grad[:3]) and _lib.load().pv_vocab_fused_supported(Hp):
             return VocabNLL._forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf,
-                                           pre)
+                                           pre, sums_only)
         if SKIP_IGNORED_TOKENS and ignore_index >= 0:
             if pre is not None and pre[0] is not None:
                 perm, count = pre
@@ -663,7 +663,8 @@ class VocabNLL(torch.autograd.Function):
         return nll, lse
 
     @staticmethod
-    def _forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf, pre=None):
+    def _forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf, pre=None,
+                       sums_only=False):
         dev = weight.device
         perm = count = t_c = None
         t32 = torch.empty(T, dtype=torch.int32, device=dev)
@@ -689,7 +690,13 @@ class VocabNLL(torch.autograd.Function):
             _lib.call("pv_vocab_fused_fwd", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias_c), _p(t32), T, V, Hp, inv_temp, ignore_index,
                       _p(ws), _p(lse), _p(nll), _p(U), _p(count), _stream())
         lse_c = lse
-        if perm is not None:
+        ctx.sums_only = False
+        if perm is not None and sums_only:
+            # the caller wants {sum, live count} only: reduce the compact rows where they are (rows past the live count
+            # carry the ignore index in the compact target vector) -- no scatter back to the caller's row order
+            nll = masked_sum(nll, target, ignore_index)
+            ctx.sums_only = True
+        elif perm is not None:
             nll_c = nll
             nll = torch.empty(T, dtype=torch.float32, device=dev)
             lse = torch.empty(T, dtype=torch.float32, device=dev)
@@ -710,8 +717,12 @@ class VocabNLL(torch.autograd.Function):
         T, H, V, Hp, ldh, inv_temp, ignore_index = ctx.dims
         dev = w_bf.device
         gscale = torch.empty(T, dtype=torch.float32, device=dev)      # `target` is already in compact order
-        _lib.call("pv_vocab_gscale", _p(dnll.to(torch.float32).contiguous()), _p(perm), _p(target), ignore_index, T, _p(gscale),
-                  _stream())
+        if ctx.sums_only:            # dnll = d{sum, count}: every live row's upstream gradient is d sum
+            _lib.call("pv_masked_sum_bwd", _p(target), ignore_index, _p(dnll.to(torch.float32).contiguous()), T, _p(gscale),
+                      _stream())
+        else:
+            _lib.call("pv_vocab_gscale", _p(dnll.to(torch.float32).contiguous()), _p(perm), _p(target), ignore_index, T,
+                      _p(gscale), _stream())
         dH = torch.empty((T, H), dtype=torch.float32, device=dev)
         _lib.call("pv_scatter_rows_scaled_f32", _p(U), _p(gscale), inv_temp, _p(perm), _p(count), T, H, _p(dH), H, _stream())
         weight, _bias = ctx.params
@@ -741,12 +752,12 @@ class VocabNLL(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dnll, _dlse):
         if dnll is None:
-            return (None,) * 10
+            return (None,) * 11
         if ctx.fused:
             dH, dW, dbias = VocabNLL._backward_fused(ctx, dnll)
             T, H, V, Hp, ldh, inv_temp, ignore_index = ctx.dims
             dev = dH.device
-            return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None, None)
+            return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None, None, None)
         if ctx.compact:
             h_bf, w_bf, bias, target, lse, perm, count = ctx.saved_tensors
         else:
@@ -771,7 +782,7 @@ class VocabNLL(torch.autograd.Function):
             dH_c = dH
             dH = torch.empty((T, H), dtype=torch.float32, device=dev)
             _lib.call("pv_scatter_rows_f32", _p(dH_c), H, _p(perm), _p(count), T, H, _p(dH), H, _stream())
-        return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None, None)
+        return VocabNLL._finish_dh(ctx, dH, H, dev) + (dW, dbias, None, None, None, None, None, None, None, None)
 
     @staticmethod
     def _finish_dh(ctx, dH, H, dev):
