@@ -237,6 +237,20 @@ int pv_masked_sum(const float* x, const int64_t* mask, int64_t ignore, long n, f
  * backward, gscale[t] = dnll[perm ? perm[t] : t] * (target[t] != ignore): one launch each for what was a chain of
  * fill / compare / cast / gather / multiply kernels behind criterions.py:55-64. */
 int pv_masked_sum_bwd(const int64_t* mask, int64_t ignore, const float* g, long n, float* dx, void* stream);
+/* No counterpart in the reference (autograd sums the gradients of a tensor's consumers there, one launch per addend): the
+ * gradient sums at the fan-out points of the latent stack -- a pyramid activation feeds the next Block, a DLS_Auto level
+ * and the InfoNCE term (dialog_models.py:3284-3307) -- for up to PV_SUM_GROUP tensors in one launch:
+ * dst[i][0..n[i]) = src[i][0] + ... + src[i][PV_SUM_SRC-1] (NULL addends skipped; added left to right); n[i] % 4 == 0,
+ * 16-byte aligned pointers. */
+#define PV_SUM_GROUP 8
+#define PV_SUM_SRC 4
+typedef struct pv_sum_group_desc {
+  float* dst[PV_SUM_GROUP];
+  const float* src[PV_SUM_GROUP][PV_SUM_SRC];
+  long n[PV_SUM_GROUP];
+  int count;
+} pv_sum_group_desc;
+int pv_sum_group(const pv_sum_group_desc* g, void* stream);
 /* NLLEntropy(avg_type 'seq') and Perplexity of one step (criterions.py:64 loss / batch_size; :137 exp(loss / n_words)) from
  * sums2 = {sum of the token NLL, number of live tokens} (pv_masked_sum): out2 = {total / batch, exp(total / count)} in one
  * launch; backward: dsums2 = {g_nll / batch + g_ppl * ppl / count, 0} (either gradient may be NULL). */

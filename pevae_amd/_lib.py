@@ -14,6 +14,11 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 lng = C.c_long
 
 
+class SumGroup(C.Structure):
+    """struct pv_sum_group_desc of include/pevae_hip.h."""
+    _fields_ = [("dst", vp * 8), ("src", (vp * 4) * 8), ("n", lng * 8), ("count", i32)]
+
+
 class BlockCall(C.Structure):
     """struct pv_block_call of include/pevae_hip.h (one Block of a pv_block_fwd / pv_block_bwd launch)."""
     _P5 = vp * 5
@@ -90,6 +95,7 @@ SIGNATURES = {
     "pv_masked_sum_bwd": (i32, [vp, i64, vp, lng, vp, vp]),
     "pv_vocab_gscale": (i32, [vp, vp, vp, i64, i32, vp, vp]),
     "pv_masked_sum": (i32, [vp, vp, i64, lng, vp, vp]),
+    "pv_sum_group": (i32, [vp, vp]),
     "pv_nll_head_fwd": (i32, [vp, i32, vp, vp]),
     "pv_nll_head_bwd": (i32, [vp, vp, vp, vp, i32, vp, vp]),
     "pv_pick_nll_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),

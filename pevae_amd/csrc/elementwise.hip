@@ -712,6 +712,30 @@ int pv_vocab_gscale(const float* dnll, const int64_t* perm, const int64_t* targe
   return PV_OK;
 }
 
+// Gradient sums at the fan-out points of the latent stack: dst_i = sum of up to PV_SUM_SRC addends, up to PV_SUM_GROUP
+// tensors per launch (the autograd engine adds the gradients of a tensor's consumers one launch at a time otherwise).
+// Addends are added left to right (fixed order).
+static __global__ void sum_group_kernel(pv_sum_group_desc g) {
+  const int i = blockIdx.y;
+  const long n4 = g.n[i] >> 2;
+  float4* dst = (float4*)g.dst[i];
+  const float4* s0 = (const float4*)g.src[i][0];
+  const float4* s1 = (const float4*)g.src[i][1];
+  const float4* s2 = (const float4*)g.src[i][2];
+  const float4* s3 = (const float4*)g.src[i][3];
+  for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < n4; k += (long)gridDim.x * blockDim.x) {
+    float4 v = s0[k];
+    float4 w1, w2, w3;
+    if (s1) w1 = s1[k];
+    if (s2) w2 = s2[k];
+    if (s3) w3 = s3[k];
+    if (s1) { v.x += w1.x; v.y += w1.y; v.z += w1.z; v.w += w1.w; }
+    if (s2) { v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w; }
+    if (s3) { v.x += w3.x; v.y += w3.y; v.z += w3.z; v.w += w3.w; }
+    dst[k] = v;
+  }
+}
+
 // NLLEntropy(avg_type 'seq') and Perplexity of one step from the pair {sum of the token NLL, live tokens} in one launch
 // each way (criterions.py:64 loss / batch, :137 exp(loss / n_words)): out2 = {total / batch, exp(total / count)};
 // backward: d total = g_nll / batch + g_ppl * ppl / count (count carries no gradient).
@@ -789,6 +813,21 @@ int pv_nll_head_bwd(const float* sums2, const float* out2, const float* g_nll, c
   hipLaunchKernelGGL(nll_head_bwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums2, out2, g_nll, g_ppl,
                      1.0f / (float)batch, dsums2);
   PV_LAUNCH_CHECK("nll_head_bwd_kernel");
+  return PV_OK;
+}
+
+int pv_sum_group(const pv_sum_group_desc* g, void* stream) {
+  PV_REQUIRE(g && g->count > 0 && g->count <= PV_SUM_GROUP, "pv_sum_group: 1..%d tensors per launch", PV_SUM_GROUP);
+  long nmax = 0;
+  for (int i = 0; i < g->count; ++i) {
+    PV_REQUIRE(g->dst[i] && g->src[i][0] && g->n[i] > 0 && g->n[i] % 4 == 0, "pv_sum_group: tensor %d: null pointer or length %ld not a multiple of 4", i, g->n[i]);
+    PV_REQUIRE((((uintptr_t)g->dst[i] | (uintptr_t)g->src[i][0] | (uintptr_t)g->src[i][1] | (uintptr_t)g->src[i][2] | (uintptr_t)g->src[i][3]) & 15) == 0,
+               "pv_sum_group: tensor %d is not 16-byte aligned", i);
+    nmax = g->n[i] > nmax ? g->n[i] : nmax;
+  }
+  const int bx = (int)((nmax / 4 + 255) / 256);
+  hipLaunchKernelGGL(sum_group_kernel, dim3(bx < 64 ? bx : 64, g->count), dim3(256), 0, (hipStream_t)stream, *g);
+  PV_LAUNCH_CHECK("sum_group_kernel");
   return PV_OK;
 }
 

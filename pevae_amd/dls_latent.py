@@ -94,9 +94,12 @@ def pyramid_pair(pyr_a, x_a, pyr_b, x_b):
         x_b = x_b[:, 0]
     acts_a, acts_b = [], []
     for ba, bb in zip(la, lb):
-        acts_a.append(x_a)
-        acts_b.append(x_b)
-        x_a, x_b = run_blocks([ba, bb], [x_a, x_b])
+        # an activation feeds the next Block and whoever reads the act lists: one alias each, so that the two
+        # gradients of both pyramids meet in one launch of the backward pass (ops.FanOut)
+        fan = ops.Fan(2, [x_a, x_b])
+        acts_a.append(fan(x_a))
+        acts_b.append(fan(x_b))
+        x_a, x_b = run_blocks([ba, bb], [fan(x_a), fan(x_b)])
     return (x_a, acts_a), (x_b, acts_b)
 
 
@@ -175,11 +178,16 @@ class DLSAuto(nn.Module):
         scaled = (lambda v: v) if cip == 1.0 else (lambda v: v * cip)     # cip_weight = 1 (the default): no launch
         batched = not restarted and not getattr(cfg, "ost", False) and all(
             a.shape[1] % 4 == 0 for a in list(act1) + [output]) and len(self.layers) < 7
+        use = lambda t: t
         if batched:
             # every cons_loss of the train branch (:3284 and :3307 per level) reads only the pyramids' activations: one
             # batched call up front instead of one chain of ten launches per level
             nl = len(self.layers)
-            rkl = scaled(ops.cons_loss_sum([(output, rec_output)] + [(act1[-i - 1], act2[-i - 1]) for i in range(nl)]))
+            # `output` and the activations of the fused levels have 2-4 readers in here (cons_loss, the level's Blocks,
+            # two level kernels): one alias per reader, their gradients summed by one launch (ops.FanOut)
+            use = ops.Fan(4, [output] + [a[-i - 1] for i in range(nl) for a in (act1, act2)])
+            rkl = scaled(ops.cons_loss_sum([(use(output), rec_output)] +
+                                           [(use(act1[-i - 1]), use(act2[-i - 1])) for i in range(nl)]))
         else:
             rkl = scaled(ops.cons_loss(output, rec_output))
         last_sample = last_t = nxt = None
@@ -195,7 +203,7 @@ class DLSAuto(nn.Module):
             a1, a2 = act1[-i - 1], act2[-i - 1]
             train_branch = not restarted and not getattr(cfg, "ost", False)
             if last_sample is None:
-                q_in, p_in = a1 + a2, a2
+                q_in, p_in = use(a1) + use(a2), use(a2)
             elif train_branch and nxt is not None:
                 q_in, p_in = nxt                                     # formed by the previous level's DlsLevelNext launch
             elif train_branch:
@@ -205,7 +213,8 @@ class DLSAuto(nn.Module):
                 p_in = torch.cat([a2, last_sample], -1)
             need_q = train_branch or self.training
             # the three Blocks of a level are independent: they share one launch (or run as parallel stream branches)
-            res = run_blocks([dis2, layer] + ([dis] if need_q else []), [p_in, output] + ([q_in] if need_q else []))
+            res = run_blocks([dis2, layer] + ([dis] if need_q else []),
+                             [p_in, use(output) if i == 0 else output] + ([q_in] if need_q else []))
             t_mean, t_lv = res[0].chunk(2, -1)
             lay_out = res[1]
             if need_q:
@@ -219,8 +228,8 @@ class DLSAuto(nn.Module):
                     # the running loss rides through the level kernels (rkl <- rkl + klw inside the launch)
                     rkl_t = rkl if torch.is_tensor(rkl) else None
                     last_sample, output, rkl_new, q_n, p_n = ops.DlsLevelNext.apply(
-                        res[2], res[0], a2, eps, lay_out, float(ew), float(cw), act1[-i - 2] if more else None,
-                        act2[-i - 2] if more else None, rkl_t)
+                        res[2], res[0], use(a2), eps, lay_out, float(ew), float(cw), use(act1[-i - 2]) if more else None,
+                        use(act2[-i - 2]) if more else None, rkl_t)
                     rkl = rkl_new if rkl_t is not None else rkl + rkl_new
                     nxt = (q_n, p_n) if more else None
                 else:

@@ -2171,6 +2171,74 @@ class ScaledMatmulNT(torch.autograd.Function):
         return da, db, None
 
 
+FAN_OUT = os.environ.get("PEVAE_FAN_OUT", "1") != "0"
+FAN_MAX_TENSORS, FAN_MAX_USES = 8, 4          # PV_SUM_GROUP, PV_SUM_SRC of include/pevae_hip.h
+
+
+class FanOut(torch.autograd.Function):
+    """k aliases of each of up to 8 tensors, one per consumer: FanOut.apply(k, x0, x1, ...) -> (x0 alias 0..k-1, x1 alias
+    0..k-1, ...).  No forward launch; the backward sums the gradients that arrived for each tensor in ONE launch
+    (pv_sum_group) instead of autograd's one add per extra consumer.  Aliases nobody used cost nothing."""
+
+    @staticmethod
+    def forward(ctx, k, *xs):
+        assert 1 <= k <= FAN_MAX_USES and 1 <= len(xs) <= FAN_MAX_TENSORS
+        ctx.k = k
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for x in xs for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        k = ctx.k
+        outs, desc, nd = [], _lib.SumGroup(), 0
+        for i in range(len(gs) // k):
+            g = [t for t in gs[i * k:(i + 1) * k] if t is not None]
+            if len(g) < 2:
+                outs.append(g[0] if g else None)
+                continue
+            if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0
+                       and t.data_ptr() % 16 == 0 for t in g):
+                acc = g[0]
+                for t in g[1:]:
+                    acc = acc + t
+                outs.append(acc)
+                continue
+            dst = torch.empty_like(g[0])
+            desc.dst[nd] = dst.data_ptr()
+            for j in range(FAN_MAX_USES):
+                desc.src[nd][j] = g[j].data_ptr() if j < len(g) else None
+            desc.n[nd] = dst.numel()
+            nd += 1
+            outs.append(dst)
+        if nd:
+            desc.count = nd
+            _lib.call("pv_sum_group", C.byref(desc), _stream())
+        return (None,) + tuple(outs)
+
+
+class Fan(object):
+    """Hands out FanOut aliases of a set of tensors, one per use: fan = Fan(k, tensors); fan(t) -> the next alias of t
+    (t itself when it is not in the set or its aliases ran out: autograd then adds as usual)."""
+
+    def __init__(self, k, tensors):
+        live = []
+        for t in tensors:
+            if torch.is_tensor(t) and t.is_cuda and t.requires_grad and all(t is not u for u in live):
+                live.append(t)
+        live = live[:FAN_MAX_TENSORS]
+        self.left = {}
+        if FAN_OUT and live and torch.is_grad_enabled():
+            al = FanOut.apply(k, *live)
+            for i, t in enumerate(live):
+                self.left[id(t)] = (t, list(al[i * k:(i + 1) * k]))
+
+    def __call__(self, t):
+        ent = self.left.get(id(t))
+        if ent is None or ent[0] is not t or not ent[1]:
+            return t
+        return ent[1].pop(0)
+
+
 class ConsLossSum(torch.autograd.Function):
     """sum_p cons_loss(v1_p, v2_p) for up to 7 pairs in one launch per stage (pv_cons_loss_fwd / _bwd)."""
 

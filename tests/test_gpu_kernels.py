@@ -687,3 +687,29 @@ def test_nll_head_matches_the_scalar_ops(dev):
     nll2, _ = ops.NllHead.apply(sums, 256)
     nll2.backward()                            # only one of the two outputs used
     np.testing.assert_allclose(float(sums.grad[0]), 1.0 / 256, rtol=1e-6)
+
+
+def test_fan_out_sums_the_gradients_of_its_aliases(dev):
+    """ops.FanOut / pv_sum_group: aliases cost no forward launch, the backward adds what arrived per tensor left to
+    right (bit-exact against the same fp32 adds), unused aliases and single-use tensors pass through."""
+    from pevae_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    xs = [torch.randn(sh, generator=g).to(dev).requires_grad_() for sh in ((256, 512), (256, 128), (10, 64), (7, 12))]
+    ws = [[torch.randn(x.shape, generator=g).to(dev) for _ in range(4)] for x in xs]
+    al = ops.FanOut.apply(4, *xs)
+    assert all(a.data_ptr() == xs[i // 4].data_ptr() for i, a in enumerate(al))
+    uses = (4, 3, 2, 1)                                      # the last tensor has one reader: no sum
+    loss = sum((al[4 * i + j] * ws[i][j]).sum() for i in range(4) for j in range(uses[i]))
+    loss.backward()
+    for i, x in enumerate(xs):
+        want = ws[i][0].clone()
+        for j in range(1, uses[i]):
+            want = want + ws[i][j]
+        assert torch.equal(x.grad, want), i
+    # the dispenser: unknown tensors and exhausted alias lists fall back to the tensor itself
+    y = torch.randn(8, 16, device=dev, requires_grad=True)
+    fan = ops.Fan(2, [y, y, None])
+    a, b, c = fan(y), fan(y), fan(y)
+    assert a is not y and b is not y and c is y and fan(xs[0]) is xs[0]
+    (a.sum() + 2 * b.sum() + 3 * c.sum()).backward()
+    assert torch.equal(y.grad, torch.full_like(y, 6.0))
