@@ -36,8 +36,10 @@ def parse():
                     help="BASELINE.json configs: yelp = configs[1]; movie = configs[2] (8k x 8k tables, decoder attention); "
                          "book = configs[3] (200k users, 100k items); mutual = configs[4] (--use_mutual + --do_pred)")
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps cycle through")
-    ap.add_argument("--force-split", type=int, default=0, help="run the N > 1 schedule (cut backward, three graphs) at N = 1")
-    ap.add_argument("--overlap", type=int, default=1, help="N > 1: start the vocabulary gradient's all-reduce before the rest of the backward pass")
+    ap.add_argument("--force-split", type=int, default=0, help="run the N > 1 schedule at N = 1: 1 = backward cut behind the vocabulary projection (three graphs), "
+                    "2 = also in front of the utterance encoder (four graphs)")
+    ap.add_argument("--overlap", type=int, default=2, help="N > 1: 1 = start the vocabulary gradient's all-reduce before the rest "
+                    "of the backward pass; 2 = also exchange everything but the encoder's gradients before the encoder's backward")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--graph", type=int, default=1, help="replay fwd+bwd / optimizer from HIP graphs")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -110,7 +112,8 @@ def main():
     # (north star item 5).  N = 1: nothing is exchanged, so the backward pass stays whole and the vocabulary projection's
     # weight gradient leaves the critical path instead (ops.defer_after_recurrence: it runs beside the latent stack).
     split = (world > 1 and bool(args.overlap)) or bool(args.force_split)
-    model.split_backward = split
+    three = split and (args.overlap >= 2 or args.force_split >= 2) and not cfg.use_attention
+    model.split_backward = 2 if three else split
     # the flat gradient holds the SUM over ranks; 1/world is applied inside the guard / Adam kernels
     opt = FlatAdam(model.parameters(), lr=cfg.init_lr, max_norm=cfg.grad_clip, warmup_steps=cfg.warmup_steps,
                    grad_scale=1.0 / world)
@@ -143,9 +146,16 @@ def main():
     dec = model.x_decoder
     early = [opt.param_range(dec.project.weight), opt.param_range(dec.project.bias)] if args.overlap else []
     early = [(min(a for a, _ in early), max(b for _, b in early))] if early else []
+    # three-stage schedule: once the latent stack and the prior path have run backward, only the utterance encoder's and
+    # the word table's gradients are missing: everything else (and the two sparse tables) travels beside the encoder's backward
+    late = [model.x_embedding.weight] + list(model.x_encoder.parameters())
+    first = [dec.project.weight, dec.project.bias] if args.overlap else []
+    tabs = [model.user_embedding.weight, model.item_embedding.weight]
+    skip = set(id(p) for p in late + first + tabs)
+    mid = opt.spans([p for p in opt.params if id(p) not in skip]) if three else []
     reducer = dp.FlatGradReducer(opt.flat_g, world, sparse_tables=[opt.table_range(model.user_embedding.weight),
                                                                   opt.table_range(model.item_embedding.weight)],
-                                 average=False, early_ranges=early)
+                                 average=False, early_ranges=early, mid_ranges=mid)
     tables = sorted([(opt.table_range(model.user_embedding.weight)[0], "user_ids"),
                      (opt.table_range(model.item_embedding.weight)[0], "item_ids")])
     sparse_ids = [feed[k] for _, k in tables]
@@ -161,20 +171,33 @@ def main():
             model.backward(0, loss)
         return loss
 
-    def part_b():                                   # the rest of the backward pass
-        if split:
+    def part_b():                                   # the rest of the backward pass (three stages: up to the encoder)
+        if three:
+            model.backward_mid(state["loss"])
+        elif split:
             model.backward_rest(state["loss"])
+
+    def part_c():                                   # three stages: the utterance encoder's backward
+        if three:
+            model.backward_encoder(state["loss"])
 
     def fwd_bwd():
         loss = part_a()
         part_b()
+        part_c()
         return loss
+
+    def exchange_mid():
+        if three:
+            reducer.start_mid(sparse_ids)
 
     def eager_step(i=0):
         select(i)
         loss = part_a()
         reducer.start()
         part_b()
+        exchange_mid()
+        part_c()
         reducer.finish(sparse_ids)
         opt.step()
         return loss
@@ -192,12 +215,15 @@ def main():
         import gc
         state.clear()
         gc.collect()
-        ga, gb, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        ga, gb, gc_, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga, stream=side):
             static_loss = part_a()
         if split:
             with torch.cuda.graph(gb, pool=ga.pool(), stream=side):
                 part_b()
+        if three:
+            with torch.cuda.graph(gc_, pool=ga.pool(), stream=side):
+                part_c()
         with torch.cuda.graph(g2, pool=ga.pool(), stream=side):
             opt.step()
         ops.LAST_GRU_SYNC.clear()
@@ -208,6 +234,9 @@ def main():
             reducer.start()
             if split:
                 gb.replay()
+            if three:
+                exchange_mid()
+                gc_.replay()
             reducer.finish(sparse_ids)
             g2.replay()
             return static_loss
@@ -311,6 +340,7 @@ def main():
                                       ", rating head (do_pred)" if cfg.do_pred else ""),
                        "resident_batches": len(batches), "skipped_steps": skipped,
                        "dp_overlap": bool(args.overlap) and world > 1,
+                       "dp_exchange_stages": (3 if three else 2 if split else 1) if world > 1 else 0,
                        "global_batch": args.batch * world, "seq_len": cfg.max_seq_len, "params": n_params,
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph),
                        "padding_rows_skipped": bool(ops.SKIP_IGNORED_TOKENS),

@@ -105,7 +105,8 @@ class DLSVAE(nn.Module):
         self.ppl = criterions.Perplexity(self.pad_id, c)                                 # :637
         self.kl_loss = criterions.NormKLLoss(unit_average=False)
         self.backLoss = True
-        self.split_backward, self._cut = False, None
+        # split_backward: True / 1 = cut behind the vocabulary projection; 2 = also in front of the utterance encoder
+        self.split_backward, self._cut, self._cut_enc = False, None, None
 
     # -- loss contract (dialog_models.py:3451-3465) ----------------------------------------------------------
     def valid_loss(self, loss, batch_cnt=None, step=None):
@@ -142,7 +143,9 @@ class DLSVAE(nn.Module):
         vocabulary softmax / projection backward alone; it leaves dL/d(decoder states) in the cut leaf."""
         loss.vae_nll.backward()
 
-    def backward_rest(self, loss):
+    def backward_mid(self, loss):
+        """Second part: decoder recurrence, latent stack, prior path.  With the encoder cut (split_backward = 2) it stops at
+        the utterance encoder's output: every gradient but the encoder's and the word table's is final when it returns."""
         hid, leaf = self._cut
         self._cut = None
         tensors, grads = [hid], [leaf.grad]
@@ -153,6 +156,19 @@ class DLSVAE(nn.Module):
             tensors.append(loss.rating_mse)
             grads.append(None)
         self._run_backward(lambda: torch.autograd.backward(tensors, grads))
+
+    def backward_encoder(self, loss=None):
+        """Third part (split_backward = 2): the utterance encoder and the encoder-side word lookup."""
+        if self._cut_enc is None:
+            return
+        h, leaf = self._cut_enc
+        self._cut_enc = None
+        if leaf.grad is not None:
+            self._run_backward(lambda: torch.autograd.backward([h], [leaf.grad]))
+
+    def backward_rest(self, loss):
+        self.backward_mid(loss)
+        self.backward_encoder(loss)
 
     def forward(self, data_feed, mode=TEACH_FORCE, gen_type="greedy", eps=None):
         if self.training and self.config.dropout > 0:
@@ -173,6 +189,12 @@ class DLSVAE(nn.Module):
         words = ops.embedding(self.x_embedding.weight, data_feed["sentence_embeddings"], self.pad_id)
         enc_outs, enc_last = self.x_encoder(words)                                        # :765
         h = enc_last.transpose(0, 1).contiguous().squeeze(1)                              # :766
+        if (self.split_backward == 2 and torch.is_grad_enabled() and h.requires_grad
+                and mode == TEACH_FORCE and not self.config.use_attention):
+            # second cut of the data-parallel overlap schedule (the encoder states reach the decoder through h alone
+            # without attention): behind it only the encoder's and the word table's gradients are still missing
+            leaf = h.detach().requires_grad_()
+            self._cut_enc, h = (h, leaf), leaf
         prior_h = ops.tanh(ops.linear(torch.cat([user, item, rating], -1), self.prior_fc.weight, self.prior_fc.bias))
         B = h.size(0)
         if self.latent_stack == "dls":

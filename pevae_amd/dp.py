@@ -78,31 +78,37 @@ class FlatGradReducer(object):
     Overlap with backward: `early_ranges` -- [(start, end)] stretches whose gradient is final before the rest of the
     backward pass has run (the vocabulary projection: a third of the dense bytes, written by the first backward
     kernels).  start() launches their all-reduces and returns at once, so they travel over xGMI while the caller runs
-    the remaining backward; finish(ids) exchanges everything else and waits for all of it.  reduce() = start + finish."""
+    the remaining backward; finish(ids) exchanges everything else and waits for all of it.  reduce() = start + finish.
+    `mid_ranges`: a second such stage (start_mid), for stretches that are final part-way through the remaining backward."""
 
     def __init__(self, flat_grad, world_size, bucket_bytes=16 << 20, group=None, sparse_tables=(), average=True,
-                 early_ranges=()):
+                 early_ranges=(), mid_ranges=()):
         # average=False leaves the SUM in the buffer: FlatAdam(grad_scale=1/world) applies the 1/world inside its guard
         # and Adam kernels, which saves a read-modify-write pass over the whole flat gradient (124 MB at the Yelp shape)
         self.flat, self.world, self.group, self.average = flat_grad, world_size, group, average
         self.tables = sorted(tuple(t) for t in sparse_tables)
         be = max(1, bucket_bytes // 4)
-        early = sorted((int(a), int(b)) for a, b in early_ranges)
-        self.bounds, self.early_bounds, at = [], [], 0
+        stages = [sorted((int(a), int(b)) for a, b in early_ranges), sorted((int(a), int(b)) for a, b in mid_ranges)]
+        self.bounds, self.early_bounds, self.mid_bounds, at = [], [], [], 0
+        staged = [self.early_bounds, self.mid_bounds]
         for off, rows, dim in self.tables + [(flat_grad.numel(), 0, 0)]:       # dense stretches between the tables
             if off < at:
                 raise ValueError("FlatGradReducer: sparse tables overlap")
-            cuts = [at] + [x for a, b in early for x in (a, b) if at < x < off] + [off]
+            cuts = sorted(set([at, off] + [x for st in stages for a, b in st for x in (a, b) if at < x < off]))
             for lo, hi in zip(cuts[:-1], cuts[1:]):
-                is_early = any(a <= lo and hi <= b for a, b in early)
-                (self.early_bounds if is_early else self.bounds).extend((lo + s, lo + e) for s, e in bucket_bounds(hi - lo, be))
+                which = [k for k, st in enumerate(stages) if any(a <= lo and hi <= b for a, b in st)]
+                if len(which) > 1:
+                    raise ValueError("FlatGradReducer: early and mid ranges overlap")
+                dst = staged[which[0]] if which else self.bounds
+                dst.extend((lo + s, lo + e) for s, e in bucket_bounds(hi - lo, be))
             at = off + rows * dim
         if at > flat_grad.numel():
             raise ValueError("FlatGradReducer: sparse table beyond the buffer")
-        for a, b in early:
-            if sum(e - s for s, e in self.early_bounds if a <= s and e <= b) != b - a:
-                raise ValueError("FlatGradReducer: an early range must lie inside one dense stretch")
-        self._works = []
+        for st, got in zip(stages, staged):
+            for a, b in st:
+                if sum(e - s for s, e in got if a <= s and e <= b) != b - a:
+                    raise ValueError("FlatGradReducer: an early / mid range must lie inside one dense stretch")
+        self._works, self._gathered = [], None
 
     def table_view(self, i):
         off, rows, dim = self.tables[i]
@@ -111,28 +117,44 @@ class FlatGradReducer(object):
     def _all_reduce(self, bounds):
         return [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in bounds]
 
-    def start(self):
-        """Launch the all-reduces of the early ranges (their gradient must be complete on the current stream)."""
-        if self.world > 1:
-            self._works += self._all_reduce(self.early_bounds)
-
-    def finish(self, sparse_ids=()):
-        if self.world <= 1:
-            return
+    def _gather_sparse(self, sparse_ids):
         if len(sparse_ids) != len(self.tables):
-            raise ValueError("FlatGradReducer.reduce: %d sparse tables need %d id tensors" % (len(self.tables), len(sparse_ids)))
-        works, self._works = self._works + self._all_reduce(self.bounds), []
+            raise ValueError("FlatGradReducer: %d sparse tables need %d id tensors" % (len(self.tables), len(sparse_ids)))
         packed = [pack_sparse_rows(self.table_view(i), ids) for i, ids in enumerate(sparse_ids)]
         gathered = []
         for ids, rows in packed:                         # every rank looks up the same number of ids (its batch)
             ids_all = torch.empty(self.world * ids.shape[0], dtype=ids.dtype, device=ids.device)
             rows_all = torch.empty((self.world * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
-            works.append(dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=self.group, async_op=True))
-            works.append(dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=self.group, async_op=True))
-            gathered.append((ids_all, rows_all))
+            self._works.append(dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=self.group, async_op=True))
+            self._works.append(dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=self.group, async_op=True))
+            gathered.append((ids, ids_all, rows_all))
+        self._gathered = gathered
+
+    def start(self):
+        """Launch the all-reduces of the early ranges (their gradient must be complete on the current stream)."""
+        if self.world > 1:
+            self._works += self._all_reduce(self.early_bounds)
+
+    def start_mid(self, sparse_ids=None):
+        """Second stage of the overlap schedule: the mid ranges -- and, with sparse_ids, the sparse tables -- are final on
+        the current stream although the backward pass has not finished (DLS_VAE: everything but the utterance encoder and
+        the word table, once the latent stack has run backward).  Returns at once."""
+        if self.world > 1:
+            self._works += self._all_reduce(self.mid_bounds)
+            if sparse_ids is not None:
+                self._gather_sparse(sparse_ids)
+
+    def finish(self, sparse_ids=()):
+        if self.world <= 1:
+            return
+        self._works += self._all_reduce(self.bounds)
+        if self._gathered is None:
+            self._gather_sparse(sparse_ids)
+        works, self._works = self._works, []
+        gathered, self._gathered = self._gathered, None
         for w in works:
             w.wait()
-        for i, ((ids, _), (ids_all, rows_all)) in enumerate(zip(packed, gathered)):
+        for i, (ids, ids_all, rows_all) in enumerate(gathered):
             merge_sparse_rows(self.table_view(i), ids, ids_all, rows_all)
         if self.average:
             self.flat.mul_(1.0 / self.world)

@@ -81,6 +81,20 @@ class FlatAdam(object):
                 return (o, o + p.numel())
         raise KeyError("FlatAdam.param_range: not one of this optimizer's parameters")
 
+    def spans(self, params):
+        """[(start, end)] covering the given parameters inside the flat buffers, alignment padding included, neighbours
+        merged (dp.FlatGradReducer early_ranges / mid_ranges)."""
+        want = set(id(p) for p in params)
+        out = []
+        for p, o in zip(self.params, self.offsets):
+            if id(p) in want:
+                e = o + (p.numel() + 3) // 4 * 4
+                if out and out[-1][1] == o:
+                    out[-1] = (out[-1][0], e)
+                else:
+                    out.append((o, e))
+        return out
+
     def zero_grad(self):
         self.flat_g.zero_()
         for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-attach the view

@@ -126,3 +126,51 @@ def test_split_schedule_sum_matches_dense_and_replicas_identical(tmp_path):
     for flat, _ in outs:
         torch.testing.assert_close(flat, want, rtol=1e-6, atol=1e-6)
     assert torch.equal(outs[0][0], outs[1][0])
+
+
+def _three_stage_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from pevae_amd import dp
+    dp.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(400 + rank)
+    # layout: dense 100 | table 30 x 4 | dense 5000 | dense tail; early [700, 3100); mid = [0, 100) + [220, 700) + [4000, 5220)
+    off, n = 100, 100 + 120 + 5000
+    early, mid = (700, 3100), [(0, 100), (220, 700), (4000, n)]
+    grad = torch.randn(n, generator=g)
+    ids = torch.randint(0, 30, (9,), generator=g)
+    t = grad[off:off + 120].view(30, 4)
+    mask = torch.zeros(30, dtype=torch.bool)
+    mask[ids] = True
+    t[~mask] = 0.0
+    flat = torch.zeros(n)
+    red = dp.FlatGradReducer(flat, world, bucket_bytes=1 << 10, sparse_tables=[(off, 30, 4)], average=False,
+                             early_ranges=[early], mid_ranges=mid)
+    assert sum(e - s for s, e in red.mid_bounds) == sum(b - a for a, b in mid)
+    assert sum(e - s for s, e in red.bounds) == 4000 - 3100
+    # bench.py's three-stage schedule: the early stretch, then the mid stretches and the sparse table, then the rest
+    flat[early[0]:early[1]] = grad[early[0]:early[1]]
+    red.start()
+    for a, b in mid:
+        flat[a:b] = grad[a:b]
+    flat[off:off + 120] = grad[off:off + 120]
+    red.start_mid([ids])
+    flat[3100:4000] = grad[3100:4000]
+    red.finish()
+    torch.save((flat, grad), os.path.join(out, "p%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_three_stage_schedule_sum_matches_dense_and_replicas_identical(tmp_path):
+    """start() / start_mid(ids) / finish(): early, mid (with the sparse exchange) and final stretches each travel once;
+    every rank ends with the SUM over ranks, bit-identical across replicas.  Overlapping stages are rejected."""
+    port = _free_port()
+    mp.spawn(_three_stage_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "p%d.pt" % r), weights_only=True) for r in range(2)]
+    want = outs[0][1] + outs[1][1]
+    for flat, _ in outs:
+        torch.testing.assert_close(flat, want, rtol=1e-6, atol=1e-6)
+    assert torch.equal(outs[0][0], outs[1][0])
+    from pevae_amd import dp
+    with pytest.raises(ValueError):
+        dp.FlatGradReducer(torch.zeros(100), 2, early_ranges=[(0, 50)], mid_ranges=[(40, 60)])

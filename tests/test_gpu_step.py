@@ -173,6 +173,71 @@ def test_step_eval_and_second_backward_accumulates(dev):
         np.testing.assert_allclose(p.grad.cpu().numpy(), 2 * g1[n].cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=n)
 
 
+@pytest.mark.parametrize("kw", [dict(latent_stack="dls", dropout=0.3), dict(do_pred=True),
+                                dict(latent_stack="dls", use_mutual=True, do_pred=True), dict(use_attention=True)])
+def test_split_backward_schedules_give_the_unsplit_gradients(dev, kw):
+    """The data-parallel overlap schedule (bench.py, N > 1): DLSVAE.backward_vocab / backward_mid / backward_encoder with
+    the autograd graph cut behind the vocabulary projection (split_backward = 1) and also in front of the utterance
+    encoder (= 2; with attention the second cut is not made) leave bit-identical gradients to the one-pass backward, and
+    after backward_mid every gradient but the encoder's and the word table's is already final."""
+    from pevae_amd import ops
+    from pevae_amd.dls_vae import DLSVAE, default_config, synthetic_batch
+    from pevae_amd.optim import FlatAdam
+    cfg = default_config(vocab_size=517, embed_size=20, dec_cell_size=64, max_seq_len=11, n_user=40, n_item=30,
+                         latent_size=16, batch_size=24, **dict(dict(dropout=0.0), **kw))
+    torch.manual_seed(0)
+    gpu = DLSVAE(cfg).to(dev)
+    gpu.train()
+    opt = FlatAdam(gpu.parameters(), lr=1e-3, max_norm=5.0, guards=False)
+    feed = {k: v.to(dev) for k, v in synthetic_batch(cfg, 24, 99).items()}
+    gen = torch.Generator().manual_seed(3)
+    if kw.get("use_mutual"):
+        eps = ([torch.rand(24, d, generator=gen).to(dev) for d in (4, 8)],
+               [(-torch.empty(24, 24).exponential_(generator=gen).log()).to(dev) for _ in range(2)])
+    elif kw.get("latent_stack") == "dls":
+        eps = [torch.rand(24, d, generator=gen).to(dev) for d in (4, 8, 16)]
+    else:
+        eps = torch.randn(24, 16, generator=gen).to(dev)
+    if cfg.dropout > 0:                        # the same keep masks in every pass
+        for name, shape in (("input_dropout", (24, 11, 20)), ("output_dropout", (24, 11, 64))):
+            getattr(gpu.x_decoder, name).mask = (torch.rand(shape, generator=gen) >= cfg.dropout).to(dev)
+    state = {n: b.clone() for n, b in gpu.named_buffers()}        # spectral-norm u / v advance in every training forward
+
+    def run(split):
+        for n, b in gpu.named_buffers():
+            b.copy_(state[n])
+        gpu.split_backward = split
+        opt.zero_grad()
+        loss = gpu(feed, eps=eps)
+        mid = None
+        if split:
+            gpu.backward_vocab(loss)
+            gpu.backward_mid(loss)
+            mid = opt.flat_g.clone()
+            gpu.backward_encoder(loss)
+        else:
+            gpu.backward(0, loss)
+        torch.cuda.synchronize()
+        ops.gru_check_all()
+        return opt.flat_g.clone(), mid
+
+    want, _ = run(False)
+    assert float(want.abs().sum()) > 0
+    late = set(id(p) for p in [gpu.x_embedding.weight] + list(gpu.x_encoder.parameters()))
+    for split in (1, 2):
+        got, mid = run(split)
+        assert torch.equal(got, want), split
+        if split == 2 and not cfg.use_attention:
+            assert gpu._cut_enc is None
+            for p in opt.params:
+                a, b = opt.param_range(p)
+                if id(p) not in late:
+                    assert torch.equal(mid[a:b], want[a:b])
+            a, b = opt.param_range(gpu.x_encoder.rnn.layer_weights(0, 0)[1])
+            assert float(mid[a:b].abs().sum()) == 0.0                # the encoder has not run backward yet
+    gpu.split_backward = False
+
+
 def test_step_full_size_oracle_and_properties(dev):
     """BASELINE.json configs[1] at full size (bs=256, L=50, V=20004, H=512, DLS pyramid): the composed step against the
     CPU oracle (a few seconds on the host cores), plus properties that hold at any size."""
