@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps cycle through")
     ap.add_argument("--force-split", type=int, default=0, help="run the N > 1 schedule at N = 1: 1 = backward cut behind the vocabulary projection (three graphs), "
                     "2 = also in front of the utterance encoder (four graphs)")
+    ap.add_argument("--rehearse-dp", type=int, default=0, help="N = 1 only: join a ONE-rank RCCL group and run the N > 1 step "
+                    "(cut backward graphs with the gradient collectives between them) on this GPU")
     ap.add_argument("--overlap", type=int, default=2, help="N > 1: 1 = start the vocabulary gradient's all-reduce before the rest "
                     "of the backward pass; 2 = also exchange everything but the encoder's gradients before the encoder's backward")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
@@ -111,7 +113,12 @@ def main():
     # N > 1: the backward pass is cut after the vocabulary projection so that its gradient's all-reduce can start early
     # (north star item 5).  N = 1: nothing is exchanged, so the backward pass stays whole and the vocabulary projection's
     # weight gradient leaves the critical path instead (ops.defer_after_recurrence: it runs beside the latent stack).
-    split = (world > 1 and bool(args.overlap)) or bool(args.force_split)
+    rehearse = bool(args.rehearse_dp) and world == 1
+    if rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+    split = ((world > 1 or rehearse) and bool(args.overlap)) or bool(args.force_split)
     three = split and (args.overlap >= 2 or args.force_split >= 2) and not cfg.use_attention
     model.split_backward = 2 if three else split
     # the flat gradient holds the SUM over ranks; 1/world is applied inside the guard / Adam kernels
@@ -155,7 +162,7 @@ def main():
     mid = opt.spans([p for p in opt.params if id(p) not in skip]) if three else []
     reducer = dp.FlatGradReducer(opt.flat_g, world, sparse_tables=[opt.table_range(model.user_embedding.weight),
                                                                   opt.table_range(model.item_embedding.weight)],
-                                 average=False, early_ranges=early, mid_ranges=mid)
+                                 average=False, early_ranges=early, mid_ranges=mid, rehearse=rehearse)
     tables = sorted([(opt.table_range(model.user_embedding.weight)[0], "user_ids"),
                      (opt.table_range(model.item_embedding.weight)[0], "item_ids")])
     sparse_ids = [feed[k] for _, k in tables]
@@ -215,16 +222,21 @@ def main():
         import gc
         state.clear()
         gc.collect()
+        # "thread_local": RCCL's watchdog thread polls the events of the warm-up's collectives; under the default
+        # ("global") capture mode its hipEventQuery fails with "operation not permitted when stream is capturing" and
+        # takes the process down (seen with --rehearse-dp 1).  All work is drained first for the same reason.
+        torch.cuda.synchronize()
+        CAPTURE_MODE = "thread_local"
         ga, gb, gc_, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, stream=side):
+        with torch.cuda.graph(ga, stream=side, capture_error_mode=CAPTURE_MODE):
             static_loss = part_a()
         if split:
-            with torch.cuda.graph(gb, pool=ga.pool(), stream=side):
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=side, capture_error_mode=CAPTURE_MODE):
                 part_b()
         if three:
-            with torch.cuda.graph(gc_, pool=ga.pool(), stream=side):
+            with torch.cuda.graph(gc_, pool=ga.pool(), stream=side, capture_error_mode=CAPTURE_MODE):
                 part_c()
-        with torch.cuda.graph(g2, pool=ga.pool(), stream=side):
+        with torch.cuda.graph(g2, pool=ga.pool(), stream=side, capture_error_mode=CAPTURE_MODE):
             opt.step()
         ops.LAST_GRU_SYNC.clear()
 
@@ -340,7 +352,8 @@ def main():
                                       ", rating head (do_pred)" if cfg.do_pred else ""),
                        "resident_batches": len(batches), "skipped_steps": skipped,
                        "dp_overlap": bool(args.overlap) and world > 1,
-                       "dp_exchange_stages": (3 if three else 2 if split else 1) if world > 1 else 0,
+                       "dp_exchange_stages": (3 if three else 2 if split else 1) if (world > 1 or rehearse) else 0,
+                       "dp_rehearsal_one_rank": rehearse,
                        "global_batch": args.batch * world, "seq_len": cfg.max_seq_len, "params": n_params,
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph),
                        "padding_rows_skipped": bool(ops.SKIP_IGNORED_TOKENS),
@@ -348,7 +361,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kern_ms, "final_vae_nll": round(final_nll, 4),
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or rehearse:
         torch.distributed.destroy_process_group()
 
 

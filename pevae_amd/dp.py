@@ -82,10 +82,12 @@ class FlatGradReducer(object):
     `mid_ranges`: a second such stage (start_mid), for stretches that are final part-way through the remaining backward."""
 
     def __init__(self, flat_grad, world_size, bucket_bytes=16 << 20, group=None, sparse_tables=(), average=True,
-                 early_ranges=(), mid_ranges=()):
+                 early_ranges=(), mid_ranges=(), rehearse=False):
         # average=False leaves the SUM in the buffer: FlatAdam(grad_scale=1/world) applies the 1/world inside its guard
         # and Adam kernels, which saves a read-modify-write pass over the whole flat gradient (124 MB at the Yelp shape)
+        # rehearse: issue the collectives even on a one-rank group (tools/rccl_selftest.py walks the N > 1 code path on one GPU)
         self.flat, self.world, self.group, self.average = flat_grad, world_size, group, average
+        self.active = world_size > 1 or bool(rehearse)
         self.tables = sorted(tuple(t) for t in sparse_tables)
         be = max(1, bucket_bytes // 4)
         stages = [sorted((int(a), int(b)) for a, b in early_ranges), sorted((int(a), int(b)) for a, b in mid_ranges)]
@@ -108,7 +110,7 @@ class FlatGradReducer(object):
             for a, b in st:
                 if sum(e - s for s, e in got if a <= s and e <= b) != b - a:
                     raise ValueError("FlatGradReducer: an early / mid range must lie inside one dense stretch")
-        self._works, self._gathered = [], None
+        self._works, self._gathered, self._aux = [], None, None
 
     def table_view(self, i):
         off, rows, dim = self.tables[i]
@@ -132,20 +134,29 @@ class FlatGradReducer(object):
 
     def start(self):
         """Launch the all-reduces of the early ranges (their gradient must be complete on the current stream)."""
-        if self.world > 1:
+        if self.active:
             self._works += self._all_reduce(self.early_bounds)
 
     def start_mid(self, sparse_ids=None):
         """Second stage of the overlap schedule: the mid ranges -- and, with sparse_ids, the sparse tables -- are final on
         the current stream although the backward pass has not finished (DLS_VAE: everything but the utterance encoder and
         the word table, once the latent stack has run backward).  Returns at once."""
-        if self.world > 1:
+        if self.active:
             self._works += self._all_reduce(self.mid_bounds)
             if sparse_ids is not None:
-                self._gather_sparse(sparse_ids)
+                if self.flat.is_cuda:
+                    # the packing launches (a dozen small kernels) must not stand in front of the caller's next backward
+                    # graph on its stream: they run on a stream of their own, ordered after the caller's work so far
+                    if self._aux is None:
+                        self._aux = torch.cuda.Stream(device=self.flat.device)
+                    self._aux.wait_stream(torch.cuda.current_stream(self.flat.device))
+                    with torch.cuda.stream(self._aux):
+                        self._gather_sparse(sparse_ids)
+                else:
+                    self._gather_sparse(sparse_ids)
 
     def finish(self, sparse_ids=()):
-        if self.world <= 1:
+        if not self.active:
             return
         self._works += self._all_reduce(self.bounds)
         if self._gathered is None:
@@ -154,6 +165,8 @@ class FlatGradReducer(object):
         gathered, self._gathered = self._gathered, None
         for w in works:
             w.wait()
+        if self._aux is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._aux)
         for i, (ids, ids_all, rows_all) in enumerate(gathered):
             merge_sparse_rows(self.table_view(i), ids, ids_all, rows_all)
         if self.average:

@@ -163,7 +163,7 @@ class GraphedStep(object):
             static = dict(batch)
             static.update({k: v.clone() for k, v in tensors.items()})
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
                 out = self._eager(optimizer, static, mode, batch_cnt)
             if self.pool is None:
                 self.pool = graph.pool()

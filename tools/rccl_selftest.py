@@ -35,5 +35,20 @@ assert torch.equal(flat[keep], ref[keep]), "single-rank sum must leave the dense
 touched = torch.zeros(50, dtype=torch.bool, device=dev)
 touched[ids] = True
 assert torch.allclose(red.table_view(0)[touched], ref[1000:1400].view(50, 8)[touched])
+# the reducer's own three-stage walk (start / start_mid on its own stream / finish), as bench.py drives it at N > 1
+flat2 = torch.randn(3_000_000, device=dev)
+flat2[1000:1400] = 0
+ids2 = torch.randint(0, 50, (16,), device=dev)
+flat2[1000:1400].view(50, 8)[ids2] = torch.randn(16, 8, device=dev)
+ref2 = flat2.clone()
+red2 = dp.FlatGradReducer(flat2, 1, sparse_tables=[(1000, 50, 8)], average=False, early_ranges=[(1_000_000, 2_000_000)],
+                          mid_ranges=[(0, 1000), (1400, 500_000), (2_500_000, 3_000_000)], rehearse=True)
+red2.start()
+red2.start_mid([ids2])
+red2.finish()
+torch.cuda.synchronize()
+assert torch.equal(flat2[keep[:3_000_000]], ref2[keep[:3_000_000]])
+assert torch.allclose(flat2[1000:1400], ref2[1000:1400]), "one rank: the merged table equals the local one"
 dist.destroy_process_group()
-print("rccl selftest ok: %d early + %d dense buckets, sparse (ids, rows) gather, broadcast" % (len(red.early_bounds), len(red.bounds)))
+print("rccl selftest ok: %d early + %d dense buckets, sparse (ids, rows) gather, broadcast; three-stage walk %d / %d / %d buckets"
+      % (len(red.early_bounds), len(red.bounds), len(red2.early_bounds), len(red2.mid_bounds), len(red2.bounds)))
