@@ -240,17 +240,35 @@ def main():
             opt.step()
         ops.LAST_GRU_SYNC.clear()
 
+        ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
+        import collections
+        cpu_t = collections.defaultdict(float)
+
         def step(i=0):
-            select(i)
+            # every backward graph is queued first; the collectives are then issued on the reducer's own stream, each
+            # ordered after the graph that completes its gradients (an event), so the host's launches for the exchange
+            # never stand between two graphs
+            T = cpu_t
+            t0 = time.perf_counter(); select(i); t1 = time.perf_counter(); T["select"] += t1 - t0
             ga.replay()
-            reducer.start()
+            ev_a.record(); t2 = time.perf_counter(); T["ga"] += t2 - t1
             if split:
                 gb.replay()
+                ev_b.record()
+            t3 = time.perf_counter(); T["gb"] += t3 - t2
             if three:
-                exchange_mid()
                 gc_.replay()
+            t4 = time.perf_counter(); T["gc"] += t4 - t3
+            if split:
+                reducer.start(after=ev_a)
+            t5 = time.perf_counter(); T["start"] += t5 - t4
+            if three:
+                reducer.start_mid(sparse_ids, after=ev_b)
+            t6 = time.perf_counter(); T["start_mid"] += t6 - t5
             reducer.finish(sparse_ids)
+            t7 = time.perf_counter(); T["finish"] += t7 - t6
             g2.replay()
+            T["g2"] += time.perf_counter() - t7; T["n"] += 1
             return static_loss
     for i in range(args.warmup):
         step(i)
@@ -288,6 +306,8 @@ def main():
     if rank == 0 and os.environ.get("PEVAE_BENCH_DEBUG"):
         print("debug: guard state", opt.state_dict_host(), "nll", float(loss.vae_nll.detach()), file=sys.stderr)
     ms = elapsed / args.steps * 1e3
+    if args.graph and os.environ.get("PEVAE_BENCH_CPUTIME"):
+        print("host us per call:", {k: round(v / cpu_t["n"] * 1e6, 1) for k, v in cpu_t.items() if k != "n"}, file=sys.stderr)
     value = args.batch * world * args.steps / elapsed
     final_nll = float(loss.vae_nll.detach())
     skipped = opt.state_dict_host()["skipped_total"]

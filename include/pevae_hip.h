@@ -223,6 +223,16 @@ size_t pv_embedding_bwd_ws_bytes(int n, int D);
 int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n, int n1, int n1p, long s0, long s1,
                      long num_rows, int D, long padding_idx, int accumulate, float* dtable, void* workspace,
                      size_t ws_bytes, void* stream);
+/* No counterpart in the reference (it is single-process): the data-parallel exchange of a table whose local gradient is
+ * non-zero only in the n rows looked up this step (user / item tables, dialog_models.py:758-759), as (ids, rows) instead
+ * of an all-reduce of the whole table.  pv_sparse_pack: occurrence r sends its id (as fp32, exact: num_rows <= 2^24) and
+ * the gradient row of its id if it is the first occurrence of that id, zeros otherwise.  pv_sparse_merge: `gathered`
+ * holds every rank's [ids n][rows n x D] block at rank_stride floats from each other (one all-gather); each id's rows are
+ * summed in (rank, occurrence) order -- identical bits on every rank -- and overwrite that row of table_grad. */
+int pv_sparse_pack(const float* table_grad, long num_rows, int D, const int64_t* ids, int n, float* out_ids,
+                   float* out_rows, void* stream);
+int pv_sparse_merge(const float* gathered, int world, long rank_stride, int n, int D, long num_rows, float* table_grad,
+                    void* stream);
 
 /* ---- layout helpers ------------------------------------------------------------------------------------------ */
 /* dst[(i0*n1p + i1)*ldd + c] = bf16(src[i0*s0 + i1*s1 + c*sc]) for c < C, 0 for C <= c < ldd */

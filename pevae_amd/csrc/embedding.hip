@@ -126,6 +126,44 @@ __global__ __launch_bounds__(64) void segment_combine_kernel(const int* __restri
   dst[c] = s;
 }
 
+// Data-parallel exchange of a table whose local gradient is non-zero only in the n rows looked up this step.
+// pack: occurrence r sends its id (as a float: exact below 2^24) and the table's gradient row if r is the FIRST occurrence
+// of that id, zeros otherwise, so that a receiver may add every occurrence.  One workgroup per occurrence.
+__global__ __launch_bounds__(256) void sparse_pack_kernel(const float* __restrict__ grad, long num_rows, int D,
+                                                           const int64_t* __restrict__ ids, int n, float* __restrict__ out_ids,
+                                                           float* __restrict__ out_rows) {
+  const int r = blockIdx.x;
+  const int64_t id = ids[r];
+  int dup = id < 0 || id >= num_rows;                        // an id outside the table sends zeros (and is dropped by the merge)
+  for (int j = threadIdx.x; j < r; j += 256) dup |= ids[j] == id;
+  dup = __syncthreads_or(dup);
+  if (threadIdx.x == 0) out_ids[r] = (float)id;
+  const float* src = grad + (size_t)(dup ? 0 : id) * D;
+  for (int c = threadIdx.x; c < D; c += 256) out_rows[(size_t)r * D + c] = dup ? 0.f : src[c];
+}
+
+// merge: `gathered` holds every rank's block [ids n][rows n x D] at rank_stride floats from each other.  Entry e = (rank,
+// occurrence); the workgroup of the first entry of an id sums that id's rows over all entries in entry order -- the same
+// order on every rank, no atomics -- and OVERWRITES the table's gradient row (every locally touched row is among them).
+__global__ __launch_bounds__(256) void sparse_merge_kernel(const float* __restrict__ gathered, int world, long rank_stride,
+                                                            int n, int D, long num_rows, float* __restrict__ table) {
+  extern __shared__ float ids_s[];                           // world * n ids
+  const int E = world * n, e = blockIdx.x;
+  for (int j = threadIdx.x; j < E; j += 256) ids_s[j] = gathered[(long)(j / n) * rank_stride + j % n];
+  __syncthreads();
+  const float idf = ids_s[e];
+  for (int j = 0; j < e; ++j)
+    if (ids_s[j] == idf) return;                             // not the first entry of this id (workgroup-uniform)
+  const long id = (long)idf;
+  if (id < 0 || id >= num_rows) return;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float acc = 0.f;
+    for (int j = e; j < E; ++j)
+      if (ids_s[j] == idf) acc += gathered[(long)(j / n) * rank_stride + n + (long)(j % n) * D + c];
+    table[id * D + c] = acc;
+  }
+}
+
 size_t sort_temp_bytes(int n) {
   size_t bytes = 0;
   hipcub::DeviceRadixSort::SortPairs((void*)nullptr, bytes, (const int*)nullptr, (int*)nullptr,
@@ -187,6 +225,27 @@ int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n,
                        padding_idx, part, dtable);
     PV_LAUNCH_CHECK("segment_combine_kernel");
   }
+  return PV_OK;
+}
+
+int pv_sparse_pack(const float* table_grad, long num_rows, int D, const int64_t* ids, int n, float* out_ids,
+                   float* out_rows, void* stream) {
+  PV_REQUIRE(table_grad && ids && out_ids && out_rows && n > 0 && D > 0, "pv_sparse_pack: bad argument");
+  PV_REQUIRE(num_rows > 0 && num_rows <= (1l << 24), "pv_sparse_pack: row ids travel as fp32: at most 2^24 table rows");
+  hipLaunchKernelGGL(sparse_pack_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table_grad, num_rows, D, ids, n, out_ids, out_rows);
+  PV_LAUNCH_CHECK("sparse_pack_kernel");
+  return PV_OK;
+}
+
+int pv_sparse_merge(const float* gathered, int world, long rank_stride, int n, int D, long num_rows, float* table_grad,
+                    void* stream) {
+  PV_REQUIRE(gathered && table_grad && world > 0 && n > 0 && D > 0 && rank_stride >= (long)n * (D + 1),
+             "pv_sparse_merge: bad argument");
+  const size_t lds = (size_t)world * n * sizeof(float);
+  PV_REQUIRE(lds <= 64 * 1024, "pv_sparse_merge: %d x %d ids exceed the 16384 the kernel stages", world, n);
+  hipLaunchKernelGGL(sparse_merge_kernel, dim3(world * n), dim3(256), lds, (hipStream_t)stream, gathered, world, rank_stride, n,
+                     D, num_rows, table_grad);
+  PV_LAUNCH_CHECK("sparse_merge_kernel");
   return PV_OK;
 }
 

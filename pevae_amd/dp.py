@@ -81,7 +81,7 @@ class FlatGradReducer(object):
     the remaining backward; finish(ids) exchanges everything else and waits for all of it.  reduce() = start + finish.
     `mid_ranges`: a second such stage (start_mid), for stretches that are final part-way through the remaining backward."""
 
-    def __init__(self, flat_grad, world_size, bucket_bytes=16 << 20, group=None, sparse_tables=(), average=True,
+    def __init__(self, flat_grad, world_size, bucket_bytes=64 << 20, group=None, sparse_tables=(), average=True,
                  early_ranges=(), mid_ranges=(), rehearse=False):
         # average=False leaves the SUM in the buffer: FlatAdam(grad_scale=1/world) applies the 1/world inside its guard
         # and Adam kernels, which saves a read-modify-write pass over the whole flat gradient (124 MB at the Yelp shape)
@@ -110,7 +110,7 @@ class FlatGradReducer(object):
             for a, b in st:
                 if sum(e - s for s, e in got if a <= s and e <= b) != b - a:
                     raise ValueError("FlatGradReducer: an early / mid range must lie inside one dense stretch")
-        self._works, self._gathered, self._aux = [], None, None
+        self._works, self._gathered, self._aux, self._sparse_buf = [], None, None, None
 
     def table_view(self, i):
         off, rows, dim = self.tables[i]
@@ -119,9 +119,42 @@ class FlatGradReducer(object):
     def _all_reduce(self, bounds):
         return [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in bounds]
 
+    def _gather_sparse_device(self, sparse_ids):
+        """On the device: one pack launch per table into ONE send buffer ([ids as fp32 | rows] per table), one all-gather,
+        and (finish) one merge launch per table -- pv_sparse_pack / pv_sparse_merge.  The buffers are allocated once: the
+        host side of an exchange is then a handful of calls, which matters because the host also has to launch the step's
+        graphs (~10 us per kernel node on this runtime)."""
+        from . import _lib, ops
+        lay, at = [], 0
+        for (off, rows, dim), ids in zip(self.tables, sparse_ids):
+            n = ids.numel()
+            lay.append((at, n, dim, rows))
+            at += n * (dim + 1)
+        if self._sparse_buf is None or self._sparse_buf[0] != lay:
+            dev = self.flat.device
+            self._sparse_buf = (lay, torch.empty(at, dtype=torch.float32, device=dev),
+                                torch.empty(self.world * at, dtype=torch.float32, device=dev))
+        _, send, recv = self._sparse_buf
+        for i, ((o, n, dim, rows), ids) in enumerate(zip(lay, sparse_ids)):
+            ids_c = ids.reshape(-1).contiguous()
+            _lib.call("pv_sparse_pack", ops._p(self.table_view(i)), rows, dim, ops._p(ids_c), n, ops._p(send[o:o + n]),
+                      ops._p(send[o + n:o + n * (dim + 1)]), ops._stream())
+        self._works.append(dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True))
+        self._gathered = "device"
+
+    def _merge_sparse_device(self):
+        from . import _lib, ops
+        lay, send, recv = self._sparse_buf
+        for i, (o, n, dim, rows) in enumerate(lay):
+            _lib.call("pv_sparse_merge", ops._p(recv[o:]), self.world, send.numel(), n, dim, rows, ops._p(self.table_view(i)),
+                      ops._stream())
+
     def _gather_sparse(self, sparse_ids):
         if len(sparse_ids) != len(self.tables):
             raise ValueError("FlatGradReducer: %d sparse tables need %d id tensors" % (len(self.tables), len(sparse_ids)))
+        if self.flat.is_cuda and all(rows <= (1 << 24) for _, rows, _ in self.tables) and self.tables \
+                and self.world * max(ids.numel() for ids in sparse_ids) <= 16384:
+            return self._gather_sparse_device(sparse_ids)
         packed = [pack_sparse_rows(self.table_view(i), ids) for i, ids in enumerate(sparse_ids)]
         gathered = []
         for ids, rows in packed:                         # every rank looks up the same number of ids (its batch)
@@ -132,27 +165,43 @@ class FlatGradReducer(object):
             gathered.append((ids, ids_all, rows_all))
         self._gathered = gathered
 
-    def start(self):
-        """Launch the all-reduces of the early ranges (their gradient must be complete on the current stream)."""
-        if self.active:
-            self._works += self._all_reduce(self.early_bounds)
+    def _aux_stream(self, after):
+        """The reducer's own stream, ordered after `after` (an event; the caller's current stream when None).  Collectives
+        issued under it are ordered after that point only -- RCCL's stream follows the stream that is current at the call
+        -- so the caller may already have queued later work (its next backward graph) on its own stream: the host then
+        never stands between two graphs with a dozen launches of its own."""
+        if self._aux is None:
+            self._aux = torch.cuda.Stream(device=self.flat.device)
+        if after is None:
+            self._aux.wait_stream(torch.cuda.current_stream(self.flat.device))
+        else:
+            self._aux.wait_event(after)
+        return torch.cuda.stream(self._aux)
 
-    def start_mid(self, sparse_ids=None):
-        """Second stage of the overlap schedule: the mid ranges -- and, with sparse_ids, the sparse tables -- are final on
-        the current stream although the backward pass has not finished (DLS_VAE: everything but the utterance encoder and
-        the word table, once the latent stack has run backward).  Returns at once."""
+    def start(self, after=None):
+        """Launch the all-reduces of the early ranges.  Their gradient must be complete at `after` (an event recorded on
+        the caller's stream), or on the current stream when no event is given."""
         if self.active:
-            self._works += self._all_reduce(self.mid_bounds)
-            if sparse_ids is not None:
-                if self.flat.is_cuda:
-                    # the packing launches (a dozen small kernels) must not stand in front of the caller's next backward
-                    # graph on its stream: they run on a stream of their own, ordered after the caller's work so far
-                    if self._aux is None:
-                        self._aux = torch.cuda.Stream(device=self.flat.device)
-                    self._aux.wait_stream(torch.cuda.current_stream(self.flat.device))
-                    with torch.cuda.stream(self._aux):
+            if self.flat.is_cuda and after is not None:
+                with self._aux_stream(after):
+                    self._works += self._all_reduce(self.early_bounds)
+            else:
+                self._works += self._all_reduce(self.early_bounds)
+
+    def start_mid(self, sparse_ids=None, after=None):
+        """Second stage of the overlap schedule: the mid ranges -- and, with sparse_ids, the sparse tables -- are final at
+        `after` / on the current stream although the backward pass has not finished (DLS_VAE: everything but the
+        utterance encoder and the word table, once the latent stack has run backward).  Returns at once."""
+        if self.active:
+            if self.flat.is_cuda:
+                # also keeps the packing launches (a dozen small kernels) off the caller's stream
+                with self._aux_stream(after):
+                    self._works += self._all_reduce(self.mid_bounds)
+                    if sparse_ids is not None:
                         self._gather_sparse(sparse_ids)
-                else:
+            else:
+                self._works += self._all_reduce(self.mid_bounds)
+                if sparse_ids is not None:
                     self._gather_sparse(sparse_ids)
 
     def finish(self, sparse_ids=()):
@@ -167,8 +216,11 @@ class FlatGradReducer(object):
             w.wait()
         if self._aux is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self._aux)
-        for i, (ids, ids_all, rows_all) in enumerate(gathered):
-            merge_sparse_rows(self.table_view(i), ids, ids_all, rows_all)
+        if gathered == "device":
+            self._merge_sparse_device()
+        else:
+            for i, (ids, ids_all, rows_all) in enumerate(gathered):
+                merge_sparse_rows(self.table_view(i), ids, ids_all, rows_all)
         if self.average:
             self.flat.mul_(1.0 / self.world)
 

@@ -638,6 +638,44 @@ def test_dp_sparse_pack_merge_on_device(dev):
     assert torch.equal(first, mine)                        # both "ranks" end with the same bits
 
 
+def test_dp_sparse_pack_merge_kernels(dev):
+    """pv_sparse_pack / pv_sparse_merge (the exchange's device path: one pack launch, one all-gather, one merge launch per
+    table): three simulated ranks' blocks laid out as the all-gather leaves them; every rank's merged table equals the
+    sum of the three tables (sequential fp32 adds in rank order: bit-exact against the same adds in torch) and the pack
+    equals dp.pack_sparse_rows."""
+    from pevae_amd import _lib, dp, ops
+    g = torch.Generator().manual_seed(22)
+    rows, D, n, W = 500, 256, 64, 3
+    tables, ids = [], []
+    for r in range(W):
+        idv = torch.randint(0, rows, (n,), generator=g)
+        idv[5] = idv[9] = idv[0]
+        idv[20] = 7                                            # id 7 on every rank
+        t = torch.zeros(rows, D)
+        t[idv.unique()] = torch.randn(idv.unique().numel(), D, generator=g)
+        tables.append(t.to(dev))
+        ids.append(idv.to(dev))
+    S = n * (D + 1) + 40                                       # a second table's block would follow: stride > block
+    recv = torch.zeros(W * S, device=dev)
+    for r in range(W):
+        blk = recv[r * S:(r + 1) * S]
+        _lib.call("pv_sparse_pack", ops._p(tables[r]), rows, D, ops._p(ids[r]), n, ops._p(blk[:n]), ops._p(blk[n:n + n * D]),
+                  ops._stream())
+        pid, prow = dp.pack_sparse_rows(tables[r], ids[r])
+        assert torch.equal(blk[:n], pid.float()) and torch.equal(blk[n:n + n * D].view(n, D), prow)
+    want = tables[0].clone()
+    for r in range(1, W):
+        want = want + tables[r]
+    outs = []
+    for r in range(W):
+        mine = tables[r].clone()
+        _lib.call("pv_sparse_merge", ops._p(recv), W, S, n, D, rows, ops._p(mine), ops._stream())
+        assert torch.equal(mine, want), r
+        outs.append(mine)
+    with pytest.raises(RuntimeError):
+        _lib.call("pv_sparse_pack", ops._p(tables[0]), (1 << 24) + 1, D, ops._p(ids[0]), n, ops._p(recv), ops._p(recv), ops._stream())
+
+
 @pytest.mark.parametrize("R,C,lds", [(200, 96, 96), (130, 512, 520), (77, 100, 100), (64, 36, 40), (300, 30, 30)])
 def test_transpose_to_bf16_both_paths(dev, R, C, lds):
     """pv_transpose_to_bf16 from fp32 and from bf16 sources: shapes that take the 16-byte path and shapes that fall back
