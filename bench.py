@@ -122,8 +122,17 @@ def main():
     three = split and (args.overlap >= 2 or args.force_split >= 2) and not cfg.use_attention
     model.split_backward = 2 if three else split
     # the flat gradient holds the SUM over ranks; 1/world is applied inside the guard / Adam kernels
-    opt = FlatAdam(model.parameters(), lr=cfg.init_lr, max_norm=cfg.grad_clip, warmup_steps=cfg.warmup_steps,
+    # Order of the flat buffers = order in which gradients become final in the backward pass, so that every stage of the
+    # exchange is ONE contiguous stretch (one collective): vocabulary projection | decoder recurrence, latent stack, prior
+    # path | utterance encoder and word table | the two tables exchanged as (ids, rows)
+    g_first = [model.x_decoder.project.weight, model.x_decoder.project.bias]
+    g_late = [model.x_embedding.weight] + list(model.x_encoder.parameters())
+    g_tabs = [model.user_embedding.weight, model.item_embedding.weight]
+    known = set(id(p) for p in g_first + g_late + g_tabs)
+    g_mid = [p for p in model.parameters() if id(p) not in known]
+    opt = FlatAdam(g_first + g_mid + g_late + g_tabs, lr=cfg.init_lr, max_norm=cfg.grad_clip, warmup_steps=cfg.warmup_steps,
                    grad_scale=1.0 / world)
+    assert len(opt.params) == sum(1 for p in model.parameters() if p.requires_grad)
     dp.broadcast_parameters(opt.flat_p)
     # NB resident batches; the step reads `feed`, whose tensors are views into two static buffers (int64 / fp32)
     batches = [synthetic_batch(cfg, args.batch, 1234 + rank + 1000 * i, dev) for i in range(max(1, args.batches))]
@@ -151,15 +160,10 @@ def main():
     # user / item tables: only the looked-up rows carry gradient, so they are exchanged as (ids, rows), not all-reduced;
     # the vocabulary projection's gradient is final after the first backward kernels: its all-reduce starts early
     dec = model.x_decoder
-    early = [opt.param_range(dec.project.weight), opt.param_range(dec.project.bias)] if args.overlap else []
-    early = [(min(a for a, _ in early), max(b for _, b in early))] if early else []
+    early = opt.spans(g_first) if args.overlap else []
     # three-stage schedule: once the latent stack and the prior path have run backward, only the utterance encoder's and
     # the word table's gradients are missing: everything else (and the two sparse tables) travels beside the encoder's backward
-    late = [model.x_embedding.weight] + list(model.x_encoder.parameters())
-    first = [dec.project.weight, dec.project.bias] if args.overlap else []
-    tabs = [model.user_embedding.weight, model.item_embedding.weight]
-    skip = set(id(p) for p in late + first + tabs)
-    mid = opt.spans([p for p in opt.params if id(p) not in skip]) if three else []
+    mid = opt.spans(g_mid) if three else []
     reducer = dp.FlatGradReducer(opt.flat_g, world, sparse_tables=[opt.table_range(model.user_embedding.weight),
                                                                   opt.table_range(model.item_embedding.weight)],
                                  average=False, early_ranges=early, mid_ranges=mid, rehearse=rehearse)
@@ -240,31 +244,28 @@ def main():
             opt.step()
         ops.LAST_GRU_SYNC.clear()
 
-        ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
         import collections
         cpu_t = collections.defaultdict(float)
 
         def step(i=0):
-            # every backward graph is queued first; the collectives are then issued on the reducer's own stream, each
-            # ordered after the graph that completes its gradients (an event), so the host's launches for the exchange
-            # never stand between two graphs
+            # This runtime's launch of a multi-queue graph keeps the host inside replay() until most of the graph has run
+            # (tools/graph_launch_cost.py), so a collective can only be issued once the graph before it is nearly done: the
+            # exchange calls sit BETWEEN the graphs and are kept to one collective per stage (flat buffers ordered by stage)
             T = cpu_t
             t0 = time.perf_counter(); select(i); t1 = time.perf_counter(); T["select"] += t1 - t0
-            ga.replay()
-            ev_a.record(); t2 = time.perf_counter(); T["ga"] += t2 - t1
+            ga.replay(); t2 = time.perf_counter(); T["ga"] += t2 - t1
+            if split:
+                reducer.start()
+            t3 = time.perf_counter(); T["start"] += t3 - t2
             if split:
                 gb.replay()
-                ev_b.record()
-            t3 = time.perf_counter(); T["gb"] += t3 - t2
+            t4 = time.perf_counter(); T["gb"] += t4 - t3
+            if three:
+                reducer.start_mid(sparse_ids)
+            t5 = time.perf_counter(); T["start_mid"] += t5 - t4
             if three:
                 gc_.replay()
-            t4 = time.perf_counter(); T["gc"] += t4 - t3
-            if split:
-                reducer.start(after=ev_a)
-            t5 = time.perf_counter(); T["start"] += t5 - t4
-            if three:
-                reducer.start_mid(sparse_ids, after=ev_b)
-            t6 = time.perf_counter(); T["start_mid"] += t6 - t5
+            t6 = time.perf_counter(); T["gc"] += t6 - t5
             reducer.finish(sparse_ids)
             t7 = time.perf_counter(); T["finish"] += t7 - t6
             g2.replay()

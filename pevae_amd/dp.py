@@ -6,8 +6,9 @@ Each rank runs the full model on its own 256 samples; the only exchange is the g
 gradient buffer of FlatAdam.  The 'seq'-averaged NLL divides by the LOCAL batch (criterions.py:64), so summed
 gradients are divided by the world size; the clip norm / skip guards are then computed on the reduced gradient,
 which is identical on every rank, so all ranks take the same decision without a further exchange.
-xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): buckets are sized (default 16 MiB) so several are in
-flight across the links while keeping launch overhead negligible.
+xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU).  The process group runs its collectives one after another
+on one stream, so splitting a stretch buys no concurrency and every call costs ~40 us of host time that the step cannot
+hide: a stage travels as ONE all-reduce when its parameters are contiguous (64 MiB bucket limit).
 """
 import os
 
