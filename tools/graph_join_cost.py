@@ -1,16 +1,19 @@
 """What does one fork + join cost inside a replayed HIP graph?  Main chain: 60 sleep kernels (~8 us each).  At K points a
 side branch with ONE tiny kernel is forked and joined again two main kernels later (the side work is long finished by
 then), so any added time is the cross-queue hand-off itself."""
+import sys
 import time
 import torch
 
 dev = torch.device("cuda:0")
 s, side = torch.cuda.Stream(), torch.cuda.Stream()
 x = torch.zeros(1024, device=dev)
-CYC, N = 20_000, 60
+CYC, N = 20_000, int(sys.argv[2]) if len(sys.argv) > 2 else 60
+
+JOIN = len(sys.argv) < 2 or sys.argv[1] != "forks-only"      # forks-only: the side branches are joined once, at the end
 with torch.cuda.stream(s):
     base = None
-    for K in (0, 1, 5, 10, 20, 27):
+    for K in ((0, 1, 5, 10, 20, 27) if N == 60 else (0, N // 8, N // 4, N // 2 - 4)):
         g = torch.cuda.CUDAGraph()
         x.add_(1)
         torch.cuda.synchronize()
@@ -24,7 +27,8 @@ with torch.cuda.stream(s):
                     side.wait_stream(cur)
                     with torch.cuda.stream(side):
                         x.add_(1)
-                    pend[i + 2] = True
+                    if JOIN:
+                        pend[i + 2] = True
                 if i in pend:
                     cur.wait_stream(side)
             cur.wait_stream(side)
