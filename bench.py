@@ -182,11 +182,22 @@ def main():
             model.backward(0, loss)
         return loss
 
+    # three stages on the device: the pack launches of the sparse exchange close the mid graph and the merge launches open
+    # the optimizer graph, so the host's part of the exchange between the graphs is the collectives alone
+    reducer.external_sparse = bool(three and (world > 1 or rehearse) and reducer.device_sparse(sparse_ids))
+
     def part_b():                                   # the rest of the backward pass (three stages: up to the encoder)
         if three:
             model.backward_mid(state["loss"])
+            if reducer.external_sparse:
+                reducer.pack_sparse(sparse_ids)
         elif split:
             model.backward_rest(state["loss"])
+
+    def optimizer_step():
+        if reducer.external_sparse:
+            reducer.merge_sparse()
+        opt.step()
 
     def part_c():                                   # three stages: the utterance encoder's backward
         if three:
@@ -210,7 +221,7 @@ def main():
         exchange_mid()
         part_c()
         reducer.finish(sparse_ids)
-        opt.step()
+        optimizer_step()
         return loss
 
     # warm-up (eager, on a side stream as torch's graph-capture rules ask): allocates every workspace
@@ -241,7 +252,7 @@ def main():
             with torch.cuda.graph(gc_, pool=ga.pool(), stream=side, capture_error_mode=CAPTURE_MODE):
                 part_c()
         with torch.cuda.graph(g2, pool=ga.pool(), stream=side, capture_error_mode=CAPTURE_MODE):
-            opt.step()
+            optimizer_step()
         ops.LAST_GRU_SYNC.clear()
 
         import collections

@@ -112,6 +112,7 @@ class FlatGradReducer(object):
                 if sum(e - s for s, e in got if a <= s and e <= b) != b - a:
                     raise ValueError("FlatGradReducer: an early / mid range must lie inside one dense stretch")
         self._works, self._gathered, self._aux, self._sparse_buf = [], None, None, None
+        self.external_sparse = False          # the caller runs pack_sparse() / merge_sparse() itself (inside its graphs)
 
     def table_view(self, i):
         off, rows, dim = self.tables[i]
@@ -120,11 +121,17 @@ class FlatGradReducer(object):
     def _all_reduce(self, bounds):
         return [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in bounds]
 
-    def _gather_sparse_device(self, sparse_ids):
-        """On the device: one pack launch per table into ONE send buffer ([ids as fp32 | rows] per table), one all-gather,
-        and (finish) one merge launch per table -- pv_sparse_pack / pv_sparse_merge.  The buffers are allocated once: the
-        host side of an exchange is then a handful of calls, which matters because the host also has to launch the step's
-        graphs (~10 us per kernel node on this runtime)."""
+    def device_sparse(self, sparse_ids):
+        """True when the sparse tables travel through pv_sparse_pack / pv_sparse_merge (device tensors, ids exact in fp32)."""
+        return bool(self.flat.is_cuda and self.tables and all(rows <= (1 << 24) for _, rows, _ in self.tables)
+                    and self.world * max(ids.numel() for ids in sparse_ids) <= 16384)
+
+    def pack_sparse(self, sparse_ids):
+        """The pack launches alone (device path), on the current stream -- for a caller that sets `external_sparse` and
+        makes them (and merge_sparse) part of its own captured graphs: the table gradients must be final, and
+        start_mid / finish then only issue the all-gather.  The buffers are allocated on the first call."""
+        if not self.active:
+            return
         from . import _lib, ops
         lay, at = [], 0
         for (off, rows, dim), ids in zip(self.tables, sparse_ids):
@@ -140,8 +147,21 @@ class FlatGradReducer(object):
             ids_c = ids.reshape(-1).contiguous()
             _lib.call("pv_sparse_pack", ops._p(self.table_view(i)), rows, dim, ops._p(ids_c), n, ops._p(send[o:o + n]),
                       ops._p(send[o + n:o + n * (dim + 1)]), ops._stream())
+
+    def _gather_sparse_device(self, sparse_ids):
+        """On the device: one pack launch per table into ONE send buffer ([ids as fp32 | rows] per table), one all-gather,
+        and (finish) one merge launch per table -- pv_sparse_pack / pv_sparse_merge.  The buffers are allocated once: the
+        host side of an exchange is a handful of calls, all of which the step cannot hide."""
+        if not self.external_sparse:
+            self.pack_sparse(sparse_ids)
+        _, send, recv = self._sparse_buf
         self._works.append(dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True))
         self._gathered = "device"
+
+    def merge_sparse(self):
+        """The merge launches alone (see pack_sparse): after finish() on the same stream."""
+        if self.active:
+            self._merge_sparse_device()
 
     def _merge_sparse_device(self):
         from . import _lib, ops
@@ -153,8 +173,7 @@ class FlatGradReducer(object):
     def _gather_sparse(self, sparse_ids):
         if len(sparse_ids) != len(self.tables):
             raise ValueError("FlatGradReducer: %d sparse tables need %d id tensors" % (len(self.tables), len(sparse_ids)))
-        if self.flat.is_cuda and all(rows <= (1 << 24) for _, rows, _ in self.tables) and self.tables \
-                and self.world * max(ids.numel() for ids in sparse_ids) <= 16384:
+        if self.device_sparse(sparse_ids):
             return self._gather_sparse_device(sparse_ids)
         packed = [pack_sparse_rows(self.table_view(i), ids) for i, ids in enumerate(sparse_ids)]
         gathered = []
@@ -218,7 +237,8 @@ class FlatGradReducer(object):
         if self._aux is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self._aux)
         if gathered == "device":
-            self._merge_sparse_device()
+            if not self.external_sparse:
+                self._merge_sparse_device()
         else:
             for i, (ids, ids_all, rows_all) in enumerate(gathered):
                 merge_sparse_rows(self.table_view(i), ids, ids_all, rows_all)
