@@ -121,6 +121,12 @@ int pv_vocab_gather32(const void* h, int ldh, const int64_t* target, const int64
  * cols % 4 == 0 */
 int pv_scatter_rows_scaled_f32(const float* src, const float* scale, float factor, const int64_t* perm, const int* count, int T,
                                int cols, float* dst, long ldd, void* stream);
+/* The same with the backward of the decoder's output dropout (decoders.py:189) folded into the store: destination row
+ * r = i0 * n1p + i1 holds the logical elements i0 * m0 + i1 * m1 + c (pv_dropout_f32's convention); keep decisions from
+ * `mask` or regenerated from (rng_state, site).  One pass over dH instead of two. */
+int pv_scatter_rows_scaled_drop_f32(const float* src, const float* scale, float factor, const int64_t* perm, const int* count,
+                                    int T, int cols, float* dst, long ldd, int n1, int n1p, long m0, long m1, float p,
+                                    const void* mask, const void* rng_state, int site, void* stream);
 /* Dense [T][V] fp32 log-probs for callers that need the reference's DecoderRNN return value as a tensor
  * (decoders.py:193,292); needs lse from pv_vocab_nll_fwd. */
 int pv_vocab_logprob_dense(const void* h, int ldh, const void* W, int ldw, const float* bias, const float* lse,

@@ -9,18 +9,10 @@
 //                         vocabulary projection's A operand in one pass instead of contiguous + dropout + cast)
 // HBM-bound: 4 B read + 2 or 4 B written per element; 16-byte accesses when C % 4 == 0.
 #include "common.h"
+#include "dropout.h"
 #include "../../include/pevae_hip.h"
 
 namespace {
-
-// keep decisions of the 4 logical elements 4*q .. 4*q+3 of call site `site` at the state's current step
-__device__ __forceinline__ void keep4(const RngState& st, uint32_t site, unsigned long long q, uint32_t thresh, bool (&keep)[4]) {
-  uint32_t r[4];
-  philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), site, (uint32_t)st.step ^ (uint32_t)(st.step >> 32) * 0x9E3779B9u,
-                (uint32_t)st.seed, (uint32_t)(st.seed >> 32), r);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) keep[k] = r[k] >= thresh;        // P(keep) = 1 - p
-}
 
 struct DropArgs {
   const float* src;
@@ -34,24 +26,7 @@ struct DropArgs {
 };
 
 __device__ __forceinline__ void drop4(const DropArgs& a, long midx, const RngState& st, float (&v)[4]) {
-  if (a.mask) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = a.mask[midx + k] ? v[k] * a.scale : 0.f;
-    return;
-  }
-  if ((midx & 3) == 0) {
-    bool keep[4];
-    keep4(st, a.site, (unsigned long long)midx >> 2, a.thresh, keep);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = keep[k] ? v[k] * a.scale : 0.f;
-  } else {                                     // group straddles two counters
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      bool keep[4];
-      keep4(st, a.site, (unsigned long long)(midx + k) >> 2, a.thresh, keep);
-      v[k] = keep[(midx + k) & 3] ? v[k] * a.scale : 0.f;
-    }
-  }
+  drop4_at(a.mask, st, a.site, a.thresh, a.scale, midx, v);
 }
 
 // one thread per 4 consecutive columns of one (i0, i1) row; BF16OUT: dst rows i0*n1p + i1 of `ldd` bf16, zero padded
@@ -110,9 +85,8 @@ int fill_args(DropArgs& a, const float* src, int n0, int n1, int n1p, int C, lon
   PV_REQUIRE(src && n0 > 0 && n1 > 0 && C > 0 && n1p >= n1, "%s: bad shape", who);
   PV_REQUIRE(p >= 0.f && p < 1.f, "%s: p=%f must be in [0, 1)", who, (double)p);
   PV_REQUIRE(mask || rng, "%s: need a keep mask or a generator state", who);
-  const double t = (double)p * 4294967296.0;
   a = DropArgs{src, n0, n1, n1p, C, s0, s1, sc, m0, m1, (const uint8_t*)mask, (const RngState*)rng, (uint32_t)site,
-               (uint32_t)(t >= 4294967295.0 ? 4294967295.0 : t), 1.f / (1.f - p)};
+               drop_threshold(p), 1.f / (1.f - p)};
   return PV_OK;
 }
 

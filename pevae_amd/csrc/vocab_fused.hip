@@ -23,6 +23,7 @@
 // share of a unit is a SEGMENT; every segment leaves a partial result in a slab of the workspace and a second kernel
 // folds a unit's segments in workgroup order (fixed order: bitwise reproducible, no atomics).
 #include "common.h"
+#include "dropout.h"
 #include "../../include/pevae_hip.h"
 
 namespace {
@@ -607,6 +608,38 @@ __global__ void scatter_rows_scaled_kernel(const float* __restrict__ src, const 
   }
 }
 
+// the same with the backward of a dropout on the destination folded in: destination row r = i0 * n1p + i1 holds the
+// logical elements i0 * m0 + i1 * m1 + c (pv_dropout_f32's index convention); rows with i1 >= n1 are padding
+struct RowDrop {
+  const uint8_t* mask;
+  const RngState* rng;
+  uint32_t site, thresh;
+  float scale;
+  int n1, n1p;
+  long m0, m1;
+};
+
+__global__ void scatter_rows_scaled_drop_kernel(const float* __restrict__ src, const float* __restrict__ scale, float factor,
+                                                const int64_t* __restrict__ perm, const int* __restrict__ count, int T, int cols4,
+                                                float* __restrict__ dst, long ldd, RowDrop d) {
+  const long n = (long)T * cols4;
+  const int live = count ? *count : T;
+  RngState st{0, 0};
+  if (!d.mask) st = *d.rng;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / cols4), c = (int)(i % cols4) * 4;
+    const long drow = perm ? perm[row] : row;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int i0 = (int)(drow / d.n1p), i1 = (int)(drow % d.n1p);
+    if (row < live && i1 < d.n1) {
+      const f32x4 x = *(const f32x4*)(src + (long)row * cols4 * 4 + c) * (scale[row] * factor);
+      v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+      drop4_at(d.mask, st, d.site, d.thresh, d.scale, i0 * d.m0 + i1 * d.m1 + c, v);
+    }
+    *(f32x4*)(dst + drow * ldd + c) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+}
+
 int grid_wgs() {
   static int g = 0;
   if (!g) {
@@ -728,6 +761,23 @@ int pv_scatter_rows_scaled_f32(const float* src, const float* scale, float facto
   hipLaunchKernelGGL(scatter_rows_scaled_kernel, dim3((unsigned)(gx > 4096 ? 4096 : gx)), dim3(256), 0, (hipStream_t)stream, src,
                      scale, factor, perm, count, T, cols / 4, dst, ldd);
   PV_LAUNCH_CHECK("scatter_rows_scaled_kernel");
+  return PV_OK;
+}
+
+int pv_scatter_rows_scaled_drop_f32(const float* src, const float* scale, float factor, const int64_t* perm, const int* count,
+                                    int T, int cols, float* dst, long ldd, int n1, int n1p, long m0, long m1, float p,
+                                    const void* mask, const void* rng_state, int site, void* stream) {
+  PV_REQUIRE(src && scale && dst && T > 0 && cols > 0 && cols % 4 == 0 && ldd >= cols && ldd % 4 == 0,
+             "pv_scatter_rows_scaled_drop_f32: bad argument (cols and ldd must be multiples of 4)");
+  PV_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "pv_scatter_rows_scaled_drop_f32: buffers must be 16-byte aligned");
+  PV_REQUIRE(n1 > 0 && n1p >= n1 && T % n1p == 0, "pv_scatter_rows_scaled_drop_f32: T=%d rows are not whole groups of n1p=%d", T, n1p);
+  PV_REQUIRE(p >= 0.f && p < 1.f && (mask || rng_state), "pv_scatter_rows_scaled_drop_f32: p in [0, 1) and a keep mask or a generator state");
+  RowDrop d{(const uint8_t*)mask, (const RngState*)rng_state, (uint32_t)site, drop_threshold(p), 1.f / (1.f - p), n1, n1p, m0, m1};
+  const long n = (long)T * (cols / 4);
+  const long gx = (n + 255) / 256;
+  hipLaunchKernelGGL(scatter_rows_scaled_drop_kernel, dim3((unsigned)(gx > 4096 ? 4096 : gx)), dim3(256), 0, (hipStream_t)stream,
+                     src, scale, factor, perm, count, T, cols / 4, dst, ldd, d);
+  PV_LAUNCH_CHECK("scatter_rows_scaled_drop_kernel");
   return PV_OK;
 }
 

@@ -583,6 +583,9 @@ SKIP_IGNORED_TOKENS = os.environ.get("PEVAE_VOCAB_DENSE", "0") != "1"     # see 
 FUSED_VOCAB = os.environ.get("PEVAE_VOCAB_FUSED", "1") != "0"
 
 
+FUSE_DROP_SCATTER = os.environ.get("PEVAE_FUSE_DROP_SCATTER", "1") == "1"
+
+
 class VocabNLL(torch.autograd.Function):
     """nll_tok[t] = -log_softmax((h W^T + b) / temperature)[target[t]], 0 for ignored targets; the [T,V]
     log-prob tensor is never built (decoders.py:191-193 + criterions.py:55-64 of the reference, fused).
@@ -724,7 +727,14 @@ class VocabNLL(torch.autograd.Function):
             _lib.call("pv_vocab_gscale", _p(dnll.to(torch.float32).contiguous()), _p(perm), _p(target), ignore_index, T,
                       _p(gscale), _stream())
         dH = torch.empty((T, H), dtype=torch.float32, device=dev)
-        _lib.call("pv_scatter_rows_scaled_f32", _p(U), _p(gscale), inv_temp, _p(perm), _p(count), T, H, _p(dH), H, _stream())
+        if ctx.drop is not None and FUSE_DROP_SCATTER and T % ctx.drop[3][2] == 0:
+            # the output dropout's backward rides in the scatter's store pass (one pass over dH instead of two)
+            p_, site_, mask_, (n0, n1, n1p, m0, m1) = ctx.drop
+            _lib.call("pv_scatter_rows_scaled_drop_f32", _p(U), _p(gscale), inv_temp, _p(perm), _p(count), T, H, _p(dH), H,
+                      n1, n1p, m0, m1, p_, _p(mask_), _p(rng_state(dev)), site_, _stream())
+            ctx.drop_done = True
+        else:
+            _lib.call("pv_scatter_rows_scaled_f32", _p(U), _p(gscale), inv_temp, _p(perm), _p(count), T, H, _p(dH), H, _stream())
         weight, _bias = ctx.params
         sink = grad_sink(weight, (V, H))
         dW = sink if sink is not None else torch.empty((V, H), dtype=torch.float32, device=dev)
@@ -788,8 +798,9 @@ class VocabNLL(torch.autograd.Function):
     def _finish_dh(ctx, dH, H, dev):
         if ctx.drop is not None:                       # dL/d(undropped states) = dH * keep / (1 - p), in place
             p_, site_, mask_, (n0, n1, n1p, m0, m1) = ctx.drop
-            _lib.call("pv_dropout_f32", _p(dH), n0, n1, H, n1p * H, H, 1, m0, m1, p_, _p(mask_), _p(rng_state(dev)), site_,
-                      _p(dH), n1p * H, H, _stream())
+            if not getattr(ctx, "drop_done", False):   # (the fused backward folds it into its scatter pass)
+                _lib.call("pv_dropout_f32", _p(dH), n0, n1, H, n1p * H, H, 1, m0, m1, p_, _p(mask_), _p(rng_state(dev)), site_,
+                          _p(dH), n1p * H, H, _stream())
             if ctx.layout is None:
                 dH = dH.view(n0, n1, H)
         if ctx.layout is not None:

@@ -751,3 +751,35 @@ def test_fan_out_sums_the_gradients_of_its_aliases(dev):
     assert a is not y and b is not y and c is y and fan(xs[0]) is xs[0]
     (a.sum() + 2 * b.sum() + 3 * c.sum()).backward()
     assert torch.equal(y.grad, torch.full_like(y, 6.0))
+
+
+@pytest.mark.parametrize("use_mask", [True, False])
+def test_scatter_rows_scaled_with_dropout_backward_folded_in(dev, use_mask):
+    """pv_scatter_rows_scaled_drop_f32 = pv_scatter_rows_scaled_f32 followed by pv_dropout_f32 on the destination (the
+    decoder's output dropout backward, decoders.py:189), bit for bit: supplied keep mask and regenerated Philox decisions,
+    time-major rows with batch padding (n1p > n1), a live-row count below T."""
+    from pevae_amd import _lib, ops
+    g = torch.Generator().manual_seed(31)
+    L, B, Bpad, H, p = 7, 24, 32, 64, 0.3
+    T = L * Bpad
+    live = 150
+    src = torch.randn(T, H, generator=g).to(dev)
+    scale = torch.randn(T, generator=g).to(dev)
+    perm = torch.randperm(T, generator=g).to(dev)
+    count = torch.tensor([live], dtype=torch.int32, device=dev)
+    mask = (torch.rand(B, L, H, generator=g) >= p).to(torch.uint8).to(dev) if use_mask else None
+    m0, m1 = H, L * H                                   # operand row (t, b) holds logical [b, t, :] of a [B, L, H] tensor
+    ops.rng_seed(1234, dev)
+    want = torch.empty(T, H, device=dev)
+    _lib.call("pv_scatter_rows_scaled_f32", ops._p(src), ops._p(scale), 0.5, ops._p(perm), ops._p(count), T, H, ops._p(want), H,
+              ops._stream())
+    _lib.call("pv_dropout_f32", ops._p(want), L, B, H, Bpad * H, H, 1, m0, m1, p, ops._p(mask), ops._p(ops.rng_state(dev)), 77,
+              ops._p(want), Bpad * H, H, ops._stream())
+    got = torch.full((T, H), 9.0, device=dev)
+    _lib.call("pv_scatter_rows_scaled_drop_f32", ops._p(src), ops._p(scale), 0.5, ops._p(perm), ops._p(count), T, H, ops._p(got), H,
+              B, Bpad, m0, m1, p, ops._p(mask), ops._p(ops.rng_state(dev)), 77, ops._stream())
+    v = got.view(L, Bpad, H)
+    assert torch.equal(v[:, :B], want.view(L, Bpad, H)[:, :B])
+    assert float(v[:, B:].abs().max()) == 0.0            # padding rows: zeros
+    kept = float((v[:, :B] != 0).float().mean())
+    assert 0.05 < kept < 0.7                             # ~ live / T * (1 - p) of the entries survive
