@@ -147,19 +147,37 @@ __global__ __launch_bounds__(256) void sparse_pack_kernel(const float* __restric
 // order on every rank, no atomics -- and OVERWRITES the table's gradient row (every locally touched row is among them).
 __global__ __launch_bounds__(256) void sparse_merge_kernel(const float* __restrict__ gathered, int world, long rank_stride,
                                                             int n, int D, long num_rows, float* __restrict__ table) {
-  extern __shared__ float ids_s[];                           // world * n ids
-  const int E = world * n, e = blockIdx.x;
-  for (int j = threadIdx.x; j < E; j += 256) ids_s[j] = gathered[(long)(j / n) * rank_stride + j % n];
+  extern __shared__ float ids_s[];                           // world * n ids, then the list of this id's entries
+  __shared__ int wave_cnt[4];
+  const int E = world * n, e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int* list = (int*)(ids_s + E);
+  for (int j = tid; j < E; j += 256) ids_s[j] = gathered[(long)(j / n) * rank_stride + j % n];
   __syncthreads();
   const float idf = ids_s[e];
-  for (int j = 0; j < e; ++j)
-    if (ids_s[j] == idf) return;                             // not the first entry of this id (workgroup-uniform)
+  int dup = 0;
+  for (int j = tid; j < e; j += 256) dup |= ids_s[j] == idf;
+  if (__syncthreads_or(dup)) return;                         // not the first entry of this id (workgroup-uniform)
   const long id = (long)idf;
   if (id < 0 || id >= num_rows) return;
-  for (int c = threadIdx.x; c < D; c += 256) {
+  int total = 0;                                             // entries e .. E-1 with this id, compacted in entry order
+  for (int base = e; base < E; base += 256) {
+    const int j = base + tid;
+    const bool m = j < E && ids_s[j] == idf;
+    const unsigned long long bal = __ballot(m);
+    if (lane == 0) wave_cnt[w] = __popcll(bal);
+    __syncthreads();
+    int off = total;
+    for (int k = 0; k < w; ++k) off += wave_cnt[k];
+    if (m) list[off + __popcll(bal & ((1ull << lane) - 1))] = j;
+    total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  for (int c = tid; c < D; c += 256) {
     float acc = 0.f;
-    for (int j = e; j < E; ++j)
-      if (ids_s[j] == idf) acc += gathered[(long)(j / n) * rank_stride + n + (long)(j % n) * D + c];
+    for (int k = 0; k < total; ++k) {
+      const int j = list[k];
+      acc += gathered[(long)(j / n) * rank_stride + n + (long)(j % n) * D + c];
+    }
     table[id * D + c] = acc;
   }
 }
@@ -241,8 +259,8 @@ int pv_sparse_merge(const float* gathered, int world, long rank_stride, int n, i
                     void* stream) {
   PV_REQUIRE(gathered && table_grad && world > 0 && n > 0 && D > 0 && rank_stride >= (long)n * (D + 1),
              "pv_sparse_merge: bad argument");
-  const size_t lds = (size_t)world * n * sizeof(float);
-  PV_REQUIRE(lds <= 64 * 1024, "pv_sparse_merge: %d x %d ids exceed the 16384 the kernel stages", world, n);
+  const size_t lds = (size_t)world * n * (sizeof(float) + sizeof(int));
+  PV_REQUIRE(lds <= 64 * 1024, "pv_sparse_merge: %d x %d ids exceed the 8192 the kernel stages", world, n);
   hipLaunchKernelGGL(sparse_merge_kernel, dim3(world * n), dim3(256), lds, (hipStream_t)stream, gathered, world, rank_stride, n,
                      D, num_rows, table_grad);
   PV_LAUNCH_CHECK("sparse_merge_kernel");

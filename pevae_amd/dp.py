@@ -124,7 +124,7 @@ class FlatGradReducer(object):
     def device_sparse(self, sparse_ids):
         """True when the sparse tables travel through pv_sparse_pack / pv_sparse_merge (device tensors, ids exact in fp32)."""
         return bool(self.flat.is_cuda and self.tables and all(rows <= (1 << 24) for _, rows, _ in self.tables)
-                    and self.world * max(ids.numel() for ids in sparse_ids) <= 16384)
+                    and self.world * max(ids.numel() for ids in sparse_ids) <= 8192)
 
     def pack_sparse(self, sparse_ids):
         """The pack launches alone (device path), on the current stream -- for a caller that sets `external_sparse` and

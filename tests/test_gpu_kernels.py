@@ -646,6 +646,12 @@ def test_dp_sparse_pack_merge_kernels(dev):
     from pevae_amd import _lib, dp, ops
     g = torch.Generator().manual_seed(22)
     rows, D, n, W = 500, 256, 64, 3
+    _sparse_pack_merge_case(dev, g, rows, D, n, W)
+    _sparse_pack_merge_case(dev, g, 30000, 256, 256, 8)      # the N = 8 Yelp shape: 2048 entries
+
+
+def _sparse_pack_merge_case(dev, g, rows, D, n, W):
+    from pevae_amd import _lib, dp, ops
     tables, ids = [], []
     for r in range(W):
         idv = torch.randint(0, rows, (n,), generator=g)
