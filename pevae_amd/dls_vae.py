@@ -26,6 +26,7 @@ from .enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
 from .enc2dec.encoders import EncoderRNN
 from .utils import Pack
 
+PREPARE_LATE = os.environ.get("PEVAE_PREPARE_LATE", "1") == "1"
 PREPARE_ON_SIDE = os.environ.get("PEVAE_PREPARE_ON_SIDE", "1") == "1"      # DLSVAE._prepare_on_side
 
 # vocab = [<pad>, <unk>, <sys>, <usr>] + words by frequency (corpora.py:649).  <s> and </s> open and close every
@@ -173,7 +174,8 @@ class DLSVAE(nn.Module):
     def forward(self, data_feed, mode=TEACH_FORCE, gen_type="greedy", eps=None):
         if self.training and self.config.dropout > 0:
             ops.rng_advance(self.x_embedding.weight.device)      # new dropout masks every step, also under graph replay
-        if data_feed["user_ids"].is_cuda and mode == TEACH_FORCE and PREPARE_ON_SIDE:
+        prep_late = PREPARE_LATE and self.latent_stack == "dls"
+        if data_feed["user_ids"].is_cuda and mode == TEACH_FORCE and PREPARE_ON_SIDE and not prep_late:
             self._prepare_on_side(data_feed)
         early_sn = self.latent_stack == "dls" and data_feed["user_ids"].is_cuda
         if early_sn:
@@ -203,6 +205,8 @@ class DLSVAE(nn.Module):
                     self._sn_modules, self._sn_cache = L.spectral_modules(self), {}
                 ops.spectral_prepass(self._sn_modules, self.training, cache=self._sn_cache)    # all 105 power iterations
             ops.join_side_work()
+            if prep_late and data_feed["user_ids"].is_cuda and mode == TEACH_FORCE and PREPARE_ON_SIDE:
+                self._prepare_on_side(data_feed)             # beside the latent stack; joined in front of the decoder
             (z_pri, pri_state), (z_rec, rec_state) = L.pyramid_pair(self.pri_encoder, prior_h,         # :3529
                                                                     self.rec_encoder, h)               # :3530
             if self.use_mutual:                                                            # :3089 (DeN_VAE)
@@ -228,6 +232,8 @@ class DLSVAE(nn.Module):
         attn_ctx = enc_outs if self.config.use_attention else None
         feature = (ops.embedding(self.feature_embedding.weight, data_feed["feature_ids"])
                    if self.use_feature else None)                                          # :762-763
+        if prep_late:
+            ops.join_side_work()
         dec_outs, dec_last, dec_ctx = self.x_decoder(B, data_feed["input_ids"], dec_init, mode=mode,
                                                      gen_type=gen_type, beam_size=self.config.beam_size,
                                                      attn_context=attn_ctx, latent_variable=feature)   # :712
