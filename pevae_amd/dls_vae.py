@@ -257,7 +257,8 @@ class DLSVAE(nn.Module):
 
     def _prepare_on_side(self, data_feed):
         """What the decoder half of the step needs and the inputs of the step already determine, made on the side stream
-        beside the embedding / encoder launches (joined by the encoder recurrence's launch): the bf16 operand copies of
+        beside the latent stack's forward (joined in front of the decoder; PEVAE_PREPARE_LATE=0 or the flat Gaussian stack:
+        beside the embedding / encoder launches, joined by the encoder recurrence's launch): the bf16 operand copies of
         the vocabulary projection and of the decoder's recurrence weights, and -- for the teacher-forced fused path -- the
         targets in operand row order with their live-row partition.  Consumed once by ops.pack_matrix /
         DeferredLogProbs.token_nll; anything left over is dropped at the next call."""
