@@ -85,13 +85,26 @@ def cpu_baseline(cfg, batch, steps):
 
 def main():
     args = parse()
-    from pevae_amd import dp, ops
+    from pevae_amd import dp
+    # --gpus N without torchrun: this process starts the N ranks itself (before it touches a GPU: device_count() does
+    # not initialise one) and leaves with their status; rank 0's JSON line goes to the inherited stdout.  There is no
+    # fall-back to fewer GPUs: a layout that cannot run exits non-zero with the reason.
+    try:
+        cmd = dp.self_launch_command(args.gpus, os.path.abspath(__file__), sys.argv[1:], os.environ,
+                                     torch.cuda.device_count())
+        if cmd is not None:
+            import subprocess
+            sys.exit(subprocess.call(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "16"))))
+        # one rank per GPU: the persistent recurrence kernels need the whole chip
+        rank, world, local = dp.init_from_env(expect_world=args.gpus)
+    except dp.LaunchError as err:
+        print("bench.py: %s" % err, file=sys.stderr)
+        sys.exit(2)
+    from pevae_amd import ops
     from pevae_amd.dls_vae import DLSVAE, default_config, synthetic_batch
     from pevae_amd.optim import FlatAdam
     if args.vocab_dense:
         ops.SKIP_IGNORED_TOKENS = False
-    rank, world, local = dp.init_from_env()      # one rank per GPU: the persistent recurrence kernels need the whole chip
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     # everything (warm-up, capture, replay, eager passes) runs on ONE non-default stream: autograd ties each node
@@ -291,8 +304,9 @@ def main():
                   float(static_loss.vae_nll.detach()) if args.graph else None, "nonfinite grads:", bad[:6], file=sys.stderr)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
-            torch.distributed.barrier()
+            torch.distributed.barrier()          # host barrier (gloo) between two device synchronisations
         torch.cuda.synchronize()
 
     barrier()
@@ -302,10 +316,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.gru_check_all()
+    rccl_ranks, devices = 1, [dp.device_identity(local)]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        rccl_ranks = dp.rccl_rank_count(dev)          # what RCCL itself joined: must be N
+        devices = [None] * world
+        torch.distributed.all_gather_object(devices, dp.device_identity(local))
+        if rccl_ranks != world:
+            print("bench.py: RCCL joined %d ranks, %d were started" % (rccl_ranks, world), file=sys.stderr)
+            sys.exit(3)
     if world > 1 and os.environ.get("PEVAE_BENCH_DEBUG"):
         # replicas must hold bit-identical parameters after any number of steps
         cs = opt.flat_p.double().sum().reshape(1)
@@ -387,7 +408,8 @@ def main():
                        "dp_exchange_stages": (3 if three else 2 if split else 1) if (world > 1 or rehearse) else 0,
                        "dp_rehearsal_one_rank": rehearse,
                        "global_batch": args.batch * world, "seq_len": cfg.max_seq_len, "params": n_params,
-                       "parallelism": "dp%d" % world, "hip_graph": bool(args.graph),
+                       "parallelism": "dp%d" % world, "rccl_ranks": rccl_ranks, "devices": devices,
+                       "hip_graph": bool(args.graph),
                        "padding_rows_skipped": bool(ops.SKIP_IGNORED_TOKENS),
                        "live_target_fraction": round(float(sum((b["ans_ids"] != 0).float().mean() for b in batches)) / len(batches), 4)},
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kern_ms, "final_vae_nll": round(final_nll, 4),

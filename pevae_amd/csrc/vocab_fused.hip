@@ -46,6 +46,24 @@ constexpr float NEG_BIG = -1e30f;
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr float RESCALE_THR = 28.f;     // log2 units: a row's maximum may exceed the one in use by this much before O is rescaled
 
+// Diagnostic build only (-DPV_VOCAB_STAMPS): every wave accumulates shader-clock cycles per section of its item loop
+// (s_memtime; the stamp drains the LDS queue, so read the SHARES, never this build's run time) into a table of its own
+// that no kernel reads; tools/vocab_stamps.py copies it out with pv_vocab_stamps_copy.
+#ifdef PV_VOCAB_STAMPS
+constexpr int NSTAMP = 8;
+__device__ unsigned long long g_vstamps[2][256][4][NSTAMP];
+#define PV_STAMP_DECL unsigned long long st_acc[NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0; \
+  { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define PV_STAMP(i) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+  st_acc[i] += t_ - st_last; st_last = t_; }
+#define PV_STAMP_FLUSH(k) if (lane == 0 && blockIdx.x < 256) { _Pragma("unroll") for (int i_ = 0; i_ < NSTAMP; ++i_) g_vstamps[k][blockIdx.x][w][i_] = st_acc[i_]; }
+#else
+#define PV_STAMP_DECL
+#define PV_STAMP(i)
+#define PV_STAMP_FLUSH(k)
+#endif
+
 struct Segs {                            // a workgroup's item range and how units map to its slabs
   long beg, end;
 };
@@ -214,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
   const int rbase = 256 * r32, swh = (((r32 & 3) << 2) | ((r32 >> 2) & 3)) ^ hh;
   const TrAddr tr = make_tr(lane);
   int seg = 0;
+  PV_STAMP_DECL
   for (long at = beg; at < end; ++seg) {
     const int rg = (int)(at / NVI), vi0 = (int)(at % NVI);
     const int nvi = (int)min((long)NVI - vi0, end - at);
@@ -241,9 +260,12 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
         __builtin_amdgcn_global_load_lds((gptr_t)(a.bias + min(v0 + r32, a.V - 1)), (lptr_t)(buf + TILE_BYTES), 4, 0, 0);
     };
     stage(0);
+    PV_STAMP(0)
     for (int k = 0; k < nvi; ++k) {
       __syncthreads();                       // tile k has landed (every wave waited for its own pieces), tile k-1 is done with
+      PV_STAMP(1)
       if (k + 1 < nvi) stage(k + 1);
+      PV_STAMP(2)
       const char* tile = smem + (k & 1) * BUF_BYTES;
       const float* bias_t = (const float*)(tile + TILE_BYTES);
       const int v0 = (vi0 + k) * 32;
@@ -252,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) X[j] = 0.f;
       first_product(tile, rbase, swh, hf, X);
+      PV_STAMP(3)
       // ---- scaled logits in LOG2 units (exp is v_exp_f32 = 2^x: no multiply per element), running maximum (shared by the
       // two lane halves of a row), target logit.  The column mask and the target pick are needed by one tile in hundreds:
       // both sit behind wave-uniform branches.
@@ -302,9 +325,11 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
         l_sum += p;
         pf[j >> 3][j & 7] = (__bf16)p;
       }
+      PV_STAMP(4)
       // ---- O^T[hc][t] += W^T[hc][v] P^T[v][t]: columns of the same W tile x the probabilities, register to register ----
       second_product<true>(tile, tr, 0, pf[0], O);
       second_product<true>(tile, tr, 1, pf[1], O);
+      PV_STAMP(5)
     }
     // ---- partial result of this segment: O^T as [hc][t] (128-byte runs), (m, l, target logit) per row -----------------
     const long slab = (long)rid * a.max_seg + seg;
@@ -317,7 +342,9 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
     tl += xor32(tl);
     if (hh == 0) a.stats[slab * UNIT + 32 * w + r32] = make_float4(m_used * LN2, l_sum, tl * LN2, 0.f);
     __syncthreads();                           // the ring restarts with the next segment
+    PV_STAMP(6)
   }
+  PV_STAMP_FLUSH(0)
 }
 
 // fold a row group's segments: lse, nll, U[t][:] = sum_seg O_seg e^(m_seg - M) / L - W[y_t]
@@ -445,6 +472,7 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
   const int rbase = 256 * r32, swh = (((r32 & 3) << 2) | ((r32 >> 2) & 3)) ^ hh;
   const TrAddr tr = make_tr(lane);
   int seg = 0;
+  PV_STAMP_DECL
   for (long at = beg; at < end; ++seg) {
     const int ct = (int)(at / NRI), ri0 = (int)(at % NRI);
     const int nri = (int)min((long)NRI - ri0, end - at);
@@ -476,9 +504,12 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
         __builtin_amdgcn_global_load_lds((gptr_t)(a.target + t), (lptr_t)(buf + TILE_BYTES + 256), 4, 0, 0);
     };
     stage(0);
+    PV_STAMP(0)
     for (int k = 0; k < nri; ++k) {
       __syncthreads();
+      PV_STAMP(1)
       if (k + 1 < nri) stage(k + 1);
+      PV_STAMP(2)
       const char* tile = smem + (k & 1) * BUF_BYTES;
       const float* lse_t = (const float*)(tile + TILE_BYTES);
       const float* gs_t = lse_t + 32;
@@ -489,6 +520,7 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) X[j] = 0.f;
       first_product(tile, rbase, swh, wf, X);
+      PV_STAMP(3)
       // ---- P = gs (softmax - onehot); its column sums are the bias gradient.  exp(s - lse) = 2^(X it_l2e + cb - lse log2e).
       // The row mask (rows past the live count: the last item only) and the onehot (a target inside this wave's 32 columns:
       // one item in twenty) sit behind a wave-uniform branch.  Columns past V need no mask: nothing reads their Z rows.
@@ -528,8 +560,10 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
         }
       }
       // ---- Z[v][hc] += P^T[v][t] h[t][hc]: the probabilities x columns of the same h tile -----------------------------
+      PV_STAMP(4)
       second_product<false>(tile, tr, 0, pf[0], Z);
       second_product<false>(tile, tr, 1, pf[1], Z);
+      PV_STAMP(5)
     }
     const long slab = (long)rid * a.max_seg + seg;
     float* z = a.z_slab + slab * UNIT * HD + r32;
@@ -540,7 +574,9 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
     bsum += xor32(bsum);
     if (hh == 0) a.b_slab[slab * UNIT + 32 * w + r32] = bsum;
     __syncthreads();
+    PV_STAMP(6)
   }
+  PV_STAMP_FLUSH(1)
 }
 
 struct DwReduceArgs {
@@ -674,6 +710,14 @@ int set_smem(K kernel) {
 }  // namespace
 
 extern "C" {
+
+#ifdef PV_VOCAB_STAMPS
+int pv_vocab_stamps_copy(void* host_dst, size_t bytes) {
+  PV_HIP(hipDeviceSynchronize());
+  PV_HIP(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_vstamps), bytes < sizeof(g_vstamps) ? bytes : sizeof(g_vstamps)));
+  return PV_OK;
+}
+#endif
 
 int pv_vocab_fused_supported(int H) { return H == HD ? 1 : 0; }
 

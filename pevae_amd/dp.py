@@ -16,20 +16,92 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+class LaunchError(RuntimeError):
+    """The process layout cannot run the step (fewer GPUs than ranks, two ranks on one GPU, world size mismatch)."""
+
+
+def device_identity(local):
+    """What tells two GPUs of a node apart: PCI domain:bus:device (and the UUID when the runtime reports one)."""
+    props = torch.cuda.get_device_properties(local)
+    bus = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    ident = "pci %04x:%02x:%02x" % bus if None not in bus else "device index %d" % local
+    uuid = getattr(props, "uuid", None)
+    return ident + (" uuid %s" % uuid if uuid is not None else "")
+
+
+def check_one_rank_per_device(identity, group=None):
+    """Every rank contributes the identity of the device it will use (an object all-gather: on a 'cpu:gloo,cuda:nccl'
+    group it travels over gloo, BEFORE any RCCL communicator exists).  Raises LaunchError on every rank when two ranks
+    name the same device: the persistent recurrence kernels need all CUs of a chip co-resident (two ranks on one GPU
+    wait for each other's workgroups inside their bounded spins) and RCCL refuses or hangs on duplicate devices --
+    gpurun_out/rehearse2.err of round 2 was exactly that layout.  Returns the identities in rank order."""
+    world = dist.get_world_size(group)
+    ids = [None] * world
+    dist.all_gather_object(ids, identity, group=group)
+    users = {}
+    for r, d in enumerate(ids):
+        users.setdefault(d, []).append(r)
+    shared = sorted((rs, d) for d, rs in users.items() if len(rs) > 1)
+    if shared:
+        raise LaunchError("one rank per GPU is required, but " + "; ".join(
+            "ranks %s share %s" % (",".join(map(str, rs)), d) for rs, d in shared))
+    return ids
+
+
+def init_from_env(backend=None, expect_world=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).  On GPUs the group
+    is 'cpu:gloo,cuda:nccl': object collectives and barriers run over gloo, tensor collectives on device buffers over
+    RCCL.  Fails loudly -- before any collective that could hang -- when the layout cannot work: WORLD_SIZE differs from
+    `expect_world`, LOCAL_RANK names a GPU the node does not have, or two ranks would share a GPU."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if expect_world is not None and world != expect_world:
+        raise LaunchError("WORLD_SIZE = %d but %d ranks were asked for: start the ranks with torch.distributed.run "
+                          "--nproc-per-node %d (bench.py --gpus N does that itself when WORLD_SIZE is unset)"
+                          % (world, expect_world, expect_world))
     if world <= 1:
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+        backend = "cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo"
+    on_gpu = "nccl" in backend
+    if on_gpu:
+        n_dev = torch.cuda.device_count()
+        if local >= n_dev:
+            raise LaunchError("rank %d (LOCAL_RANK %d) has no GPU of its own: this node shows %d GPU(s) for %d ranks; "
+                              "one rank per GPU is required" % (rank, local, n_dev, world))
         torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if on_gpu:
+        check_one_rank_per_device(device_identity(local))
     return rank, world, local
+
+
+def rccl_rank_count(device):
+    """All-reduce of ones on `device`: the number of ranks the collective backend really joined."""
+    one = torch.ones(1, device=device)
+    dist.all_reduce(one)
+    return int(one.item())
+
+
+def self_launch_command(n_gpus, script, argv, env, device_count, port=None):
+    """What `python bench.py --gpus N` does when it was not started by torchrun (WORLD_SIZE unset).  Returns None when
+    this process is itself a rank (or N = 1), else the command line that starts N fresh ranks -- decided before anything
+    touches a GPU.  Raises LaunchError when the node has fewer than N GPUs: never a silent one-GPU run."""
+    if n_gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    if device_count < n_gpus:
+        raise LaunchError("--gpus %d asked for, but this node shows %d GPU(s): one rank per GPU is required"
+                          % (n_gpus, device_count))
+    if port is None:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    import sys
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
 
 
 def bucket_bounds(n, bucket_elems):

@@ -174,3 +174,72 @@ def test_three_stage_schedule_sum_matches_dense_and_replicas_identical(tmp_path)
     from pevae_amd import dp
     with pytest.raises(ValueError):
         dp.FlatGradReducer(torch.zeros(100), 2, early_ranges=[(0, 50)], mid_ranges=[(40, 60)])
+
+
+# ---- launch layout: bench.py --gpus N starts its own ranks, and a layout that cannot run fails before it can hang ----------
+def test_self_launch_command_decides_before_any_gpu_call():
+    from pevae_amd import dp
+    argv = ["--gpus", "4", "--steps", "5"]
+    assert dp.self_launch_command(1, "bench.py", argv, {}, 8) is None                  # N = 1: this process is the run
+    assert dp.self_launch_command(4, "bench.py", argv, {"WORLD_SIZE": "4"}, 8) is None  # already a rank of torchrun
+    cmd = dp.self_launch_command(4, "/x/bench.py", argv, {}, 8, port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29999" and cmd[-5:] == ["/x/bench.py"] + argv
+    with pytest.raises(dp.LaunchError, match="shows 1 GPU"):                               # never a silent one-GPU run
+        dp.self_launch_command(2, "bench.py", argv, {}, 1)
+    port = int(dp.self_launch_command(2, "bench.py", argv, {}, 2)[9])                     # a free port is chosen when none is given
+    assert 1024 < port < 65536
+
+
+def test_init_from_env_rejects_a_world_size_mismatch(monkeypatch):
+    from pevae_amd import dp
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(dp.LaunchError, match="WORLD_SIZE = 1 but 8 ranks"):
+        dp.init_from_env(backend="gloo", expect_world=8)
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(dp.LaunchError, match="WORLD_SIZE = 4 but 2 ranks"):
+        dp.init_from_env(backend="gloo", expect_world=2)
+
+
+def _layout_worker(rank, world, port, out, shared):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from pevae_amd import dp
+    dp.init_from_env(backend="gloo", expect_world=world)
+    ident = "pci 0000:05:00" if shared else "pci 0000:%02x:00" % (5 + rank)
+    try:
+        got = dp.check_one_rank_per_device(ident)
+        msg = "ok " + "|".join(got)
+    except dp.LaunchError as err:
+        msg = "refused: %s" % err
+    with open(os.path.join(out, "l%d.txt" % rank), "w") as fh:
+        fh.write(msg)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_two_ranks_on_one_device_are_refused_on_every_rank(tmp_path, shared):
+    """The layout that hung round 2's rehearsal (two ranks, one GPU) now ends with a message on every rank."""
+    port = _free_port()
+    mp.spawn(_layout_worker, args=(2, port, str(tmp_path), shared), nprocs=2, join=True)
+    for r in range(2):
+        msg = open(os.path.join(str(tmp_path), "l%d.txt" % r)).read()
+        if shared:
+            assert msg.startswith("refused") and "ranks 0,1 share pci 0000:05:00" in msg
+        else:
+            assert msg == "ok pci 0000:05:00|pci 0000:06:00"
+
+
+def test_bench_gpus_n_without_enough_gpus_exits_nonzero_with_the_reason():
+    """`python bench.py --gpus 2` on a node with fewer GPUs (here: none) must not fall back to one GPU."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 2 and "one rank per GPU is required" in res.stderr and res.stdout.strip() == ""
+    env["WORLD_SIZE"] = "4"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 2 and "WORLD_SIZE = 4 but 2 ranks" in res.stderr
