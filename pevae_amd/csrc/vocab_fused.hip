@@ -22,6 +22,8 @@
 // whatever the live row count is (a device scalar: the launch geometry is static, HIP-graph capturable).  A workgroup's
 // share of a unit is a SEGMENT; every segment leaves a partial result in a slab of the workspace and a second kernel
 // folds a unit's segments in workgroup order (fixed order: bitwise reproducible, no atomics).
+#include <type_traits>
+#include <utility>
 #include "common.h"
 #include "dropout.h"
 #include "../../include/pevae_hip.h"
@@ -37,8 +39,10 @@ typedef __attribute__((address_space(3))) bf16x4* ltr_t;
 constexpr int HD = 512;                 // hidden width the kernels are built for (16 column blocks of 32)
 constexpr int NCB = HD / 32;            // 16 accumulator blocks per wave
 constexpr int NKS = HD / 16;            // 32 k-steps of the first product
-constexpr int TILE_BYTES = 32 * HD * 2; // one streamed tile: 32 rows x 512 bf16 = 32 KiB, four panels of 8 KiB
-constexpr int AUX_BYTES = 1024;         // per-tile side data (bias slice, or lse / gscale / targets of 32 rows)
+constexpr int SUB_BYTES = 32 * HD * 2;  // one sub-tile: 32 rows x 512 bf16 = 32 KiB, four panels of 8 KiB
+constexpr int ITEM = 64;                // rows of the streamed operand per item: two sub-tiles
+constexpr int TILE_BYTES = 2 * SUB_BYTES;
+constexpr int AUX_BYTES = 1024;         // per-tile side data (bias slice, or lse / gscale / targets of 64 rows)
 constexpr int BUF_BYTES = TILE_BYTES + AUX_BYTES;
 constexpr int SMEM_BYTES = 2 * BUF_BYTES;
 constexpr int UNIT = 128;               // rows (forward) / columns (dW) a workgroup's accumulators cover: 4 waves x 32
@@ -97,114 +101,208 @@ __device__ __forceinline__ int phase_sorted_range(long N, int G, int period, int
   return k;
 }
 
-// ---- staging: wave w fills panel w (32 rows x 256 B) of a tile with 8 LDS-DMA pieces of 4 rows ------------------------
-// image: off(panel, row, chunk) = panel * 8192 + row * 256 + 16 * (chunk ^ swz(row)), swz(row) = ((row & 3) << 2) | ((row >> 2) & 3)
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, long ld, int row0, int max_row, char* buf, int w,
-                                           int lane) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = 4 * i + (lane >> 4);
-    const int ch = (lane & 15) ^ (((lane >> 4) << 2) | (i & 3));
-    const bf16_t* p = src + (long)min(row0 + row, max_row) * ld + w * 128 + ch * 8;
-    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(buf + w * 8192 + i * 1024), 16, 0, 0);
-  }
+// ---- the streamed tile: TWO 32-row sub-tiles (A, B) of 32 KiB, each four 128-column panels of 256-byte rows ---------------
+// image of a sub-tile: off(panel, row, chunk) = panel * 8192 + row * 256 + 16 * (chunk ^ swz(row)), swz(row) = ((row & 3) << 2) | ((row >> 2) & 3)
+// Staging: wave w fills panel w of both sub-tiles with 16 LDS-DMA pieces of 4 rows (buffer_load_dwordx4 ... lds; the whole
+// byte offset sits in the VGPR operand -- the SGPR offset of a buffer instruction is NOT range-checked -- so rows past the
+// matrix are outside the descriptor and arrive as zeros: no address is clamped) -- issued ONE piece at a time between the
+// MFMAs of the item before (an LDS-DMA piece costs its wave 60-90 cycles of issue; back to back at the head of an item they
+// were 15 % of the kernel).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
+// One LDS-DMA piece, issued from asm: hipcc must assume that an LDS-DMA builtin in flight aliases every later LDS read of the
+// one dynamic LDS array and puts s_waitcnt vmcnt(0) in front of those reads -- each piece then cost its wave a full
+// L2 round trip (~150 cycles, 30 % of the weight-gradient kernel by timing ablation).  From asm the compiler sees neither the
+// load nor its LDS write; the kernels' own COUNTED waits (half_tile_landed) order the data.  M0 carries the wave-uniform LDS
+// destination and is restored (the compiler does not expect it to change).  SIZE: 16 or 4 bytes per lane.
+template <int SIZE>
+__device__ __forceinline__ void lds_dma(rsrc_t src, int voff, const void* lds_dst) {
+  const unsigned dst = (unsigned)(unsigned long)(lptr_t)lds_dst;
+  unsigned keep;
+  if constexpr (SIZE == 16)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
 }
 
-// row read for k-step ks (A operand of the first product): lane (r = lane & 31, hh = lane >> 5) gets row r, k = 16 ks + 8 hh ..
-__device__ __forceinline__ bf16x8 row_frag(const char* tile, int ks, int rbase, int swh) {
-  const int off = (ks >> 3) * 8192 + rbase + 16 * (((2 * ks) & 15) ^ swh);
-  return __builtin_bit_cast(bf16x8, *(const uint4*)(tile + off));
-}
-
-// column read for column block c, k-step s (operand of the second product): the 8 tile rows
-// 16 s + 8 (j >> 2) + 4 hh + (j & 3), j = 0..7, of column 32 c + (lane & 31) -- the k order in which an accumulator of the
-// first product hands its rows to the next MFMA
-struct TrAddr {
-  int base[2];      // per part u: 256 * (8 u + 4 hh + q) + 8 * (p & 1)
-  int sw[2];        // per part u: (q << 2) | (2 u + hh)
-  int lane_part;    // 2 cg + (p >> 1)
+struct StageLane {     // per lane: row part and chunk part of the source offset of a piece
+  int rowpart;         // (lane >> 4) * ld_bytes + w * 256
+  int chbase;          // (lane & 15) ^ ((lane >> 4) << 2)
 };
-__device__ __forceinline__ TrAddr make_tr(int lane) {
-  const int g = lane >> 4, hh = g >> 1, cg = g & 1, q = (lane & 15) >> 2, p = lane & 3;
-  TrAddr t;
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    t.base[u] = 256 * (8 * u + 4 * hh + q) + 8 * (p & 1);
-    t.sw[u] = (q << 2) | (2 * u + hh);
-  }
-  t.lane_part = 2 * cg + (p >> 1);
-  return t;
+__device__ __forceinline__ StageLane make_stage_lane(int lane, int w, int ld_bytes) {
+  return StageLane{(lane >> 4) * ld_bytes + w * 256, (lane & 15) ^ ((lane >> 4) << 2)};
 }
-__device__ __forceinline__ bf16x8 col_frag(const char* tile, const TrAddr& t, int c, int s) {
-  bf16x4 part[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int off = (c >> 2) * 8192 + 4096 * s + t.base[u] + 16 * (((4 * (c & 3)) | t.lane_part) ^ t.sw[u]);
-    part[u] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ltr_t)(tile + off));
-  }
-  return bf16x8{part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+template <int I>       // piece I of 16: sub-tile I >> 3, rows 4 (I & 7) .. + 3; off_tile: byte offset of the tile's first row
+__device__ __forceinline__ void stage_piece(rsrc_t src, const StageLane& sl, int ld_bytes, int off_tile, char* buf, int w) {
+  int cb = sl.chbase, rp = sl.rowpart;
+  asm volatile("" : "+v"(cb), "+v"(rp));     // (recomputed per piece: sixteen more loop-invariant registers would be spilled)
+  const int voff = rp + ((cb ^ (I & 3)) << 4) + (off_tile + (32 * (I >> 3) + 4 * (I & 7)) * ld_bytes);
+#ifdef PV_ABL_NOPIECE                    // timing ablation: the piece's address arithmetic without the instruction
+  asm volatile("" :: "v"(voff));
+#else
+  lds_dma<16>(src, voff, buf + (I >> 3) * SUB_BYTES + w * 8192 + (I & 7) * 1024);
+#endif
 }
 
+// ---- fragment reads.  A tile's LDS addresses are a per-lane base XOR a small constant (the swizzle) plus immediates:
+//   row read, k-step ks (A operand of the first product; lane (r = lane & 31, hh = lane >> 5) gets row r, k = 16 ks + 8 hh ..):
+//       (ks >> 3) * 8192 + [256 r | 16 (swz(r) ^ hh)] ^ 32 (ks & 7)
+//   column read, column block c, k-step s, part u (operand of the second product: the 8 tile rows
+//   16 s + 8 (j >> 2) + 4 hh + (j & 3), j = 0..7, of column 32 c + (lane & 31) -- the k order in which an accumulator of the
+//   first product hands its rows to the next MFMA; lane: g = lane >> 4, hh = g >> 1, cg = g & 1, q = (lane & 15) >> 2, p = lane & 3):
+//       (c >> 2) * 8192 + 4096 s + [256 (8 u + 4 hh + q) + 8 (p & 1) | 16 ((2 cg + (p >> 1)) ^ ((q << 2) | (2 u + hh)))] ^ 64 (c & 3)
+// Held as registers, the 8 + 8 XOR variants are loop-invariant, and hipcc spilled them (13 scratch reloads at the head of
+// every item).  The stream therefore walks the k-steps and the column blocks VARIANT-major -- four consecutive reads share
+// one XOR constant and differ by immediates -- and derives the variant's address from the base when it changes (FragAddr;
+// the empty asm keeps hipcc from hoisting the eight variants out of the loop again).
+struct FragBase { int row, col0, col1; };      // the bracketed per-lane terms above, plus the tile's LDS offset
+struct FragAddr { int row, col0, col1; };      // the current variant's addresses
+__device__ __forceinline__ FragBase make_frag_base(int lane) {
+  const int r32 = lane & 31, hh = lane >> 5, g = lane >> 4, cg = g & 1, q = (lane & 15) >> 2, p = lane & 3;
+  const int lp = 2 * cg + (p >> 1);
+  FragBase b;
+  b.row = 256 * r32 + 16 * ((((r32 & 3) << 2) | ((r32 >> 2) & 3)) ^ hh);
+  b.col0 = 256 * (4 * hh + q) + 8 * (p & 1) + 16 * (lp ^ ((q << 2) | hh));
+  b.col1 = 256 * (8 + 4 * hh + q) + 8 * (p & 1) + 16 * (lp ^ ((q << 2) | (2 + hh)));
+  return b;
+}
+// step N of an item (0..127) -> what its MFMA multiplies (the stream's layout: see "An item" below).  First product: k-step
+// ks = 8 (n & 3) + (n >> 2) (variant-major); second product: k-step s = n >> 4, column block c = 4 (n & 3) + ((n & 15) >> 2)
+template <int N> struct StepMap {
+  static constexpr int phase = N >> 5, n = N & 31;
+  static constexpr bool first = (phase & 1) == 0;
+  static constexpr int sub = phase == 0 ? 0 : phase == 1 ? 1 : phase == 2 ? 1 : 0;   // the sub-tile whose LDS image is read
+  static constexpr bool prev = phase == 1;                                         // ... of the tile BEFORE this item's
+  static constexpr int ks = 8 * (n & 3) + (n >> 2);
+  static constexpr int s = n >> 4, c = 4 * (n & 3) + ((n & 15) >> 2);
+};
+// dprev: byte distance from this item's LDS buffer to the other one (wave-uniform)
+template <int N>
+__device__ __forceinline__ bf16x8 item_frag(const char* lds, const FragBase& fb, int dprev, FragAddr& fa) {
+  using M = StepMap<N>;
+#ifdef PV_ABL_NOLDS                      // timing ablation: no fragment reads at all (results are garbage)
+  return __builtin_bit_cast(bf16x8, uint4{(unsigned)fb.row, (unsigned)fb.col0, (unsigned)fb.col1, (unsigned)N});
+#endif
+  if constexpr (M::first) {
+    if constexpr ((M::n & 3) == 0) {
+      int t = fb.row;
+      asm volatile("" : "+v"(t));
+      fa.row = t ^ (32 * (M::n >> 2));
+    }
+    return __builtin_bit_cast(bf16x8, *(const uint4*)(lds + fa.row + M::sub * SUB_BYTES + (M::n & 3) * 8192));
+  } else {
+    if constexpr ((M::n & 3) == 0) {
+      int t0 = fb.col0, t1 = fb.col1;
+      asm volatile("" : "+v"(t0), "+v"(t1));
+      fa.col0 = (t0 ^ (64 * ((M::n & 15) >> 2))) + (M::prev ? dprev : 0);
+      fa.col1 = (t1 ^ (64 * ((M::n & 15) >> 2))) + (M::prev ? dprev : 0);
+    }
+    constexpr int imm = M::sub * SUB_BYTES + (M::n & 3) * 8192 + 4096 * M::s;
+    const bf16x4 p0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ltr_t)(lds + fa.col0 + imm));
+    const bf16x4 p1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ltr_t)(lds + fa.col1 + imm));
+    return bf16x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+  }
+}
+// the second product of a segment's LAST sub-tile (B of the buffer at `fb`), which no later item carries: step n of 32
+template <int n>
+__device__ __forceinline__ bf16x8 tail_frag(const char* lds, const FragBase& fb, FragAddr& fa) {
+  if constexpr ((n & 3) == 0) {
+    int t0 = fb.col0, t1 = fb.col1;
+    asm volatile("" : "+v"(t0), "+v"(t1));
+    fa.col0 = t0 ^ (64 * ((n & 15) >> 2));
+    fa.col1 = t1 ^ (64 * ((n & 15) >> 2));
+  }
+  constexpr int imm = SUB_BYTES + (n & 3) * 8192 + 4096 * (n >> 4);
+  const bf16x4 p0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ltr_t)(lds + fa.col0 + imm));
+  const bf16x4 p1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ltr_t)(lds + fa.col1 + imm));
+  return bf16x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+}
+
+// max over the two lanes (l, l + 32) that share a row of the 32x32 accumulator layout: one v_permlane32_swap, no LDS
+__device__ __forceinline__ float max_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
-// First product, X += rows(tile) x stat[ks] over the 32 k-steps.  The LDS reads run one batch of four fragments ahead of
-// the MFMAs that consume them (an LDS round trip is about four 32-cycle MFMAs long); left to itself hipcc emits
-// read -> wait -> MFMA with one fragment register set and the chain runs at LDS latency.  ROWS_ARE_A: the streamed rows
-// are the A operand (forward kernel: rows of W against h fragments give S^T) or the B operand ... both kernels stream A.
+// The first product's accumulator must sit in VGPRs: the transform reads it with VALU instructions, and all 256 AGPRs belong
+// to the second product's accumulators.  Left to hipcc (the builtin), it is placed in AGPRs, the second product's
+// accumulators no longer fit and the kernel moves them in and out with thousands of v_accvgpr copies and spills; so this one
+// MFMA is written as asm with VGPR operands.  Nothing inside asm is padded by the assembler: FIRST (the chain's head, whose C
+// input a VALU or LDS instruction has just written) waits two states in front; mfma_v_done, behind the chain's tail, waits
+// the 18 states a 16-pass MFMA needs before VALU instructions may read its result.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int HEAD>      // 0: X += a b;  1: the chain's head, X (just written) += a b;  2: the chain's head, X = a b
+__device__ __forceinline__ void mfma_v(f32x16& X, const bf16x8& a, const bf16x8& b) {
+  const u32x4 av = __builtin_bit_cast(u32x4, a), bv = __builtin_bit_cast(u32x4, b);
+  if constexpr (HEAD == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(X) : "v"(av), "v"(bv));
+  else if constexpr (HEAD == 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(X) : "v"(av), "v"(bv));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(X) : "v"(av), "v"(bv));
+}
+__device__ __forceinline__ void mfma_v_done(f32x16& X) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(X)); }
+// The second product's accumulators, pinned to AGPRs the same way (under register pressure hipcc otherwise keeps some of the
+// sixteen blocks in VGPRs, uses the freed AGPRs for LDS fragments and spills the stationary operand: 372 spilled registers in
+// the weight-gradient kernel).  No wait states in front: the operands are LDS fragments (the compiler has waited for them) and
+// v_cvt_pk results that are at least one whole step old -- a step's VALU fillers come AFTER its MFMA, and the next step opens
+// with its LDS requests and the s_waitcnt, more than the two states a VALU-written operand needs.  (An s_nop 1 in front of every
+// MFMA was 8 of the 32 issue cycles a step has: one wave per SIMD is bound by its own instruction issue.)
+// mfma_a_done: before anything but an MFMA touches the accumulators.
+__device__ __forceinline__ void mfma_a(f32x16& ACC, const bf16x8& a, const bf16x8& b) {
+  const u32x4 av = __builtin_bit_cast(u32x4, a), bv = __builtin_bit_cast(u32x4, b);
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(av), "v"(bv));
+}
+__device__ __forceinline__ void mfma_a_done() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (LO < HI) {
+    f(std::integral_constant<int, LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
 #define PV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-__device__ __forceinline__ void first_product(const char* tile, int rbase, int swh, const bf16x8 (&stat)[NKS], f32x16& X) {
-  bf16x8 fa[4], fb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fa[i] = row_frag(tile, i, rbase, swh);
-#pragma unroll
-  for (int b = 0; b < NKS / 4; b += 2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fb[i] = row_frag(tile, 4 * (b + 1) + i, rbase, swh);
-    PV_SCHED_FENCE();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], stat[4 * b + i], X, 0, 0, 0);
-    PV_SCHED_FENCE();
-    if (b + 2 < NKS / 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = row_frag(tile, 4 * (b + 2) + i, rbase, swh);
-    }
-    PV_SCHED_FENCE();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], stat[4 * (b + 1) + i], X, 0, 0, 0);
-    PV_SCHED_FENCE();
-  }
+// "this half-tile has landed": every wave waits for its own pieces of it -- all but the 8 pieces (of the NEXT half-tile) it has
+// issued since -- and then the workgroup meets.  A raw s_barrier: __syncthreads() would add vmcnt(0) and drain the stream.
+__device__ __forceinline__ void half_tile_landed() {
+  PV_SCHED_FENCE();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  PV_SCHED_FENCE();
 }
+// which first-product step q (0..31) of wave w issues staging piece q / 4: the four waves of a workgroup run in lockstep
+// (one barrier per item) and share the CU's one vector-memory address unit, so their pieces go out at four different steps
+// Staging schedule.  A CU takes in LDS-DMA pieces at about one per 37 cycles (45 GB/s), and a wave that issues a piece into
+// a full queue stands still -- MFMAs included -- until there is room: 8 pieces per 32 steps from each of four waves ran at
+// that limit and cost 28 % of the kernel (timing ablations).  So the 16 pieces of a tile go out one per 7 steps over the
+// WHOLE item: during the 64 steps of sub-tile A the 8 pieces of the next tile's sub-tile A (needed 69+ steps later, at the
+// next item's head), during sub-tile B's the 8 pieces of the next tile's sub-tile B (needed 58+ steps later, when the next
+// item's stream reaches its first B fragment).  Two "half-tile landed" meetings per item, each behind a COUNTED wait.
+// (tried: staggered by wave behind a wave-uniform branch per step -- 375 -> 415 us, the branches cost more than they saved)
+#define PV_STAGE_AT(q) ((q) % 7 == 2 && (q) < 52)
 
-// Second product for k-step s: ACC[c] += (COLS_ARE_A ? cols(tile, c, s) x pf : pf x cols(tile, c, s)), c = 0..15, with the
-// transposed reads one batch of four column fragments ahead.
-template <bool COLS_ARE_A>
-__device__ __forceinline__ void second_product(const char* tile, const TrAddr& tr, int s, const bf16x8& pf, f32x16 (&ACC)[NCB]) {
-  bf16x8 fa[4], fb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fa[i] = col_frag(tile, tr, i, s);
-#pragma unroll
-  for (int b = 0; b < NCB / 4; b += 2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fb[i] = col_frag(tile, tr, 4 * (b + 1) + i, s);
-    PV_SCHED_FENCE();
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      ACC[4 * b + i] = COLS_ARE_A ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], pf, ACC[4 * b + i], 0, 0, 0)
-                                  : __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, fa[i], ACC[4 * b + i], 0, 0, 0);
-    PV_SCHED_FENCE();
-    if (b + 2 < NCB / 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = col_frag(tile, tr, 4 * (b + 2) + i, s);
-    }
-    PV_SCHED_FENCE();
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      ACC[4 * (b + 1) + i] = COLS_ARE_A ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], pf, ACC[4 * (b + 1) + i], 0, 0, 0)
-                                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, fb[i], ACC[4 * (b + 1) + i], 0, 0, 0);
-    PV_SCHED_FENCE();
-  }
-}
-
+// An item = 128 MFMA steps around one streamed tile (sub-tiles A, B), as ONE stream; the second product runs ONE sub-tile
+// behind the first, so that each sub-tile's transform (VALU) sits in the shadow of the sub-tile-before's second product:
+//   steps   0.. 31   X  = rows(A)[ks] x stat[ks]                           first product of A    | 8 pieces: next tile's A
+//   (between)        decision for A (mask / target pick / row maximum / rare rescale)             the one section without MFMAs
+//   steps  32.. 63   ACC[c] += cols(B of the tile BEFORE)[c, s] (x) P_B'   second product of B'  | transform X -> P_A
+//   steps  64.. 95   X  = rows(B)[ks] x stat[ks]                           first product of B    | 8 pieces: next tile's B
+//   (between)        decision for B
+//   steps  96..127   ACC[c] += cols(A)[c, s] (x) P_A                       second product of A   | transform X -> P_B
+// and the last sub-tile of a segment is multiplied in by a 32-step tail behind the item loop.  A segment starts with P_B' = 0
+// (its first second product adds zeros from whatever finite tile the other buffer holds).  One accumulator X and two sets
+// of probabilities are live (8 registers more than without the lag; both sub-tiles' X at once does not fit: hipcc spilled).
+// The LDS fragment of step i is requested at step i - DEPTH (across the phase boundaries: an LDS round trip under load is
+// several MFMAs long), and every step is fenced (sched_barrier) so that each MFMA keeps its few fillers -- one LDS request,
+// now and then a piece of the next tile's staging, a slice of the transform -- in its own 32-cycle shadow: one wave per SIMD
+// has nobody else to fill the matrix pipe's issue gaps.
+#ifndef PV_DEPTH
+#define PV_DEPTH 6
+#endif
+constexpr int DEPTH = PV_DEPTH;
 // =====================================================================================================================
 // forward + dH:  per row t   lse, target logit, O[t] = sum_v exp(s_tv - m) W[v]  (partial over a vocabulary range)
 // =====================================================================================================================
@@ -222,17 +320,32 @@ struct FwdArgs {
 
 __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r32 = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x;
   const int nlive = a.live ? min(a.T, *a.live) : a.T;
-  const int NVI = (a.V + 31) / 32, NRG = (nlive + UNIT - 1) / UNIT;
+  const int NVI = (a.V + ITEM - 1) / ITEM, NRG = (nlive + UNIT - 1) / UNIT;
   const long N = (long)NRG * NVI;
-  const int rid = phase_sorted_range(N, G, NVI, (int*)smem);
+  const int rid = __builtin_amdgcn_readfirstlane(phase_sorted_range(N, G, NVI, (int*)smem));
   const long beg = seg_beg(rid, N, G), end = seg_beg(rid + 1, N, G);
-  const int rbase = 256 * r32, swh = (((r32 & 3) << 2) | ((r32 >> 2) & 3)) ^ hh;
-  const TrAddr tr = make_tr(lane);
-  int seg = 0;
+  const FragBase fb0 = make_frag_base(lane);
+  const int ldb = a.ldw * 2;
+  const rsrc_t wsrc = make_rsrc(a.W, (long)a.V * ldb), bsrc = make_rsrc(a.bias, (long)a.V * 4);
+  const StageLane sl = make_stage_lane(lane, w, ldb);
+  const float c_l2 = a.inv_temp * LOG2E;
+  int seg = 0, par = 0;
   PV_STAMP_DECL
+  if (beg < end) {                               // the first tile of this workgroup's range (later ones ride in the stream)
+    char* buf = smem;
+    const int v0 = (int)(beg % NVI) * ITEM;
+    // (in the stream's order: sub-tile A, side data, sub-tile B -- the counted waits rely on it)
+    static_for<0, 8>([&](auto I) { stage_piece<decltype(I)::value>(wsrc, sl, ldb, v0 * ldb, buf, w); });
+    if (w == 0) lds_dma<4>(bsrc, (v0 + lane) * 4, buf + TILE_BYTES);
+    static_for<8, 16>([&](auto I) { stage_piece<decltype(I)::value>(wsrc, sl, ldb, v0 * ldb, buf, w); });
+    // the first second product of a segment multiplies the OTHER buffer's sub-tile B by zeros: it must hold finite numbers
+    for (int i = tid; i < SUB_BYTES / 16; i += 256) *(uint4*)(smem + BUF_BYTES + SUB_BYTES + 16 * i) = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
   for (long at = beg; at < end; ++seg) {
     const int rg = (int)(at / NVI), vi0 = (int)(at % NVI);
     const int nvi = (int)min((long)NVI - vi0, end - at);
@@ -243,95 +356,171 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
     bf16x8 hf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) hf[ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(hrow + 16 * ks));
-    const int y = a.target[min(t_mine, a.T - 1)];
+    int y = a.target[min(t_mine, a.T - 1)];
+    // The loads above must be waited for HERE: left alone, hipcc puts their vmcnt waits at the first uses, inside the item
+    // loop, where they run every iteration -- and vmcnt also counts the stream's LDS-DMA pieces, which the compiler does not
+    // know about: every item would drain the staging pipeline.  (An empty asm that reads the registers forces the wait.)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { u32x4 t_ = __builtin_bit_cast(u32x4, hf[ks]); asm volatile("" : "+v"(t_)); hf[ks] = __builtin_bit_cast(bf16x8, t_); }
+    asm volatile("" : "+v"(y));
     f32x16 O[NCB];
 #pragma unroll
     for (int c = 0; c < NCB; ++c)
 #pragma unroll
       for (int j = 0; j < 16; ++j) O[c][j] = 0.f;
-    float m_used = NEG_BIG, l_sum = 0.f, tl = 0.f;       // running maximum and target logit in log2 units
-    const float it_l2e = a.inv_temp * LOG2E;
-
-    auto stage = [&](int k) {
-      char* buf = smem + (k & 1) * BUF_BYTES;
-      const int v0 = (vi0 + k) * 32;
-      stage_tile(a.W, a.ldw, v0, a.V - 1, buf, w, lane);
-      if (w == 0)
-        __builtin_amdgcn_global_load_lds((gptr_t)(a.bias + min(v0 + r32, a.V - 1)), (lptr_t)(buf + TILE_BYTES), 4, 0, 0);
-    };
-    stage(0);
+    // running maximum (an INTEGER in log2 units: a rescale is then an exact power of two, also for probabilities that are
+    // already rounded to bf16), the sum of exponentials at that maximum, the target logit (log2 units)
+    float m_used = NEG_BIG, l_sum = 0.f, tl = 0.f;
+    bf16x8 pfA[2], pfB[2];                        // probabilities of sub-tile A (this item) / B (the item before)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pfB[0][e] = (__bf16)0.f; pfB[1][e] = (__bf16)0.f; }
     PV_STAMP(0)
-    for (int k = 0; k < nvi; ++k) {
-      __syncthreads();                       // tile k has landed (every wave waited for its own pieces), tile k-1 is done with
+    for (int k = 0; k < nvi; ++k, par ^= 1) {
+      half_tile_landed();       // sub-tile A and the side data of this item's tile; the other buffer's sub-tile A is free
       PV_STAMP(1)
-      if (k + 1 < nvi) stage(k + 1);
-      PV_STAMP(2)
-      const char* tile = smem + (k & 1) * BUF_BYTES;
+      const char* tile = smem + par * BUF_BYTES;
+      char* nbuf = smem + (par ^ 1) * BUF_BYTES;
       const float* bias_t = (const float*)(tile + TILE_BYTES);
-      const int v0 = (vi0 + k) * 32;
-      // ---- S^T block [32 v][32 t]: rows of W (LDS) x this wave's h fragments -----------------------------------------
-      f32x16 X;
+      const int v0 = (vi0 + k) * ITEM;
+      // the tile the stream stages while it computes: the next of this segment, else the first of the next segment (vocabulary
+      // row 0), else nothing (rows >= V are outside the descriptor: no fetch)
+      const int nv0 = k + 1 < nvi ? v0 + ITEM : (at < end ? 0 : NVI * ITEM);
+      const int noff = nv0 * ldb;
+      const int dprev = par ? -BUF_BYTES : BUF_BYTES;
+      bf16x8 f[8];
+      f32x16 XA, XB;
+      // the bias rides in as the initial accumulator: X = bias + W h^T needs no add pass (element j of a lane: row
+      // 8 (j >> 2) + 4 hh + (j & 3) of the sub-tile)
+      auto init_x = [&](f32x16& X, int sub) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) X[j] = 0.f;
-      first_product(tile, rbase, swh, hf, X);
-      PV_STAMP(3)
-      // ---- scaled logits in LOG2 units (exp is v_exp_f32 = 2^x: no multiply per element), running maximum (shared by the
-      // two lane halves of a row), target logit.  The column mask and the target pick are needed by one tile in hundreds:
-      // both sit behind wave-uniform branches.
-      float sv[16], mx = NEG_BIG;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 b4 = *(const f32x4*)(bias_t + 32 * sub + 8 * g4 + 4 * hh);
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 b4 = *(const f32x4*)(bias_t + 8 * g4 + 4 * hh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sv[4 * g4 + i] = (X[4 * g4 + i] + b4[i]) * it_l2e;
-      }
-      if (v0 + 32 > a.V) {                                 // the last tile: columns past V
-#pragma unroll
-        for (int j = 0; j < 16; ++j) sv[j] = v0 + 8 * (j >> 2) + 4 * hh + (j & 3) < a.V ? sv[j] : NEG_BIG;
-      }
-      if (__any((unsigned)(y - v0) < 32u)) {               // some row of this wave has its target in this tile
-#pragma unroll
-        for (int j = 0; j < 16; ++j) tl += v0 + 8 * (j >> 2) + 4 * hh + (j & 3) == y ? sv[j] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) mx = fmaxf(mx, sv[j]);
-      mx = fmaxf(mx, xor32(mx));
-      if (k == 0) {
-        m_used = mx;                                       // O and l are still zero: nothing to rescale
-      } else if (__builtin_expect(!__all(mx - m_used <= RESCALE_THR), 0)) {
-        // Rare (a row's maximum grew by more than RESCALE_THR since the segment's first tile): bring O and l to the new
-        // maximum.  The accumulators live in AGPRs; written as plain C++ the 256 multiplies pull them into VGPRs and the
-        // whole kernel spills (944 bytes of scratch per lane), so each one is read / scaled / written back in place.
-        // MFMA results need up to 18 wait states before v_accvgpr_read may see them; the assembler pads nothing inside asm.
-        const float m_new = fmaxf(m_used, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_used - m_new);
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-#pragma unroll
-        for (int c = 0; c < NCB; ++c)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            float tmp;
-            asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 1\n\tv_mul_f32 %1, %1, %2\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1"
-                         : "+a"(O[c][j]), "=&v"(tmp) : "v"(alpha));
-          }
-        asm volatile("s_nop 7" ::: "memory");
-        l_sum *= alpha;
-        m_used = m_new;
-      }
-      bf16x8 pf[2];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float p = __builtin_amdgcn_exp2f(sv[j] - m_used);   // <= 2^RESCALE_THR; masked columns: 2^(-1e30 - m) = 0
+          for (int i = 0; i < 4; ++i) X[4 * g4 + i] = b4[i];
+        }
+      };
+      init_x(XA, 0);
+      const FragBase fb{fb0.row + par * BUF_BYTES, fb0.col0 + par * BUF_BYTES, fb0.col1 + par * BUF_BYTES};
+      FragAddr fa;
+      static_for<0, DEPTH>([&](auto I) { f[decltype(I)::value & 7] = item_frag<decltype(I)::value>(smem, fb, dprev, fa); });
+      PV_SCHED_FENCE();
+
+      // one step of the stream: request the fragment of step i + DEPTH, run MFMA i, now and then issue a staging piece
+      auto mfma_step = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        using M = StepMap<i>;
+        if constexpr (i + DEPTH == 64) half_tile_landed();       // sub-tile B, ahead of the stream's first read of it
+        if constexpr (i + DEPTH < 128) f[(i + DEPTH) & 7] = item_frag<i + DEPTH>(smem, fb, dprev, fa);
+        if constexpr (M::phase == 0) mfma_v<(M::n == 0 ? 1 : 0)>(XA, f[i & 7], hf[M::ks]);
+        else if constexpr (M::phase == 1) mfma_a(O[M::c], f[i & 7], pfB[M::s]);
+        else if constexpr (M::phase == 2) mfma_v<(M::n == 0 ? 1 : 0)>(XB, f[i & 7], hf[M::ks]);
+        else mfma_a(O[M::c], f[i & 7], pfA[M::s]);
+#ifndef PV_ABL_NOSTAGE
+        if constexpr (PV_STAGE_AT(i & 63)) stage_piece<8 * (i >> 6) + (i & 63) / 7>(wsrc, sl, ldb, noff, nbuf, w);
+#endif
+        if constexpr (i == 54) {                                 // the next tile's bias slice, behind its sub-tile A
+          if (w == 0) lds_dma<4>(bsrc, (nv0 + lane) * 4, nbuf + TILE_BYTES);
+        }
+      };
+      // element J of an accumulator -> probability at the maximum in use, its row sum, bf16
+      auto exp_elem = [&](f32x16& X, bf16x8 (&pf)[2], auto J) {
+        constexpr int j = decltype(J)::value;
+        const float p = __builtin_amdgcn_exp2f(fmaf(X[j], c_l2, -m_used));   // <= 2^RESCALE_THR; masked columns: 2^(-huge) = 0
         l_sum += p;
         pf[j >> 3][j & 7] = (__bf16)p;
-      }
+      };
+      // what stands between a sub-tile's first product and its transform: no MFMA runs beside this section
+      auto decide = [&](f32x16& X, int vs, bf16x8 (&pending)[2], bool nothing_yet) {
+        mfma_v_done(X);
+        // ---- rare, wave-uniform: columns past V (the last tile) and the target pick (a row of this wave has its target here)
+        if (__builtin_expect(vs + 32 > a.V || __any((unsigned)(y - vs) < 32u), 0)) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int v = vs + 8 * (j >> 2) + 4 * hh + (j & 3);
+            X[j] = v < a.V ? X[j] : NEG_BIG;
+            tl += v == y ? X[j] * c_l2 : 0.f;
+          }
+        }
+        // ---- row maximum of the block (the two lane halves of a row share it), in log2 units -------------------------------
+        float m0 = fmaxf(fmaxf(X[0], X[1]), X[2]), m1 = fmaxf(fmaxf(X[3], X[4]), X[5]);
+        m0 = fmaxf(fmaxf(m0, X[6]), X[7]); m1 = fmaxf(fmaxf(m1, X[8]), X[9]);
+        m0 = fmaxf(fmaxf(m0, X[10]), X[11]); m1 = fmaxf(fmaxf(m1, X[12]), X[13]);
+        const float mx = max_xor32(fmaxf(fmaxf(fmaxf(m0, X[14]), X[15]), m1)) * c_l2;
+        // ---- rare, wave-uniform: a row's maximum outgrew the one in use by more than RESCALE_THR -> bring O, l and the
+        // probabilities that are exponentiated but not yet multiplied in (`pending`: the sub-tile before) to a new one.  The
+        // maximum in use is an INTEGER, so the factor is an exact power of two, also for the bf16 probabilities.  The
+        // accumulators live in AGPRs; written as plain C++ the 256 multiplies pull them into VGPRs and the whole kernel spills,
+        // so each one is read / scaled / written back in place.  MFMA results need up to 18 wait states before
+        // v_accvgpr_read may see them; the assembler pads nothing inside asm.
+        if (__builtin_expect(!__all(mx - m_used <= RESCALE_THR), 0)) {
+          const float m_new = ceilf(fmaxf(m_used, mx));
+          const float alpha = __builtin_amdgcn_exp2f(m_used - m_new);
+          if (!nothing_yet) {                                  // (the segment's first block: O, l and `pending` are zero)
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+              for (int j = 0; j < 16; ++j) {
+                float tmp;
+                asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 1\n\tv_mul_f32 %1, %1, %2\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1"
+                             : "+a"(O[c][j]), "=&v"(tmp) : "v"(alpha));
+              }
+            asm volatile("s_nop 7" ::: "memory");
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) pending[s2][e] = (__bf16)((float)pending[s2][e] * alpha);
+          }
+          l_sum *= alpha;
+          m_used = m_new;
+        }
+      };
+
+      // ---- steps 0..31: first product of A ------------------------------------------------------------------------------------
+      static_for<0, 32>([&](auto I) { mfma_step(I); PV_SCHED_FENCE(); });
+      PV_STAMP(2)
+      decide(XA, v0, pfB, k == 0);
+      PV_STAMP(3)
+      // ---- steps 32..63: second product of the sub-tile before | transform of A; B's bias into its accumulator near the end ----
+      static_for<32, 64>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        mfma_step(I);
+        if constexpr ((i & 1) == 0) exp_elem(XA, pfA, std::integral_constant<int, (i - 32) / 2>{});
+        if constexpr (i == 63) init_x(XB, 1);
+        PV_SCHED_FENCE();
+      });
       PV_STAMP(4)
-      // ---- O^T[hc][t] += W^T[hc][v] P^T[v][t]: columns of the same W tile x the probabilities, register to register ----
-      second_product<true>(tile, tr, 0, pf[0], O);
-      second_product<true>(tile, tr, 1, pf[1], O);
-      PV_STAMP(5)
+      // ---- steps 64..95: first product of B ------------------------------------------------------------------------------------
+      static_for<64, 96>([&](auto I) { mfma_step(I); PV_SCHED_FENCE(); });
+      PV_STAMP(2)
+      decide(XB, v0 + 32, pfA, false);
+      PV_STAMP(3)
+      // ---- steps 96..127: second product of A | transform of B ------------------------------------------------------------------
+      static_for<96, 128>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        mfma_step(I);
+        if constexpr ((i & 1) == 0) exp_elem(XB, pfB, std::integral_constant<int, (i - 96) / 2>{});
+        PV_SCHED_FENCE();
+      });
+      PV_STAMP(4)
     }
+    // ---- the segment's last sub-tile (B of the last item's buffer) has not been multiplied in yet ---------------------------
+    {
+      const int lpar = par ^ 1;
+      const FragBase fbl{fb0.row + lpar * BUF_BYTES, fb0.col0 + lpar * BUF_BYTES, fb0.col1 + lpar * BUF_BYTES};
+      FragAddr fa;
+      bf16x8 f[8];
+      static_for<0, DEPTH>([&](auto I) { f[decltype(I)::value & 7] = tail_frag<decltype(I)::value>(smem, fbl, fa); });
+      static_for<0, 32>([&](auto I) {
+        constexpr int n = decltype(I)::value;
+        if constexpr (n + DEPTH < 32) f[(n + DEPTH) & 7] = tail_frag<n + DEPTH>(smem, fbl, fa);
+        mfma_a(O[4 * (n & 3) + ((n & 15) >> 2)], f[n & 7], pfB[n >> 4]);
+        PV_SCHED_FENCE();
+      });
+    }
+    PV_STAMP(5)
     // ---- partial result of this segment: O^T as [hc][t] (128-byte runs), (m, l, target logit) per row -----------------
+    mfma_a_done();
     const long slab = (long)rid * a.max_seg + seg;
     float* o = a.o_slab + slab * HD * UNIT + 32 * w + r32;
 #pragma unroll
@@ -341,7 +530,6 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
     l_sum += xor32(l_sum);
     tl += xor32(tl);
     if (hh == 0) a.stats[slab * UNIT + 32 * w + r32] = make_float4(m_used * LN2, l_sum, tl * LN2, 0.f);
-    __syncthreads();                           // the ring restarts with the next segment
     PV_STAMP(6)
   }
   PV_STAMP_FLUSH(0)
@@ -367,7 +555,7 @@ __global__ __launch_bounds__(256) void vocab_fwd_combine_kernel(FwdCombineArgs a
   __shared__ float invL[UNIT];
   const int rg = blockIdx.x, hc0 = blockIdx.y * 32, tid = threadIdx.x;
   const int nlive = a.live ? min(a.T, *a.live) : a.T;
-  const int NVI = (a.V + 31) / 32, NRG = (nlive + UNIT - 1) / UNIT;
+  const int NVI = (a.V + ITEM - 1) / ITEM, NRG = (nlive + UNIT - 1) / UNIT;
   if (rg >= NRG) {                             // rows nobody computed (ignored tokens behind the live ones): zeros
     for (int i = tid; i < UNIT * 32; i += 256) {
       const int t = rg * UNIT + (i >> 5);
@@ -462,109 +650,178 @@ struct DwArgs {
 
 __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r32 = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x;
   const int nlive = a.live ? min(a.T, *a.live) : a.T;
-  const int NCT = (a.V + UNIT - 1) / UNIT, NRI = (nlive + 31) / 32;
+  const int NCT = (a.V + UNIT - 1) / UNIT, NRI = (nlive + ITEM - 1) / ITEM;
   const long N = (long)NCT * NRI;
-  const int rid = phase_sorted_range(N, G, NRI, (int*)smem);
+  const int rid = __builtin_amdgcn_readfirstlane(phase_sorted_range(N, G, NRI, (int*)smem));
   const long beg = seg_beg(rid, N, G), end = seg_beg(rid + 1, N, G);
-  const int rbase = 256 * r32, swh = (((r32 & 3) << 2) | ((r32 >> 2) & 3)) ^ hh;
-  const TrAddr tr = make_tr(lane);
-  int seg = 0;
+  const FragBase fb0 = make_frag_base(lane);
+  const int ldb = a.ldh * 2;
+  const rsrc_t hsrc = make_rsrc(a.h, (long)a.T * ldb);
+  // side data of a tile: lse[64] | gs[64] | target[64], one 4-byte piece each (waves 0, 1, 2); rows >= T arrive as zeros
+  const rsrc_t asrc = make_rsrc(w == 0 ? (const void*)a.lse : w == 1 ? (const void*)a.gs : (const void*)a.target, (long)a.T * 4);
+  const StageLane sl = make_stage_lane(lane, w, ldb);
+  const float c_l2 = a.inv_temp * LOG2E;
+  int seg = 0, par = 0;
   PV_STAMP_DECL
+  if (beg < end) {
+    char* buf = smem;
+    const int t0 = (int)(beg % NRI) * ITEM;
+    static_for<0, 8>([&](auto I) { stage_piece<decltype(I)::value>(hsrc, sl, ldb, t0 * ldb, buf, w); });
+    if (w < 3) lds_dma<4>(asrc, (t0 + lane) * 4, buf + TILE_BYTES + 256 * w);
+    static_for<8, 16>([&](auto I) { stage_piece<decltype(I)::value>(hsrc, sl, ldb, t0 * ldb, buf, w); });
+    // the first second product of a segment multiplies the OTHER buffer's sub-tile B by zeros: it must hold finite numbers
+    for (int i = tid; i < SUB_BYTES / 16; i += 256) *(uint4*)(smem + BUF_BYTES + SUB_BYTES + 16 * i) = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
   for (long at = beg; at < end; ++seg) {
     const int ct = (int)(at / NRI), ri0 = (int)(at % NRI);
     const int nri = (int)min((long)NRI - ri0, end - at);
     at += nri;
     // ---- this wave's 32 rows of W as 32 B-operand fragments ------------------------------------------------------------
-    const int v_mine = ct * UNIT + 32 * w + r32;
-    const bool v_ok = v_mine < a.V;
+    const int vbase = ct * UNIT + 32 * w, v_mine = vbase + r32;
     const bf16_t* wrow = a.W + (long)min(v_mine, a.V - 1) * a.ldw + 8 * hh;
     bf16x8 wf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(wrow + 16 * ks));
-    const float bias_v = a.bias[min(v_mine, a.V - 1)];
+    float cb = a.bias[min(v_mine, a.V - 1)] * c_l2;
+    // (waited for here, not at their first uses inside the item loop: see the forward kernel)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { u32x4 t_ = __builtin_bit_cast(u32x4, wf[ks]); asm volatile("" : "+v"(t_)); wf[ks] = __builtin_bit_cast(bf16x8, t_); }
+    asm volatile("" : "+v"(cb));
     f32x16 Z[NCB];
 #pragma unroll
     for (int c = 0; c < NCB; ++c)
 #pragma unroll
       for (int j = 0; j < 16; ++j) Z[c][j] = 0.f;
     float bsum = 0.f;
-    const float it_l2e = a.inv_temp * LOG2E, cb = bias_v * it_l2e;
-
-    auto stage = [&](int k) {
-      char* buf = smem + (k & 1) * BUF_BYTES;
-      const int t0 = (ri0 + k) * 32;
-      stage_tile(a.h, a.ldh, t0, a.T - 1, buf, w, lane);
-      const int t = min(t0 + r32, a.T - 1);
-      if (w == 0)        // aux: lse[32] | gs[32] | target[32]
-        __builtin_amdgcn_global_load_lds((gptr_t)(hh ? a.gs + t : a.lse + t), (lptr_t)(buf + TILE_BYTES), 4, 0, 0);
-      if (w == 1)
-        __builtin_amdgcn_global_load_lds((gptr_t)(a.target + t), (lptr_t)(buf + TILE_BYTES + 256), 4, 0, 0);
-    };
-    stage(0);
+    bf16x8 pfA[2], pfB[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pfB[0][e] = (__bf16)0.f; pfB[1][e] = (__bf16)0.f; }
     PV_STAMP(0)
-    for (int k = 0; k < nri; ++k) {
-      __syncthreads();
+    for (int k = 0; k < nri; ++k, par ^= 1) {
+      half_tile_landed();
       PV_STAMP(1)
-      if (k + 1 < nri) stage(k + 1);
-      PV_STAMP(2)
-      const char* tile = smem + (k & 1) * BUF_BYTES;
-      const float* lse_t = (const float*)(tile + TILE_BYTES);
-      const float* gs_t = lse_t + 32;
-      const int* tgt_t = (const int*)(tile + TILE_BYTES + 256);
-      const int t0 = (ri0 + k) * 32;
-      // ---- S block [32 t][32 v]: rows of h (LDS) x this wave's W fragments ---------------------------------------------
-      f32x16 X;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) X[j] = 0.f;
-      first_product(tile, rbase, swh, wf, X);
-      PV_STAMP(3)
-      // ---- P = gs (softmax - onehot); its column sums are the bias gradient.  exp(s - lse) = 2^(X it_l2e + cb - lse log2e).
-      // The row mask (rows past the live count: the last item only) and the onehot (a target inside this wave's 32 columns:
-      // one item in twenty) sit behind a wave-uniform branch.  Columns past V need no mask: nothing reads their Z rows.
-      bf16x8 pf[2];
-      const bool edge = t0 + 32 > nlive;
-      const bool hit = __any((unsigned)(tgt_t[r32] - (ct * UNIT + 32 * w)) < 32u);
-      if (__builtin_expect(edge || hit, 0)) {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 l4 = *(const f32x4*)(lse_t + 8 * g4 + 4 * hh);
-          const f32x4 g_4 = *(const f32x4*)(gs_t + 8 * g4 + 4 * hh);
-          const int4 y4 = *(const int4*)(tgt_t + 8 * g4 + 4 * hh);
-          const int yy[4] = {y4.x, y4.y, y4.z, y4.w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int tloc = 8 * g4 + 4 * hh + i;
-            const float gsv = t0 + tloc < nlive ? g_4[i] * a.inv_temp : 0.f;
-            // (the clamp keeps 2^x finite where lse is stale, e.g. the 0 of a dead row: its gsv is 0 and 0 * inf is NaN)
-            float p = __builtin_amdgcn_exp2f(fminf(fmaf(X[4 * g4 + i], it_l2e, fmaf(l4[i], -LOG2E, cb)), 126.f));
-            p = (yy[i] == v_mine ? p - 1.f : p) * gsv;
-            bsum += p;
-            pf[(4 * g4 + i) >> 3][(4 * g4 + i) & 7] = (__bf16)p;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 l4 = *(const f32x4*)(lse_t + 8 * g4 + 4 * hh);
-          const f32x4 g_4 = *(const f32x4*)(gs_t + 8 * g4 + 4 * hh);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float p = __builtin_amdgcn_exp2f(fminf(fmaf(X[4 * g4 + i], it_l2e, fmaf(l4[i], -LOG2E, cb)), 126.f)) *
-                            (g_4[i] * a.inv_temp);
-            bsum += p;
-            pf[(4 * g4 + i) >> 3][(4 * g4 + i) & 7] = (__bf16)p;
-          }
-        }
+      const char* tile = smem + par * BUF_BYTES;
+      char* nbuf = smem + (par ^ 1) * BUF_BYTES;
+      float* lse_t = (float*)(tile + TILE_BYTES);
+      float* gs_t = lse_t + 64;
+      const int* tgt_t = (const int*)(tile + TILE_BYTES + 512);
+      const int t0 = (ri0 + k) * ITEM;
+      const int nt0 = k + 1 < nri ? t0 + ITEM : (at < end ? 0 : NRI * ITEM);
+      const int noff = nt0 * ldb;
+      const int dprev = par ? -BUF_BYTES : BUF_BYTES;
+      // rows past the live count (the last item of a unit): their gs is zeroed in the tile's side data, so P = 0 exactly
+      // (every wave stores the same zeros ahead of its own reads; 2^x is clamped to 1, so nothing is infinite)
+      if (__builtin_expect(t0 + ITEM > nlive, 0)) {
+        if (t0 + lane >= nlive) gs_t[lane] = 0.f;
       }
-      // ---- Z[v][hc] += P^T[v][t] h[t][hc]: the probabilities x columns of the same h tile -----------------------------
+      bf16x8 f[8];
+      f32x16 X;
+      const FragBase fb{fb0.row + par * BUF_BYTES, fb0.col0 + par * BUF_BYTES, fb0.col1 + par * BUF_BYTES};
+      FragAddr fa;
+      static_for<0, DEPTH>([&](auto I) { f[decltype(I)::value & 7] = item_frag<decltype(I)::value>(smem, fb, dprev, fa); });
+      PV_SCHED_FENCE();
+
+      auto mfma_step = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        using M = StepMap<i>;
+        if constexpr (i + DEPTH == 64) half_tile_landed();
+        if constexpr (i + DEPTH < 128) f[(i + DEPTH) & 7] = item_frag<i + DEPTH>(smem, fb, dprev, fa);
+        if constexpr (M::first) mfma_v<(M::n == 0 ? 2 : 0)>(X, f[i & 7], wf[M::ks]);
+        else if constexpr (M::phase == 1) mfma_a(Z[M::c], pfB[M::s], f[i & 7]);
+        else mfma_a(Z[M::c], pfA[M::s], f[i & 7]);
+#ifndef PV_ABL_NOSTAGE
+        if constexpr (PV_STAGE_AT(i & 63)) stage_piece<8 * (i >> 6) + (i & 63) / 7>(hsrc, sl, ldb, noff, nbuf, w);
+#endif
+        if constexpr (i == 54) {
+          if (w < 3) lds_dma<4>(asrc, (nt0 + lane) * 4, nbuf + TILE_BYTES + 256 * w);
+        }
+      };
+      // P = gs (softmax - onehot) for element J of a sub-tile's accumulator, in two halves (one per MFMA step): 2^z,
+      // z = X c + cb - lse log2e, with the output clamped to [0, 1] by the instruction's own modifier (a dead row's stale lse
+      // must not give infinity: its gs is 0); then q = p g - [y == v] g as one compare, one select and one fma.  Column sums of P
+      // are the bias gradient.  inv_temp is applied by the reduce kernel.  Columns past V need no mask: nothing reads their Z rows.
+      // The onehot is branch-free: with word frequencies as skewed as a vocabulary's, the waves that own the frequent tokens'
+      // columns meet a target in every tile, and a slower variant for them would be the kernel's tail (stream-K gives every
+      // workgroup the same number of items); two variants of the stream in one kernel also made hipcc spill 360 registers.
+      f32x4 l4, g4;
+      int4 y4;
+      float p_half;
+      auto elem_a = [&](int sub, auto J) {
+        constexpr int j = decltype(J)::value;
+#ifndef PV_ABL_NOEXP
+        if constexpr ((j & 3) == 0) {
+          l4 = *(const f32x4*)(lse_t + 32 * sub + 2 * j + 4 * hh);
+          g4 = *(const f32x4*)(gs_t + 32 * sub + 2 * j + 4 * hh);
+          y4 = *(const int4*)(tgt_t + 32 * sub + 2 * j + 4 * hh);
+        }
+        const float z = fmaf(X[j], c_l2, fmaf(l4[j & 3], -LOG2E, cb));
+        float pe;                                           // (asm operands cannot name a captured variable)
+        asm("v_exp_f32_e64 %0, %1 clamp" : "=v"(pe) : "v"(z));
+        p_half = pe;
+#else
+        p_half = X[j];
+#endif
+      };
+      auto elem_b = [&](bf16x8 (&pf)[2], auto J) {
+        constexpr int j = decltype(J)::value;
+#ifndef PV_ABL_NOEXP
+        const int yy = (j & 3) == 0 ? y4.x : (j & 3) == 1 ? y4.y : (j & 3) == 2 ? y4.z : y4.w;
+        const float g = g4[j & 3];
+        const float q = fmaf(p_half, g, yy == v_mine ? -g : 0.f);
+#else
+        const float q = p_half;
+#endif
+        bsum += q;
+        pf[j >> 3][j & 7] = (__bf16)q;
+      };
+      // ---- steps 0..31: first product of A; 32..63: second product of the sub-tile before | transform of A --------------------
+      static_for<0, 32>([&](auto I) { mfma_step(I); PV_SCHED_FENCE(); });
+      PV_STAMP(2)
+      mfma_v_done(X);
+      PV_STAMP(3)
+      static_for<32, 64>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        mfma_step(I);
+        if constexpr ((i & 1) == 0) elem_a(0, std::integral_constant<int, (i - 32) / 2>{});
+        else elem_b(pfA, std::integral_constant<int, (i - 32) / 2>{});
+        PV_SCHED_FENCE();
+      });
       PV_STAMP(4)
-      second_product<false>(tile, tr, 0, pf[0], Z);
-      second_product<false>(tile, tr, 1, pf[1], Z);
-      PV_STAMP(5)
+      // ---- steps 64..95: first product of B; 96..127: second product of A | transform of B ------------------------------------
+      static_for<64, 96>([&](auto I) { mfma_step(I); PV_SCHED_FENCE(); });
+      PV_STAMP(2)
+      mfma_v_done(X);
+      PV_STAMP(3)
+      static_for<96, 128>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        mfma_step(I);
+        if constexpr ((i & 1) == 0) elem_a(1, std::integral_constant<int, (i - 96) / 2>{});
+        else elem_b(pfB, std::integral_constant<int, (i - 96) / 2>{});
+        PV_SCHED_FENCE();
+      });
+      PV_STAMP(4)
     }
+    // ---- the segment's last sub-tile (B of the last item's buffer) has not been multiplied in yet ---------------------------
+    {
+      const int lpar = par ^ 1;
+      const FragBase fbl{fb0.row + lpar * BUF_BYTES, fb0.col0 + lpar * BUF_BYTES, fb0.col1 + lpar * BUF_BYTES};
+      FragAddr fa;
+      bf16x8 f[8];
+      static_for<0, DEPTH>([&](auto I) { f[decltype(I)::value & 7] = tail_frag<decltype(I)::value>(smem, fbl, fa); });
+      static_for<0, 32>([&](auto I) {
+        constexpr int n = decltype(I)::value;
+        if constexpr (n + DEPTH < 32) f[(n + DEPTH) & 7] = tail_frag<n + DEPTH>(smem, fbl, fa);
+        mfma_a(Z[4 * (n & 3) + ((n & 15) >> 2)], pfB[n >> 4], f[n & 7]);
+        PV_SCHED_FENCE();
+      });
+    }
+    PV_STAMP(5)
+    mfma_a_done();
     const long slab = (long)rid * a.max_seg + seg;
     float* z = a.z_slab + slab * UNIT * HD + r32;
 #pragma unroll
@@ -573,7 +830,6 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
       for (int j = 0; j < 16; ++j) z[(long)(32 * w + (j & 3) + 8 * (j >> 2) + 4 * hh) * HD + 32 * c] = Z[c][j];
     bsum += xor32(bsum);
     if (hh == 0) a.b_slab[slab * UNIT + 32 * w + r32] = bsum;
-    __syncthreads();
     PV_STAMP(6)
   }
   PV_STAMP_FLUSH(1)
@@ -584,6 +840,7 @@ struct DwReduceArgs {
   const float* b_slab;
   const int* live;
   int T, V, max_seg, G, lddw, accumulate, accumulate_bias;
+  float scale;          // inv_temp: d(logit)/d(W h + b)
   float* dW;            // [V][lddw]
   float* dbias;         // [V]
 };
@@ -591,7 +848,7 @@ struct DwReduceArgs {
 __global__ __launch_bounds__(256) void vocab_dw_reduce_kernel(DwReduceArgs a) {
   const int ct = blockIdx.x, tid = threadIdx.x;
   const int nlive = a.live ? min(a.T, *a.live) : a.T;
-  const int NCT = (a.V + UNIT - 1) / UNIT, NRI = (nlive + 31) / 32;
+  const int NCT = (a.V + UNIT - 1) / UNIT, NRI = (nlive + ITEM - 1) / ITEM;
   const long N = (long)NCT * NRI, x0 = (long)ct * NRI, x1 = x0 + NRI;
   int w0 = 0, w1 = 0;
   if (N > 0) {
@@ -615,6 +872,7 @@ __global__ __launch_bounds__(256) void vocab_dw_reduce_kernel(DwReduceArgs a) {
       if (sl >= 0) acc += *(const f32x4*)(a.z_slab + (sl * UNIT + vl) * HD + c4);
     }
     f32x4* dst = (f32x4*)(a.dW + (long)v * a.lddw + c4);
+    acc *= a.scale;
     *dst = a.accumulate ? *dst + acc : acc;
   }
   if (tid < 16) {
@@ -625,6 +883,7 @@ __global__ __launch_bounds__(256) void vocab_dw_reduce_kernel(DwReduceArgs a) {
         const long sl = slab_of(w);
         if (sl >= 0) acc += a.b_slab[sl * UNIT + vl];
       }
+      acc *= a.scale;
       a.dbias[v] = a.accumulate_bias ? a.dbias[v] + acc : acc;
     }
   }
@@ -687,7 +946,7 @@ int grid_wgs() {
 }
 
 int max_seg_fwd(int T, int V, int G) {
-  const long NVI = (V + 31) / 32, NRG = (T + UNIT - 1) / UNIT;
+  const long NVI = (V + ITEM - 1) / ITEM, NRG = (T + UNIT - 1) / UNIT;
   const long per = (NRG * NVI + G - 1) / G;
   return (int)(per / NVI) + 2;
 }
@@ -698,6 +957,8 @@ int check_common(const void* h, int ldh, const void* W, int ldw, int T, int V, i
   PV_REQUIRE(H == HD, "%s: built for H = %d (got %d); use the tile-GEMM path", who, HD, H);
   PV_REQUIRE(ldh >= HD && ldw >= HD && ldh % 8 == 0 && ldw % 8 == 0, "%s: leading dimensions must be multiples of 8 and >= %d", who, HD);
   PV_REQUIRE(((uintptr_t)h & 15) == 0 && ((uintptr_t)W & 15) == 0, "%s: operands must be 16-byte aligned", who);
+  PV_REQUIRE(((long)T + 2 * ITEM) * ldh * 2 < 0x7fffffffL && ((long)V + 2 * ITEM) * ldw * 2 < 0x7fffffffL,
+             "%s: an operand of 2 GiB or more (buffer offsets are 32-bit)", who);
   return PV_OK;
 }
 
@@ -789,7 +1050,7 @@ int pv_vocab_fused_dw_wgs(const void* h, int ldh, const void* W, int ldw, const 
   DwArgs a{(const bf16_t*)h, (const bf16_t*)W, bias, target32, lse, gscale, live_rows, T, V, ldh, ldw, ms, inv_temp, z_slab, b_slab};
   hipLaunchKernelGGL(vocab_dw_kernel, dim3(G), dim3(256), SMEM_BYTES, st, a);
   PV_LAUNCH_CHECK("vocab_dw_kernel");
-  DwReduceArgs r{z_slab, b_slab, live_rows, T, V, ms, G, lddw, accumulate, accumulate_bias, dW, dbias};
+  DwReduceArgs r{z_slab, b_slab, live_rows, T, V, ms, G, lddw, accumulate, accumulate_bias, inv_temp, dW, dbias};
   hipLaunchKernelGGL(vocab_dw_reduce_kernel, dim3(cdiv(V, UNIT), UNIT / 16), dim3(256), 0, st, r);
   PV_LAUNCH_CHECK("vocab_dw_reduce_kernel");
   return PV_OK;

@@ -120,13 +120,19 @@ class FlatAdam(object):
         8-byte copy {skip, lr_eff} into one of 8 page-locked slots, ordered behind the step on the current stream.
         -> handle with .ready() (poll), .skipped() (waits for the copy) and .lr()."""
         if len(self._flag_ring) < 8:
-            self._flag_ring.append((torch.empty(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event()))
-        buf, ev = self._flag_ring[self._flag_slot % len(self._flag_ring)]
+            self._flag_ring.append([torch.empty(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event(), None])
+        slot = self._flag_ring[self._flag_slot % len(self._flag_ring)]
         self._flag_slot += 1
-        ev.synchronize()                                      # the slot's previous copy (8 steps ago) has landed
+        buf, ev, last = slot
+        if last is not None:
+            # The handle given out 8 steps ago may not have been read yet (a host that runs ahead of the device keeps
+            # unread handles): it takes its value NOW -- waiting for its copy -- before the event is re-armed and the
+            # buffer overwritten, so every handle reports its own step whenever it is read.
+            last._read()
         buf.copy_(self.state[28:36].view(torch.int32), non_blocking=True)
         ev.record()
-        return SkipFlag(buf, ev)
+        slot[2] = flag = SkipFlag(buf, ev)
+        return flag
 
     def state_dict_host(self):
         """Copy the device-side guard state to the host (synchronises; logging / tests only)."""

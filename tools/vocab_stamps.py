@@ -49,8 +49,9 @@ def timed(f, n=20):
 print("T = %d live rows; fwd %.1f us, dw %.1f us per call (pair of launches each)" % (T, timed(fwd), timed(dw)))
 if not hasattr(lib, "pv_vocab_stamps_copy"):
     sys.exit(0)
-names = ["prologue (stationary loads, stage 0)", "barrier", "stage issue", "first product", "softmax", "second product",
-         "epilogue (slab stores)", "-"]
+names = ["prologue (stationary loads, first tile)", "barrier (tile landed)", "first products (2 x 32 steps + staging)",
+         "transform, first half (no MFMA beside it)", "second products k-step 0 (2 x 16 steps + transform)",
+         "second products k-step 1 (2 x 16 steps)", "epilogue (slab stores)", "-"]
 buf = np.zeros((2, 256, 4, 8), dtype=np.uint64)
 lib.pv_vocab_stamps_copy.restype = C.c_int
 lib.pv_vocab_stamps_copy.argtypes = [C.c_void_p, C.c_size_t]
@@ -59,7 +60,7 @@ assert lib.pv_vocab_stamps_copy(buf.ctypes.data, buf.nbytes) == 0
 for k, kn in enumerate(("vocab_fwd_dh_kernel", "vocab_dw_kernel")):
     x = buf[k].astype(np.float64)            # [wg][wave][section]
     tot = x.sum(-1)
-    items = (T + 127) // 128 * ((V + 31) // 32) / 256 if k == 0 else (V + 127) // 128 * ((T + 31) // 32) / 256
+    items = (T + 127) // 128 * ((V + 63) // 64) / 256 if k == 0 else (V + 127) // 128 * ((T + 63) // 64) / 256
     print("%s: cycles per wave: median %.0f, min %.0f, max %.0f; %.1f items per workgroup -> %.0f cycles per item" %
           (kn, np.median(tot), tot.min(), tot.max(), items, np.median(tot) / items))
     for i, n in enumerate(names[:7]):
