@@ -188,9 +188,17 @@ int pv_logsoftmax_bwd_bf16(const float* logp, const float* dlogp, int T, int V, 
  * reverse != 0 walks time backwards (bidirectional encoders).  lengths (optional, int32 [B]): packed-sequence
  * semantics of encoders.py:55-65 -- row b keeps its state at time steps t >= lengths[b] (the caller zeroes those
  * output rows).
- * max_wgs <= 0 means "one workgroup per CU of the current device". */
+ * max_wgs <= 0 means "one workgroup per CU of the current device".
+ * Limit (PV_ERR_LIMIT): B <= 2720 (the sync buffer's layout: error word and arrival counters in front of the flags). */
 int pv_gru_geometry(int B, int H, int* Hk, int* K3, int* Bpad, int* NG);   /* host out-params */
 size_t pv_gru_sync_bytes(int B);
+/* *flag = 1 if a bounded wait of ANY pv_gru_* / pv_lstm_* launch has timed out since the library was loaded (or since the
+ * last call with clear != 0): a process-level word that no launch resets.  A launch's own error word (sync word NG) is
+ * zeroed when the launch starts, so under HIP-graph replay only this one survives until somebody looks.  Synchronises the
+ * device.  pv_rnn_sync_error_inject sets the word from a one-thread kernel on `stream` (capturable; tests of the reporting
+ * path).  No counterpart in the reference (cuDNN's recurrence cannot time out). */
+int pv_rnn_sync_error(int* flag, int clear);
+int pv_rnn_sync_error_inject(void* stream);
 int pv_gru_fwd(const float* xprojT, long ldx, const void* whh_bf16, const float* bhh, const float* h0,
                const int* lengths, int L, int B, int H, int reverse, void* hseq_bf16, float* gsaveT, float* hall,
                float* hn, void* sync, int max_wgs, void* stream);

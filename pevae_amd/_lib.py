@@ -70,6 +70,8 @@ SIGNATURES = {
     "pv_logsoftmax_bwd_bf16": (i32, [vp, vp, i32, i32, f32, vp, i32, vp, vp]),
     "pv_gru_geometry": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "pv_gru_sync_bytes": (sz, [i32]),
+    "pv_rnn_sync_error": (i32, [C.POINTER(i32), i32]),
+    "pv_rnn_sync_error_inject": (i32, [vp]),
     "pv_gru_fwd": (i32, [vp, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     "pv_gru_bwd": (i32, [vp, lng, lng, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pv_block_layout": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),

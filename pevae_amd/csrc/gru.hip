@@ -41,6 +41,11 @@ typedef unsigned int u32;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int AUX_SC1 = 16;                 // cache-policy bits of the raw buffer builtins: sc1
 
+// Sticky, process-level: set beside a launch's own error word whenever a bounded wait gives up, and cleared by no launch.
+// A launch zeroes ITS sync buffer (error word included) when it starts, so under HIP-graph replay a step that timed out
+// is wiped by the next replay before anybody has looked; this word survives (pv_rnn_sync_error reads it).
+__device__ unsigned g_rnn_err;
+
 __device__ __forceinline__ u32 ld_relaxed(const u32* p) {      // global_load_dword ... sc1
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -72,6 +77,7 @@ __device__ __forceinline__ bool wait_ge(const u32* ctr, u32 want, u32* err) {
       if (ld_relaxed(err) != 0) return false;
       if (wall_clock64() - t0 > SPIN_LIMIT) {
         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g_rnn_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
     }
@@ -92,7 +98,10 @@ __device__ __forceinline__ bool wait_flags_ge(const u32* flags, int S, u32 want,
     if ((it & 15) == 15) {
       if (ld_relaxed(err) != 0) return false;
       if (wall_clock64() - t0 > SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&g_rnn_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return false;
       }
     }
@@ -916,6 +925,12 @@ int xcd_map(int G, int S, int cap) {
 int rnn_geometry(int ngt, int B, int H, int* Hk, int* KG, int* Bpad, int* NG) {
   PV_REQUIRE(B > 0 && H > 0 && H % 16 == 0, "pv_gru/pv_lstm: hidden size %d must be a positive multiple of 16", H);
   PV_REQUIRE(H <= 1024, "pv_gru/pv_lstm: hidden size %d > 1024 not supported (LDS-resident weight slice)", H);
+  // sync buffer layout: word NG = error flag, then up to 2 NG arrival counters, and the per-slice arrival flags from word
+  // FLAGS_AT: beyond this batch the error word / counters would run into the flags
+  if (3 * cdiv(B, ROWS) + 1 > FLAGS_AT) {
+    pv_set_error("pv_gru/pv_lstm: batch %d exceeds the sync buffer layout's limit of %d rows", B, (FLAGS_AT - 1) / 3 * ROWS);
+    return PV_ERR_LIMIT;
+  }
   if (Hk) *Hk = round_up(H, 64);      // also the K of GEMMs that consume the bf16 state sequence
   if (KG) *KG = round_up(ngt * H, 64);
   if (Bpad) *Bpad = round_up(B, ROWS);
@@ -929,6 +944,31 @@ extern "C" {
 
 int pv_gru_geometry(int B, int H, int* Hk, int* K3, int* Bpad, int* NG) { return rnn_geometry(3, B, H, Hk, K3, Bpad, NG); }
 int pv_lstm_geometry(int B, int H, int* Hk, int* K4, int* Bpad, int* NG) { return rnn_geometry(4, B, H, Hk, K4, Bpad, NG); }
+
+}  // extern "C"
+namespace {
+__global__ void rnn_err_inject_kernel() { __hip_atomic_store(&g_rnn_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}  // namespace
+extern "C" {
+
+int pv_rnn_sync_error_inject(void* stream) {
+  hipLaunchKernelGGL(rnn_err_inject_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream);
+  PV_LAUNCH_CHECK("rnn_err_inject_kernel");
+  return PV_OK;
+}
+
+int pv_rnn_sync_error(int* flag, int clear) {
+  PV_REQUIRE(flag, "pv_rnn_sync_error: null argument");
+  unsigned v = 0;
+  PV_HIP(hipDeviceSynchronize());
+  PV_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_rnn_err), sizeof(v)));
+  *flag = (int)v;
+  if (v && clear) {
+    const unsigned zero = 0;
+    PV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rnn_err), &zero, sizeof(zero)));
+  }
+  return PV_OK;
+}
 
 size_t pv_gru_sync_bytes(int B) {
   // [NG]: unused, [NG]: error flag, then up to 2*NG arrival counters (diagnostic build: stamps from word 64); from word

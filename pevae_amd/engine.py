@@ -169,7 +169,10 @@ class GraphedStep(object):
                 self.pool = graph.pool()
             entry = self.graphs[key] = (graph, static, out)
             from . import ops
-            ops.LAST_GRU_SYNC.clear()                      # (sync words of captured launches are rewritten by every replay)
+            # The sync buffers of captured launches are rewritten by every replay, so their error words say nothing about
+            # earlier replays: timed-out waits of replayed recurrence launches are reported through the library's sticky
+            # word instead (pv_rnn_sync_error, read by ops.gru_check_all at every evaluation).
+            ops.LAST_GRU_SYNC.clear()
         graph, static, out = entry
         for k, v in tensors.items():
             static[k].copy_(v, non_blocking=True)
@@ -179,7 +182,8 @@ class GraphedStep(object):
 
 def _check_recurrence():
     """A timed-out wait inside a persistent GRU / LSTM launch is reported through an error word only; read the words of
-    the recent launches at every evaluation so that a run cannot continue on garbage states (one small read-back)."""
+    the recent eager launches AND the library's sticky word (which also covers launches replayed from HIP graphs) at every
+    evaluation so that a run cannot continue on garbage states (one small read-back)."""
     if torch.cuda.is_available():
         from . import ops
         ops.gru_check_all()

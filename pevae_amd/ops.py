@@ -969,8 +969,20 @@ def gru_check_all():
     while LAST_GRU_SYNC:
         sync, NG, tag = LAST_GRU_SYNC.pop()
         gru_check_sync(sync, NG, tag)
+    rnn_check()
     block_check()
     greedy_decode_check()
+
+
+def rnn_check():
+    """Raise if ANY persistent GRU / LSTM launch since the last check reported a timed-out wait -- the library's sticky
+    word, which launches replayed from a HIP graph cannot erase (their own error words are zeroed by every replay, and
+    no Python runs during a replay to register them in LAST_GRU_SYNC).  Synchronises the device; clears the word."""
+    flag = C.c_int(0)
+    _lib.call("pv_rnn_sync_error", C.byref(flag), 1)
+    if flag.value:
+        raise _lib.PevaeHipError("pv_gru / pv_lstm: a bounded inter-workgroup wait timed out in a launch since the last "
+                                 "check (possibly inside a replayed HIP graph): the recurrent states are garbage")
 
 
 def block_check():

@@ -129,3 +129,42 @@ def test_data_path_matches_reference_code_golden():
             assert torch.equal(got[k], want_t), (k, b["max_seq_len"])
             assert torch.equal(ora[k], want_t) and ora[k].dtype == got[k].dtype, (k, b["max_seq_len"])
     assert any(len(rows["train"][i][3]) > b["max_seq_len"] for b in g["batches"] for i in b["rows"])   # truncation exercised
+
+
+@pytest.mark.gpu
+def test_data_path_cuda_batcher_matches_reference_code_golden():
+    """The CUDA branch of the batcher (pinned staging ring of three sets, event-guarded reuse, non-blocking H2D copies;
+    data_loaders.py:649-715 moved the batch with .to(device) inside the worker) against the same golden: every batch of
+    the fixture several times over through ONE batcher object -- each staging set is reused at least twice, with batches of
+    different shapes in between -- and every tensor that arrives on the device is bit-identical to what the reference's own
+    batcher produced.  The device tensors are checked only after ALL calls have been issued, so a staging set that was
+    overwritten before its copy had finished would show."""
+    assert torch.cuda.is_available()
+    from pevae_amd.dataset import process_reviews
+    g = _golden_data_path()
+    rows = {name: process_reviews([tuple(r) for r in raw], rd=[w[5] for w in g["rows"][name]]) for name, raw in g["raw"].items()}
+    order = ("train", "valid", "test", "pretrain")
+    _, rev, _ = build_vocab(tuple(rows[k] for k in order), g["max_vocab_cnt"])
+    by_len = {}
+    for b in g["batches"]:
+        by_len.setdefault(b["max_seq_len"], []).append(b)
+    calls = 0
+    for L, batches in by_len.items():
+        collate = YELPDataLoader.batcher(rev, L, "cuda")
+        issued = []
+        for rep in range(3):                               # >= 7 calls per batcher whenever the fixture has 3+ batches of a length
+            for b in batches:
+                issued.append((b, collate([rows["train"][i] for i in b["rows"]])))
+        while len(issued) < 7:
+            b = batches[len(issued) % len(batches)]
+            issued.append((b, collate([rows["train"][i] for i in b["rows"]])))
+        assert len(collate._ring) == 3 and collate._slot == len(issued) >= 7
+        torch.cuda.synchronize()
+        for b, got in issued:
+            assert set(got) == set(b["out"])
+            for k, want in b["out"].items():
+                assert got[k].is_cuda and got[k].is_contiguous()
+                want_t = torch.tensor(want, dtype=got[k].dtype)
+                assert torch.equal(got[k].cpu(), want_t), (k, L)
+        calls += len(issued)
+    assert calls >= 7

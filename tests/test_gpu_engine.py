@@ -195,3 +195,66 @@ def test_freeze_phase_with_the_dls_stack_and_gen_ids(dev, tmp_path):
     for b, ln in enumerate(ret["length"]):
         eos_at = (seq[b] == rev[EOS]).nonzero()
         assert ln == (int(eos_at[0]) + 1 if len(eos_at) else seq.shape[1])
+
+
+def test_recurrence_timeout_inside_a_replayed_graph_is_reported(dev):
+    """a captured GRU launch zeroes its own sync buffer (error word included) at the start of every replay and no
+    Python runs during a replay, so a wait that gave up in replay n was wiped by replay n + 1 and training went on with
+    garbage states.  The kernels now also set a sticky process-level word that no launch clears; ops.gru_check_all (every
+    evaluation of engine.train / validate) raises on it.  Here the time-out is injected by the library's one-thread test
+    kernel INSIDE a captured graph that is followed by real recurrence launches and replayed several times."""
+    from pevae_amd import _lib, ops
+    ops.gru_check_all()                                    # clean start (also clears the sticky word)
+    B, L, E, H = 16, 5, 12, 32
+    torch.manual_seed(0)
+    x = torch.randn(B, L, E, device=dev)
+    h0 = torch.zeros(B, H, device=dev)
+    w_ih, w_hh = torch.randn(3 * H, E, device=dev) * 0.1, torch.randn(3 * H, H, device=dev) * 0.1
+    b = torch.zeros(3 * H, device=dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.no_grad():
+            for _ in range(2):
+                ops.GRULayer.apply(x, h0, w_ih, w_hh, b, b, False)
+        side.synchronize()
+        ops.gru_check_all()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            _lib.call("pv_rnn_sync_error_inject", ops._stream())
+            with torch.no_grad():
+                out = ops.GRULayer.apply(x, h0, w_ih, w_hh, b, b, False)[0]
+        ops.LAST_GRU_SYNC.clear()                          # what engine.GraphedStep does after a capture
+        for _ in range(3):
+            graph.replay()                                 # every replay re-zeroes the launch's own error word
+        side.synchronize()
+    assert torch.isfinite(out).all()
+    with pytest.raises(_lib.PevaeHipError, match="timed out"):
+        ops.gru_check_all()
+    ops.gru_check_all()                                    # the check cleared the word: the next one passes
+
+
+def test_skip_flags_report_their_own_step_when_the_host_runs_ahead(dev):
+    """FlatAdam.skip_flag_async hands out handles on a ring of 8 pinned slots.  A host that runs more than 8
+    steps ahead of its reads (graph replay with no report boundary in reach) used to re-arm a slot's event and overwrite
+    its buffer while the handle of 8 steps earlier was still unread: that handle then reported the LATER step.  A slot now
+    resolves its outstanding handle before it is reused: 20 handles read only after the last step each tell their own
+    step's decision and learning rate."""
+    from pevae_amd.optim import FlatAdam
+    p = torch.nn.Parameter(torch.ones(64, device=dev))
+    opt = FlatAdam([p], lr=1e-2, max_norm=5.0, warmup_steps=10)
+    bad_steps = {3, 11, 12}
+    flags = []
+    for step in range(20):
+        opt.zero_grad()
+        p.grad.fill_(float("inf") if step in bad_steps else 0.1)
+        opt.step()
+        flags.append(opt.skip_flag_async())               # never read inside the loop
+    got = [f.skipped() for f in flags]
+    assert got == [s in bad_steps for s in range(20)]
+    # the warm-up schedule counts APPLIED steps: the k-th applied step runs at lr * min(1, k / warmup)
+    applied = 0
+    for s, f in enumerate(flags):
+        if s in bad_steps:
+            continue
+        assert abs(f.lr() - 1e-2 * min(1.0, applied / 10.0)) <= 1e-9, (s, f.lr())
+        applied += 1
