@@ -480,7 +480,10 @@ int pv_dropout_pack_bf16(const float* src, int n0, int n1, int n1p, int C, long 
 /* ---- clip + skip guards + Adam over one flat buffer (main_pretrain.py:207-225,268-269;
  * dialog_models.py:122-131) ------------------------------------------------------------------------------------ */
 /* state: pv_optim_state_bytes() of device memory, zeroed once; its first 48 bytes are {float avg_norm; int have_avg,
- * jump_cnt, batch_cnt, adam_step; float last_norm, clip_coef; int skip; float lr_eff, bc1, bc2; int skipped_total}.
+ * jump_cnt, batch_cnt, adam_step; float last_norm, clip_coef; int skip; float lr_eff, bc1, bc2; int skipped_total},
+ * followed at byte 48 by {float lr_base}: with lr < 0 the base learning rate is read from there (the host writes it, e.g.
+ * at a plateau decay, main_pretrain.py:343-348), so guards + clip + Adam can be replayed from a HIP graph whose
+ * kernel arguments are frozen.
  * grad_scale: the gradient is grad_scale * grads (data parallel: grads = SUM over ranks, grad_scale = 1/world; norm,
  * clip and update use the scaled values without another pass).  weight_decay: decoupled decay of torch.optim.AdamW
  * (the freeze-phase optimizer, dialog_models.py:834: p *= 1 - lr * wd before the update); 0 = torch.optim.Adam. */

@@ -24,7 +24,8 @@ struct OptState {       // 16 x 4 bytes, lives in device memory (pv_optim_state_
   float lr_eff;
   float bc1, bc2;       // 1 - beta^t
   int skipped_total;
-  float pad[4];
+  float lr_base;        // byte 48: the base learning rate when pv_grad_guard is called with lr < 0 (written by the host)
+  float pad[3];
 };
 
 constexpr int NPART = 1024;
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ pa
     o.clip_coef = (max_norm > 0.f ? fminf(coef, 1.f) : 1.f) * grad_scale;
     // LambdaLR: the k-th optimizer.step() (k = 0,1,..) runs with lr * min(1, k / warmup)
     const int k = o.adam_step;
-    o.lr_eff = (warmup > 0 && k < warmup) ? lr * (float)k / fmaxf(1.f, (float)warmup) : lr;
+    // lr < 0: the base rate is a DEVICE scalar (lr_base), so that a replayed HIP graph follows the host's plateau decay
+    const float lr_now = lr < 0.f ? o.lr_base : lr;
+    o.lr_eff = (warmup > 0 && k < warmup) ? lr_now * (float)k / fmaxf(1.f, (float)warmup) : lr_now;
     o.adam_step = k + 1;
     o.batch_cnt += 1;
     o.bc1 = 1.f - powf(beta1, (float)o.adam_step);

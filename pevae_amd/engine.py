@@ -117,8 +117,10 @@ class GraphedStep(object):
     first `warmup` batches of every (mode, phase, batch shape) run eagerly -- they are real steps: they allocate every
     workspace and take the lazy paths once --, the next one is CAPTURED (torch.cuda.graph) on static copies of its
     tensors and then replayed, and from then on a step is: copy the batch into the static tensors, one graph launch.
-    Everything that decides something stays where it was: the guards / clip / Adam run in optimizer.step() outside the
-    graph (the learning rate is a host value that changes at evaluations), the skip flag is read back as before.  New
+    The guards / clip / Adam of the step are part of the graph too (`with_step`): the base learning rate is a device scalar
+    that the host writes at evaluations (FlatAdam.lr), the decisions are taken on the device, and the skip flag is read back
+    as before.  Only a batch that could be the freeze phase's switching batch -- whose gradients the reference discards after
+    looking at the guards (:207-266) -- runs the graph WITHOUT the optimizer step and lets the loop decide.  New
     dropout masks every replay: the generator's step counter lives in device memory and is advanced inside the graph;
     torch's own generator (the uniform draws of DLS_Auto) is graph-safe.  The loss Pack handed back holds CLONES of the
     static scalars (the next replay overwrites those).  Batches of another shape (a ragged last batch) or in GEN mode run
@@ -142,29 +144,33 @@ class GraphedStep(object):
         sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
         return (mode, bool(getattr(model, "restarted", False)), sig)
 
-    def _eager(self, optimizer, batch, mode, batch_cnt):
+    def _eager(self, optimizer, batch, mode, batch_cnt, with_step=False):
         optimizer.zero_grad()
         loss = self.model(batch, mode=mode)
         self.model.backward(batch_cnt, loss, step=batch_cnt)
+        if with_step:
+            optimizer.step()                      # clip, skip rules and Adam on the device (:207-225, :268-269)
         return loss
 
-    def __call__(self, optimizer, batch, mode, batch_cnt):
+    def __call__(self, optimizer, batch, mode, batch_cnt, with_step=False):
+        """-> loss Pack.  with_step: optimizer.step() is part of what runs (and of what is captured); the caller then only
+        reads the skip flag back."""
         tensors = {k: v for k, v in batch.items() if torch.is_tensor(v)}
         if mode != TEACH_FORCE or not tensors or not all(v.is_cuda for v in tensors.values()):
-            return self._eager(optimizer, batch, mode, batch_cnt)
-        key = self._key(batch, mode, self.model)
+            return self._eager(optimizer, batch, mode, batch_cnt, with_step)
+        key = self._key(batch, mode, self.model) + (bool(with_step), id(optimizer))
         entry = self.graphs.get(key)
         if entry is None:
             self.seen[key] += 1
             if self.seen[key] <= self.warmup:
-                return self._eager(optimizer, batch, mode, batch_cnt)
+                return self._eager(optimizer, batch, mode, batch_cnt, with_step)
             import gc
             gc.collect()                                   # no autograd graph of an eager step may be alive during capture
             static = dict(batch)
             static.update({k: v.clone() for k, v in tensors.items()})
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
-                out = self._eager(optimizer, static, mode, batch_cnt)
+                out = self._eager(optimizer, static, mode, batch_cnt, with_step)
             if self.pool is None:
                 self.pool = graph.pool()
             entry = self.graphs[key] = (graph, static, out)
@@ -273,14 +279,18 @@ def _train_loop(model, train_feed, valid_feed, config, max_evals, checkpoint, op
                 break
             model.steps = batch_cnt + len(pending)
             mode = TEACH_FORCE if done_epoch < config.teach_force_bound else GEN
+            # could this batch be the one at which the freeze phase starts?  (its gradients are then only looked at, :207-266)
+            may_switch = freeze_step is not None and not model.restarted and batch_cnt + len(pending) >= freeze_step
+            stepped = False
             if graphed is not None:
-                loss = graphed(optimizer, batch, mode, batch_cnt)
+                stepped = not may_switch and hasattr(optimizer, "skip_flag_async")
+                loss = graphed(optimizer, batch, mode, batch_cnt, with_step=stepped)
             else:
                 optimizer.zero_grad()
                 loss = model(batch, mode=mode)
                 model.backward(batch_cnt, loss, step=batch_cnt)
             nstep += 1
-            if freeze_step is not None and not model.restarted and batch_cnt + len(pending) >= freeze_step:
+            if may_switch:
                 settle(True)
                 if batch_cnt >= freeze_step:
                     # :207-266: the guards come first -- a skipped step `continue`s before the switch is looked at
@@ -309,7 +319,8 @@ def _train_loop(model, train_feed, valid_feed, config, max_evals, checkpoint, op
                     learning_rate = config.init_lr
                     batch_cnt = 0
                     continue
-            optimizer.step()                       # clip, skip rules and Adam on the device (:207-225, :268-269)
+            if not stepped:
+                optimizer.step()                   # clip, skip rules and Adam on the device (:207-225, :268-269)
             pending.append((loss, optimizer.skip_flag_async(), nstep))
             applied = settle(boundary_within(batch_cnt, batch_cnt + len(pending)))
             if pending or not applied:             # no boundary in reach, or this step was skipped (`continue`, :216 / :222)

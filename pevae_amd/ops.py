@@ -477,11 +477,18 @@ _RNG = {}
 
 
 def rng_state(device):
-    """{uint64 seed, uint64 step} in device memory (csrc/dropout.hip); seeded from torch.initial_seed() on first use."""
+    """{uint64 seed, uint64 step} in device memory (csrc/dropout.hip); seeded on first use from torch.initial_seed() and the
+    data-parallel rank (replicas seed torch identically to start from identical weights: without the rank every replica
+    would draw the same masks for its different samples).  The masks of a step are regenerated in backward from (seed, step,
+    site): ONE training-mode forward per backward -- a second forward before the first one's backward advances the step
+    and the first backward would apply other masks."""
     st = _RNG.get(device)
     if st is None:
         import struct
-        raw = struct.pack("QQ", torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0)
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        raw = struct.pack("QQ", (torch.initial_seed() + 0x9E3779B97F4A7C15 * rank) & 0xFFFFFFFFFFFFFFFF, 0)
         st = _RNG[device] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     return st
 
@@ -595,6 +602,8 @@ class VocabNLL(torch.autograd.Function):
     front (pv_vocab_compact / pv_vocab_gather) and the four GEMMs of the group take the live-row count from device
     memory (static launch geometry, graph-capturable).  PEVAE_VOCAB_DENSE=1 computes every row like the reference."""
 
+    RETURNED_SUMS = False       # set by every forward: True when `nll` is the {sum, live count} pair asked for with sums_only
+
     @staticmethod
     def forward(ctx, hid, weight, bias, target, inv_temp, ignore_index, hid_bf16, layout, drop=None, pre=None, sums_only=False):
         # hid: fp32 [T,H] -- or, with `hid_bf16` ([L*Bpad, ld] time-major bf16 rows from the GRU kernel) and
@@ -627,6 +636,7 @@ class VocabNLL(torch.autograd.Function):
         target = target.contiguous()
         perm = count = None
         ctx.fused = False
+        VocabNLL.RETURNED_SUMS = False
         if FUSED_VOCAB and any(ctx.needs_input_grad[:3]) and _lib.load().pv_vocab_fused_supported(Hp):
             return VocabNLL._forward_fused(ctx, hid, weight, bias, target, inv_temp, ignore_index, T, H, V, Hp, h_bf, ldh, w_bf,
                                            pre, sums_only)
@@ -694,11 +704,13 @@ class VocabNLL(torch.autograd.Function):
                       _p(ws), _p(lse), _p(nll), _p(U), _p(count), _stream())
         lse_c = lse
         ctx.sums_only = False
+        VocabNLL.RETURNED_SUMS = False
         if perm is not None and sums_only:
             # the caller wants {sum, live count} only: reduce the compact rows where they are (rows past the live count
             # carry the ignore index in the compact target vector) -- no scatter back to the caller's row order
             nll = masked_sum(nll, target, ignore_index)
             ctx.sums_only = True
+            VocabNLL.RETURNED_SUMS = True            # (what the caller must look at: the shape of `nll` does not tell)
         elif perm is not None:
             nll_c = nll
             nll = torch.empty(T, dtype=torch.float32, device=dev)
@@ -715,6 +727,9 @@ class VocabNLL(torch.autograd.Function):
 
     @staticmethod
     def _backward_fused(ctx, dnll):
+        if ctx.fused_saved is None:
+            raise RuntimeError("VocabNLL: second backward through the fused vocabulary node -- its saved operands (the "
+                               "compact states, U = dNLL/dh) are released by the first one; retain_graph is not supported here")
         h_bf, w_bf, bias, target, t32, lse, perm, count, U = ctx.fused_saved
         ctx.fused_saved = None
         T, H, V, Hp, ldh, inv_temp, ignore_index = ctx.dims

@@ -48,7 +48,7 @@ class FlatAdam(object):
         dev = self.params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FlatAdam needs parameters on an MI355X device; there is no CPU fallback")
-        self.lr, self.max_norm, self.warmup, self.betas, self.eps, self.guards = lr, max_norm, warmup_steps, betas, eps, guards
+        self.max_norm, self.warmup, self.betas, self.eps, self.guards = max_norm, warmup_steps, betas, eps, guards
         self.weight_decay, self.grad_scale = float(weight_decay), float(grad_scale)
         self._flag_ring, self._flag_slot = [], 0
         offs, n = [], 0
@@ -66,6 +66,18 @@ class FlatAdam(object):
             p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
         self.offsets = offs
         self.state = torch.zeros(_lib.load().pv_optim_state_bytes(), dtype=torch.uint8, device=dev)
+        self.lr = lr
+
+    @property
+    def lr(self):
+        """The base learning rate.  It lives in device memory (state block, byte 48) and the guard kernel reads it from
+        there, so a step captured in a HIP graph follows later assignments (engine.adjust_learning_rate at a plateau)."""
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        self.state[48:52].view(torch.float32).fill_(self._lr)          # stream-ordered with the steps around it
 
     def table_range(self, param):
         """(offset, rows, dim) of a 2-D parameter inside the flat buffers (dp.FlatGradReducer sparse_tables)."""
@@ -103,7 +115,7 @@ class FlatAdam(object):
 
     def guard(self):
         """Clip norm + the skip rules of main_pretrain.py:207-225 on the device (decision and coefficients into `state`)."""
-        _lib.call("pv_grad_guard", _p(self.flat_g), self.n, _p(self.state), self.max_norm, self.lr, self.warmup,
+        _lib.call("pv_grad_guard", _p(self.flat_g), self.n, _p(self.state), self.max_norm, -1.0, self.warmup,
                   self.betas[0], self.betas[1], 1 if self.guards else 0, self.grad_scale, _stream())
 
     def apply(self):
