@@ -14,7 +14,7 @@ Deviations, all forced by the reference being un-runnable as written (SURVEY sec
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import dp, ops
 
 
 class SNLinear(nn.Module):
@@ -179,6 +179,10 @@ class DLSAuto(nn.Module):
         batched = not restarted and not getattr(cfg, "ost", False) and all(
             a.shape[1] % 4 == 0 for a in list(act1) + [output]) and len(self.layers) < 7
         use = lambda t: t
+        # config.global_negatives under batch sharding: the score matrices of cons_loss span the GLOBAL batch (every rank
+        # computes the same loss from gathered rows; dp.GatherRows), as one process at that batch would
+        gather, _ = dp.global_rows(cfg)
+        glob = (lambda t: t) if gather is None else (lambda t: gather(t, replicated=True))
         if batched:
             # every cons_loss of the train branch (:3284 and :3307 per level) reads only the pyramids' activations: one
             # batched call up front instead of one chain of ten launches per level
@@ -186,10 +190,10 @@ class DLSAuto(nn.Module):
             # `output` and the activations of the fused levels have 2-4 readers in here (cons_loss, the level's Blocks,
             # two level kernels): one alias per reader, their gradients summed by one launch (ops.FanOut)
             use = ops.Fan(4, [output] + [a[-i - 1] for i in range(nl) for a in (act1, act2)])
-            rkl = scaled(ops.cons_loss_sum([(use(output), rec_output)] +
-                                           [(use(act1[-i - 1]), use(act2[-i - 1])) for i in range(nl)]))
+            rkl = scaled(ops.cons_loss_sum([(glob(use(output)), glob(rec_output))] +
+                                           [(glob(use(act1[-i - 1])), glob(use(act2[-i - 1]))) for i in range(nl)]))
         else:
-            rkl = scaled(ops.cons_loss(output, rec_output))
+            rkl = scaled(ops.cons_loss(glob(output), glob(rec_output)))
         last_sample = last_t = nxt = None
         if noise is None and not restarted and not getattr(cfg, "ost", False):
             # the uniform draws of every level (:3206-3207) in one launch
@@ -235,7 +239,7 @@ class DLSAuto(nn.Module):
                 else:
                     last_sample, output, klw = ops.DlsLevel.apply(res[2], res[0], a2, eps, lay_out, float(ew), float(cw))
                     nxt = None
-                    rkl = rkl + klw + scaled(ops.cons_loss(a1, a2))                                  # :3307
+                    rkl = rkl + klw + scaled(ops.cons_loss(glob(a1), glob(a2)))                      # :3307
                 last_t = t_mean
             else:
                 if self.training:
@@ -316,6 +320,9 @@ class DeNAuto(nn.Module):
         rkl = 0
         last_sample = last_t = None
         train_branch = not restarted and not getattr(cfg, "ost", False)
+        # config.global_negatives: the hard negative of a row is drawn among the rows of ALL ranks (dp.GatherRows; the
+        # negative's gradient travels back to the rank that owns the row)
+        gather, rank = dp.global_rows(cfg)
         for i, (layer, dis, dis2, m_layer) in enumerate(zip(self.layers, self.dis_layers, self.dis_layers2, self.y_z_info)):
             a1, a2 = act1[-i - 1], act2[-i - 1]
             if train_branch:
@@ -334,9 +341,12 @@ class DeNAuto(nn.Module):
                 z, _ = ops.reparam_kl(m_mean, m_lv, None, None, eps, mode=1, want_kl=False)     # :2719
                 last_sample = z + a2
                 if not getattr(cfg, "no_mutual_information", False):                             # :2721-2727
-                    perm = gumbel_sampling(last_sample.detach(), None if gumbels is None else gumbels[i])
+                    pool = last_sample if gather is None else gather(last_sample)
+                    perm = gumbel_sampling(pool.detach(), None if gumbels is None else gumbels[i])
+                    if gather is not None:               # this rank's rows of the global draw
+                        perm = perm[rank * last_sample.shape[0]:(rank + 1) * last_sample.shape[0]]
                     pos = m_layer(torch.cat([last_t, last_sample], -1))
-                    neg = m_layer(torch.cat([last_t, last_sample[perm]], -1))
+                    neg = m_layer(torch.cat([last_t, pool[perm]], -1))
                     rkl = rkl - torch.mean(torch.log(pos + 1e-6) + torch.log(1 - neg + 1e-6))
                 output = res[2] + last_sample                                                    # :2729
             else:

@@ -43,7 +43,8 @@ def default_config(**kw):
                     attn_type="cat", do_pred=False, beam_size=10, batch_size=256, init_lr=1e-4, grad_clip=5.0,
                     warmup_steps=0, use_gpu=True, latent_stack="gauss", expand_weight=0.5, converge_weight=0.1,
                     cip_weight=1.0, ost=False, pad_id=PAD_ID, unk_id=UNK_ID, bos_id=BOS_ID, eos_id=EOS_ID,
-                    use_mutual=False, use_feature=False, n_feature=0, den_weight=1.0)
+                    use_mutual=False, use_feature=False, n_feature=0, den_weight=1.0,
+                    global_negatives=False)     # batch sharding only: batch-coupled losses over gathered rows (dp.GatherRows)
     for k, v in kw.items():
         setattr(cfg, k, v)
     return cfg

@@ -104,6 +104,69 @@ def self_launch_command(n_gpus, script, argv, env, device_count, port=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
 
 
+def _host_staged(x, group):
+    """A gloo group handed device tensors (the two-rank rehearsal on one card): the exchange goes through host memory."""
+    return x.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class GatherRows(torch.autograd.Function):
+    """[B_local, d] rows of every rank -> [world * B_local, d] in rank order, differentiable (config.global_negatives).
+
+    The batch-coupled losses of the latent stacks -- DLS_Auto.cons_loss (dialog_models.py:3266-3272: a B x B score matrix,
+    soft-max over rows and columns) and the Gumbel hard negatives of DeN_Auto (:2676-2685, :2722-2726: a row of ANOTHER
+    sample as the negative) -- see only the local shard under batch sharding.  Gathering their inputs makes them see the
+    global batch, which is what one process at batch world * B_local computes.
+    Backward.  The step's parameter gradient is (1 / world) * sum over ranks of what each rank back-propagates
+    (FlatGradReducer with average=True), while the loss meant is (1 / world) * sum_r L_r.  A rank's rows reach the
+    losses of ALL ranks through the gathered copies, so its rows' gradient is sum_s dL_s / d rows_r: an all-reduce (sum)
+    of the gathered gradient, of which the rank keeps its own slice.  replicated=True says every rank computes the SAME
+    loss from the gathered rows (the global cons_loss): then all ranks hold the same gathered gradient and the sum is
+    `world` times the local slice -- no collective in backward.
+    All ranks must hold the same number of rows (a ragged last batch cannot be gathered; drop it or pad it)."""
+
+    @staticmethod
+    def forward(ctx, x, group=None, replicated=False):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        src = x.detach().contiguous()
+        staged = _host_staged(src, group)
+        send = src.cpu() if staged else src
+        out = send.new_empty((world * send.shape[0],) + tuple(send.shape[1:]))
+        dist.all_gather(list(out.chunk(world, 0)), send, group=group)
+        ctx.meta = (group, world, rank, x.shape[0], bool(replicated))
+        return out.to(x.device) if staged else out
+
+    @staticmethod
+    def backward(ctx, g):
+        group, world, rank, rows, replicated = ctx.meta
+        if replicated:
+            return g[rank * rows:(rank + 1) * rows] * float(world), None, None
+        g = g.contiguous().clone()
+        if _host_staged(g, group):
+            h = g.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            g = h.to(g.device)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        return g[rank * rows:(rank + 1) * rows].clone(), None, None
+
+
+def global_rows(config, group=None):
+    """-> (gather(x, replicated=False), row offset of this rank) when config.global_negatives is set and more than one
+    rank runs, else (None, 0): the callers then keep the reference's per-batch form (the default; a shard IS a batch)."""
+    if not getattr(config, "global_negatives", False) or not dist.is_available() or not dist.is_initialized():
+        return None, 0
+    world = dist.get_world_size(group)
+    if world <= 1:
+        return None, 0
+    rank = dist.get_rank(group)
+
+    def gather(x, replicated=False):
+        return GatherRows.apply(x, group, replicated)
+
+    gather.rank, gather.world = rank, world
+    return gather, rank
+
+
 def bucket_bounds(n, bucket_elems):
     """[(start, end)] covering [0, n) in order."""
     return [(s, min(s + bucket_elems, n)) for s in range(0, n, bucket_elems)]

@@ -243,3 +243,76 @@ def test_bench_gpus_n_without_enough_gpus_exits_nonzero_with_the_reason():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                          text=True, timeout=120)
     assert res.returncode == 2 and "WORLD_SIZE = 4 but 2 ranks" in res.stderr
+
+
+def _cons_loss(v1, v2):
+    """DLS_Auto.cons_loss (dialog_models.py:3266-3272) in plain torch."""
+    import torch.nn.functional as F
+    v1 = v1 / torch.norm(v1, dim=1).unsqueeze(-1)
+    v2 = v2 / torch.norm(v2, dim=1).unsqueeze(-1)
+    sc = v1 @ v2.t() * 1.1
+    t = torch.arange(sc.shape[0])
+    return (F.nll_loss(F.log_softmax(sc, 1), t) + F.nll_loss(F.log_softmax(sc, 0), t)) / 2
+
+
+def _coupled_losses(x, w1, w2, perm, gather=None, rank=0):
+    """A cons_loss over the batch plus a hard-negative term that reads ANOTHER sample's row (the DeN_Auto pattern,
+    dialog_models.py:2722-2727) plus a per-sample term; `gather` makes the first two span the global batch."""
+    a, b = torch.tanh(x @ w1), torch.tanh(x @ w2)
+    if gather is None:
+        ga, gb, pool = a, b, b
+    else:
+        ga, gb, pool = gather(a, replicated=True), gather(b, replicated=True), gather(b)
+        perm = perm[rank * x.shape[0]:(rank + 1) * x.shape[0]]
+    neg = torch.sigmoid((a * pool[perm]).sum(-1))
+    return _cons_loss(ga, gb) - torch.mean(torch.log(1 - neg + 1e-6)) + a.pow(2).sum(-1).mean()
+
+
+def _global_neg_inputs(B, world):
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(world * B, 12, generator=g)
+    w1, w2 = torch.randn(12, 8, generator=g) * 0.5, torch.randn(12, 8, generator=g) * 0.5
+    perm = torch.randint(0, world * B, (world * B,), generator=g)
+    return x, w1, w2, perm
+
+
+def _global_neg_worker(rank, world, port, B, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from types import SimpleNamespace
+    from pevae_amd import dp
+    dp.init_from_env(backend="gloo")
+    assert dp.global_rows(SimpleNamespace(global_negatives=False)) == (None, 0)           # the default: per shard
+    gather, r = dp.global_rows(SimpleNamespace(global_negatives=True))
+    assert r == rank and gather.world == world
+    x, w1, w2, perm = _global_neg_inputs(B, world)
+    w1.requires_grad_(True), w2.requires_grad_(True)
+    loss = _coupled_losses(x[rank * B:(rank + 1) * B], w1, w2, perm, gather, rank)
+    loss.backward()
+    flat = torch.cat([w1.grad.reshape(-1), w2.grad.reshape(-1)])
+    dp.FlatGradReducer(flat, world).reduce()                     # the step's own exchange: mean over ranks
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    torch.save((flat, lsum / world), os.path.join(out, "g%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_global_negatives_equal_the_single_process_result_at_twice_the_batch(tmp_path):
+    """config.global_negatives: two ranks of B rows with gathered rows give the loss and the parameter
+    gradient of ONE process at 2B rows -- for a loss every rank replicates (cons_loss) and for one whose negatives are
+    other ranks' rows (the gradient travels back through the gather)."""
+    B, world = 6, 2
+    port = _free_port()
+    mp.spawn(_global_neg_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+    x, w1, w2, perm = _global_neg_inputs(B, world)
+    w1.requires_grad_(True), w2.requires_grad_(True)
+    want = _coupled_losses(x, w1, w2, perm)
+    want.backward()
+    want_flat = torch.cat([w1.grad.reshape(-1), w2.grad.reshape(-1)])
+    for r in range(world):
+        flat, loss = torch.load(os.path.join(str(tmp_path), "g%d.pt" % r), weights_only=True)
+        torch.testing.assert_close(flat, want_flat, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(loss, want.detach(), rtol=1e-6, atol=1e-6)
+    # and the per-shard default is a different loss: the test would notice a gather that does nothing
+    local = sum(_coupled_losses(x[r * B:(r + 1) * B], w1, w2, perm[r * B:(r + 1) * B] % B) for r in range(world)) / world
+    assert abs(float(local.detach()) - float(want.detach())) > 1e-3

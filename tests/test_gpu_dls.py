@@ -1,6 +1,8 @@
 """GPU parity of the DLS latent pyramid (a15-a17): Block / DlsRec / DlsPri against the goldens generated from the
 reference's own classes, the DLS_Auto helpers against dls_helpers.npz, and DLSAuto + the composed 'dls' step against
 the CPU oracle.  Everything here is fp32 (f32-input MFMA for the linears): tolerance 1e-4 relative."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -216,3 +218,43 @@ def test_dls_auto_golden_from_reference_class(dev, tag):
     from test_oracle_golden import dls_auto_from_golden, run_dls_auto_golden
     g = load_golden("dls_auto_" + tag)
     run_dls_auto_golden(dls_auto_from_golden(L.DLSAuto, g, dev), g, lambda a: T(a, dev), 5e-4, 1e-4)
+
+
+def test_global_negatives_two_ranks(dev, tmp_path):
+    """config.global_negatives (dialog_models.py:3266-3272, :2676-2685, :2722-2726): two ranks of 8 rows each
+    -- DLSAuto's cons_loss over gathered rows, DeNAuto's hard negatives drawn among all 16 rows -- give the loss and the
+    rank-averaged parameter gradient of ONE process at 16 rows.  Both ranks use this box's one GPU over a gloo group
+    (dp.GatherRows stages through the host there); tests/test_dp_gloo.py covers the gradient rule on CPU."""
+    import socket
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _global_negatives_worker as W
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_global_negatives_worker.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(port), str(tmp_path)]) for r in range(2)]
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=100))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(-9)
+    assert codes == [0, 0]
+    dls, den = W.build(dev, False)                     # one process, 16 rows, the reference's per-batch form
+    d = W.inputs(16, dev)
+    d["_gumbels"] = [g.to(dev) for g in d["gumbels"]]
+    want_loss, want_flat = W.run(dls, den, d, 0, 16, dev)
+    scale = float(want_flat.abs().max())
+    for r in range(2):
+        loss, flat = torch.load(os.path.join(str(tmp_path), "gn%d.pt" % r), weights_only=True)
+        np.testing.assert_allclose(float(loss), float(want_loss), rtol=2e-5)
+        np.testing.assert_allclose(flat.numpy(), want_flat.numpy(), rtol=1e-3, atol=2e-5 * scale)
+    # the per-shard default on the same halves is a different loss
+    dls, den = W.build(dev, False)
+    d["_gumbels"] = [g[:8, :8].to(dev) for g in d["gumbels"]]
+    half, _ = W.run(dls, den, d, 0, 8, dev)
+    assert abs(float(half) - float(want_loss)) > 1e-3
