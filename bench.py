@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--vocab-dense", type=int, default=0,
                     help="1 = run the vocabulary GEMMs over the padding rows too (no ignored-token compaction)")
     ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for per-kernel times")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file", "off"],
+                    help="roofline.traffic: measure = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short child run of "
+                         "this script, before this process touches the GPU; file = the committed profiles/r03_pmc_traffic.json; "
+                         "auto = measure when rocprofv3 is on PATH (N = 1, yelp config), else file")
     return ap.parse_args()
 
 
@@ -83,9 +87,73 @@ def cpu_baseline(cfg, batch, steps):
                        % (steps, batch, cfg.max_seq_len, cfg.vocab_size, sec))
 
 
+VOCAB_KERNELS = ("vocab_fwd_dh_kernel", "vocab_fwd_combine_kernel", "vocab_dw_kernel", "vocab_dw_reduce_kernel")
+
+
+def measure_traffic(args):
+    """HBM bytes per step of the vocabulary group, measured NOW: one rocprofv3 --pmc pass per counter (the guide's
+    prescription: separate passes, no trace domains beside --pmc) over a short eager child run of this script, the program
+    itself behind `--`.  Per kernel the median over its launches of FETCH_SIZE x 2 (gfx950 counts 64-byte halves of its
+    128-byte fetches once) + WRITE_SIZE, both in KiB; each of the four kernels runs once per step.  Runs before this
+    process initialises the GPU.  -> (bytes per step, per-kernel dict) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import statistics
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None, "rocprofv3 is not on PATH"
+    child = ["python3", os.path.abspath(__file__), "--cpu-baseline", "0", "--graph", "0", "--steps", "3", "--warmup", "1",
+             "--profile-steps", "1", "--traffic", "off", "--batch", str(args.batch), "--dropout", str(args.dropout)]
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="pevae_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return None, "the %s pass did not finish in 240 s" % counter
+            files = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                return None, "the %s pass left no counter file (exit status %d)" % (counter, rc)
+            with open(max(files, key=os.path.getmtime)) as fh:
+                for r in csv.DictReader(fh):
+                    if r["Counter_Name"] != counter:
+                        continue
+                    for k in VOCAB_KERNELS:
+                        if (k + "(") in r["Kernel_Name"]:
+                            vals.setdefault((k, counter), []).append(float(r["Counter_Value"]))
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    per, total = {}, 0
+    for k in VOCAB_KERNELS:
+        if (k, "FETCH_SIZE") not in vals or (k, "WRITE_SIZE") not in vals:
+            return None, "no counter rows for %s" % k
+        b = int((2 * statistics.median(vals[(k, "FETCH_SIZE")]) + statistics.median(vals[(k, "WRITE_SIZE")])) * 1024)
+        per[k] = b
+        total += b
+    return total, per
+
+
 def main():
     args = parse()
     from pevae_amd import dp
+    measured = None
+    if (args.traffic in ("auto", "measure") and args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == "yelp"
+            and not args.vocab_dense):
+        measured = measure_traffic(args)
+        if measured[0] is None:
+            print("bench.py: roofline.traffic not measured in this run: %s" % measured[1], file=sys.stderr)
+            if args.traffic == "measure":
+                sys.exit(4)
     # --gpus N without torchrun: this process starts the N ranks itself (before it touches a GPU: device_count() does
     # not initialise one) and leaves with their status; rank 0's JSON line goes to the inherited stdout.  There is no
     # fall-back to fewer GPUs: a layout that cannot run exits non-zero with the reason.
@@ -368,18 +436,25 @@ def main():
         vocab_tags = [k for k in kern_ms if k.startswith("vocab_")]
         vocab_ms = sum(kern_ms[k]["ms_per_step"] for k in vocab_tags)
         ach = alg_flop / (vocab_ms * 1e-3) / 1e12
-        traffic = None          # HBM bytes per step of the group, from the committed rocprofv3 --pmc passes (this script
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # cannot run the profiler on itself)
-        if os.path.exists(pmc):
-            with open(pmc) as fh:
-                traffic = json.load(fh).get("vocab_group_hbm_bytes_per_step")
+        # HBM bytes per step of the group: measured at the start of this run (measure_traffic), else the committed passes
+        traffic, traffic_source, traffic_kernels = None, None, None
+        if measured is not None and measured[0] is not None:
+            traffic, traffic_kernels = measured
+            traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each) over an "
+                              "eager 5-step child run; per kernel median of FETCH_SIZE x2 + WRITE_SIZE (KiB), summed, per step")
+        elif args.traffic != "off":
+            pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+            if os.path.exists(pmc):
+                with open(pmc) as fh:
+                    traffic = json.load(fh).get("vocab_group_hbm_bytes_per_step")
+                traffic_source = "profiles/r03_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per step; not measured in this run)"
         fused = "vocab_fused_fwd" in kern_ms
         fwd_tag = "vocab_fused_fwd" if fused else "vocab_fwd"
         # the forward entry point: logits + softmax + NLL (2 T H V); fused, it also carries the dH product (4 T H V)
         fwd_flop = (4.0 if fused else 2.0) * T_live * H * V
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
-                    traffic_source="profiles/r02_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per step)",
+                    traffic_source=traffic_source, traffic_per_kernel=traffic_kernels,
                     kernel=("vocab_fwd_dh_kernel + vocab_fwd_combine_kernel + vocab_dw_kernel + vocab_dw_reduce_kernel "
                             "(fused vocabulary projection + softmax + NLL forward, dH and dW; no [T,V] matrix in HBM)") if fused
                     else "gemm_nt_kernel<EpiSoftmax|EpiProb|EpiStore> (vocab projection+softmax+NLL fwd+bwd group)",

@@ -1,9 +1,9 @@
 """Per-kernel HBM traffic and MFMA utilisation of one training step from rocprofv3 counter passes
 (MI355X_MICROARCH.md: separate --pmc passes; FETCH_SIZE doubled on gfx950; values are KB; SQ_VALU_MFMA_BUSY_CYCLES counts
-cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs).  tools/evidence_r02.sh runs the
+cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs).  tools/evidence_r0N.sh runs the
 passes; then:
 
-  python tools/pmc_report.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma <kernel_stats.csv> profiles/r02_pmc_traffic.json
+  python tools/pmc_report.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma <kernel_stats.csv> profiles/r0N_pmc_traffic.json
 
 Durations come from the --kernel-trace --stats pass of the graph-replayed bench (average per launch)."""
 import csv
