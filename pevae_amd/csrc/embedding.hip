@@ -50,6 +50,92 @@ __global__ void fill_keys_kernel(const int64_t* __restrict__ ids, int n, int n1,
   vals[r] = (r / n1) * n1p + r % n1;                                // row of the gradient matrix
 }
 
+// Stable sort of the (row id, occurrence) pairs of one lookup: ONE workgroup, everything in LDS, keys made from the ids in the
+// same launch (the hot path's lookups have n <= 16 384 occurrences and tables below 2^18 rows: one packed word
+// key << 14 | occurrence per pair).  LSD radix sort, 4 bits a pass: thread t owns the E consecutive elements [tE, tE + E) of
+// the current order, counts its digits (sixteen 8-bit counters in two registers), the counts -- laid out [digit][thread] -- get
+// one exclusive scan over the whole workgroup, and each thread scatters its elements in order to the offsets of its own
+// column: equal digits keep their order.  Element p lives at word p + p / 32, so that the threads' chunks start in different
+// banks.  Elements past n are all-ones: they stay last in every pass and are never written out.
+constexpr int SORT_T = 512, SORT_E_MAX = 32, SORT_N_MAX = SORT_T * SORT_E_MAX, SORT_OCC_BITS = 14, SORT_KEY_BITS = 18;
+__device__ __forceinline__ int sort_at(int p) { return p + (p >> 5); }
+static inline size_t sort_lds_bytes(int n) {
+  const int span = cdiv(n, SORT_T) * SORT_T;
+  return (size_t)2 * (span + (span >> 5) + 1) * 4 + 16 * SORT_T * 2 + 64;
+}
+__global__ __launch_bounds__(SORT_T) void sort_pairs_lds_kernel(const int64_t* __restrict__ ids, int n, int n1, int n1p, long s0,
+                                                               long s1, long num_rows, int bits, int* __restrict__ skeys,
+                                                               int* __restrict__ svals) {
+  extern __shared__ unsigned sort_sm[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int E = (n + SORT_T - 1) / SORT_T, span = E * SORT_T, words = span + (span >> 5) + 1;
+  unsigned* src = sort_sm;
+  unsigned* dst = sort_sm + words;
+  unsigned short* cnt = (unsigned short*)(sort_sm + 2 * words);
+  unsigned* wsum = (unsigned*)(cnt + 16 * SORT_T);
+  for (int p = t; p < span; p += SORT_T) {
+    unsigned v = 0xffffffffu;
+    if (p < n) {
+      const int64_t id = ids[(long)(p / n1) * s0 + (long)(p % n1) * s1];
+      const unsigned key = (id < 0 || id >= num_rows) ? (unsigned)num_rows : (unsigned)id;   // out of range: last, no gradient
+      v = key << SORT_OCC_BITS | (unsigned)p;
+    }
+    src[sort_at(p)] = v;
+  }
+  __syncthreads();
+  for (int shift = SORT_OCC_BITS; shift < SORT_OCC_BITS + bits; shift += 4) {
+    unsigned long long c0 = 0, c1 = 0;
+    for (int j = 0; j < E; ++j) {
+      const unsigned d = (src[sort_at(t * E + j)] >> shift) & 15u;
+      if (d < 8) c0 += 1ull << (8 * d);
+      else c1 += 1ull << (8 * (d - 8));
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      cnt[d * SORT_T + t] = (unsigned short)((c0 >> (8 * d)) & 255u);
+      cnt[(d + 8) * SORT_T + t] = (unsigned short)((c1 >> (8 * d)) & 255u);
+    }
+    __syncthreads();
+    // exclusive scan of the 16 * SORT_T counts in [digit][thread] order: 16 consecutive entries per thread, then the threads
+    unsigned loc[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      loc[k] = sum;
+      sum += cnt[16 * t + k];
+    }
+    unsigned incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned base = incl - sum;
+    for (int k = 0; k < w; ++k) base += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cnt[16 * t + k] = (unsigned short)(base + loc[k]);
+    __syncthreads();
+    for (int j = 0; j < E; ++j) {
+      const unsigned v = src[sort_at(t * E + j)];
+      const unsigned d = (v >> shift) & 15u;
+      const unsigned o = cnt[d * SORT_T + t];
+      cnt[d * SORT_T + t] = (unsigned short)(o + 1);
+      dst[sort_at((int)o)] = v;
+    }
+    __syncthreads();
+    unsigned* tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+  for (int p = t; p < n; p += SORT_T) {
+    const unsigned v = src[sort_at(p)];
+    const int r = (int)(v & ((1u << SORT_OCC_BITS) - 1));
+    skeys[p] = (int)(v >> SORT_OCC_BITS);
+    svals[p] = (r / n1) * n1p + r % n1;                                 // row of the gradient matrix
+  }
+}
+
 // One wave per (sorted position that starts a piece, 64-column block).  A segment (all occurrences of one row id) is
 // summed in occurrence order, so a row with fewer than SEG_CH occurrences gets the bits of a sequential CPU
 // index_add_.  64 gradient rows are kept in flight per wave: the row ids of a batch are fetched with one coalesced load
@@ -230,11 +316,25 @@ int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n,
   void* temp = ws + 4 * a;
   size_t temp_bytes = sort_temp_bytes(n);
   float* part = (float*)(ws + 4 * a + ((temp_bytes + 255) & ~(size_t)255) + 256);   // one row per multiple of SEG_CH
-  hipLaunchKernelGGL(fill_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, n, n1, n1p, s0, s1, num_rows, keys, vals);
-  PV_LAUNCH_CHECK("fill_keys_kernel");
   int bits = 1;
   while ((1l << bits) <= num_rows && bits < 31) ++bits;
-  PV_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, skeys, vals, svals, n, 0, bits, st));
+  static const int own_sort = getenv("PV_EMB_OWN_SORT") ? atoi(getenv("PV_EMB_OWN_SORT")) : 1;
+  if (own_sort && n <= SORT_N_MAX && bits <= SORT_KEY_BITS) {
+    // the hot path: keys and the stable sort in one single-workgroup launch
+    static size_t seen = 0;
+    const size_t lds = sort_lds_bytes(n);
+    if (lds > 64 * 1024 && lds > seen) {
+      PV_HIP(hipFuncSetAttribute((const void*)sort_pairs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      seen = lds;
+    }
+    hipLaunchKernelGGL(sort_pairs_lds_kernel, dim3(1), dim3(SORT_T), lds, st, ids, n, n1, n1p, s0, s1, num_rows, bits, skeys, svals);
+    PV_LAUNCH_CHECK("sort_pairs_lds_kernel");
+  } else {
+    // lookups beyond 16 384 occurrences or tables of 2^18 rows and more: the library's device-wide sort
+    hipLaunchKernelGGL(fill_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, n, n1, n1p, s0, s1, num_rows, keys, vals);
+    PV_LAUNCH_CHECK("fill_keys_kernel");
+    PV_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, skeys, vals, svals, n, 0, bits, st));
+  }
   hipLaunchKernelGGL(segment_sum_kernel, dim3(cdiv(n, 4), cdiv(D, 64)), dim3(256), 0, st, skeys, svals, n, grad_rows, ldg, D,
                      num_rows, padding_idx, accumulate, dtable, part);
   PV_LAUNCH_CHECK("segment_sum_kernel");

@@ -351,6 +351,48 @@ def test_embedding_scatter_long_segments(dev):
     assert np.array_equal(tw.grad.cpu().numpy(), got)
 
 
+@pytest.mark.parametrize("rows,n,n1,n1p", [(262143, 16384, 64, 64), (200001, 12800, 50, 50), (20004, 16385, 16385, 16385),
+                                            (262144, 4096, 16, 32), (30000, 256, 256, 256), (5, 1, 1, 1), (1000, 777, 7, 9)])
+def test_embedding_backward_sort_limits(dev, rows, n, n1, n1p):
+    """pv_embedding_bwd through the C ABI at the edges of its own single-workgroup LDS sort (embedding.hip: n <= 16 384
+    occurrences, tables below 2^18 rows) and just beyond them (the library sort): bit-exact against numpy's sequential
+    scatter-add in occurrence order, ids outside the table ignored, padded gradient-row layout (n1p > n1)."""
+    import ctypes as C
+    from pevae_amd import _lib
+    g = torch.Generator().manual_seed(rows + n)
+    D = 8
+    ids = torch.randint(0, rows, (n,), generator=g)
+    ids[::97] = ids[0]                                  # duplicates (below the 256 of a cut segment)
+    if n > 4:
+        ids[3] = rows + 5                                   # outside the table: no gradient
+        ids[4] = -2
+    n0 = (n + n1 - 1) // n1
+    assert n0 * n1 == n
+    grad = torch.randn(n0 * n1p, D, generator=g)
+    want = np.zeros((rows, D), dtype=np.float32)
+    cnt = np.zeros(rows, dtype=np.int64)
+    gf = grad.numpy()
+    for r, i in enumerate(ids.tolist()):
+        if 0 <= i < rows and i != 0:
+            want[i] += gf[(r // n1) * n1p + r % n1]
+            cnt[i] += 1
+    assert cnt.max() < 256 or rows == 5                     # (long segments have their own test)
+    ids_d, grad_d = ids.to(dev), grad.to(dev)
+    dt = torch.empty(rows, D, device=dev)
+    ws_bytes = _lib.load().pv_embedding_bwd_ws_bytes(n, D)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        _lib.call("pv_embedding_bwd", C.c_void_p(grad_d.data_ptr()), D, C.c_void_p(ids_d.data_ptr()), n, n1, n1p, n1, 1,
+                  rows, D, 0, 0, C.c_void_p(dt.data_ptr()), C.c_void_p(ws.data_ptr()), ws_bytes, st)
+        torch.cuda.synchronize()
+        got = dt.cpu().numpy()
+        if rows == 5:
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+        else:
+            assert np.array_equal(got, want)
+
+
 def test_reparam_kl(dev):
     from pevae_amd import ops
     torch.manual_seed(6)
