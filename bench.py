@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--vocab-dense", type=int, default=0,
                     help="1 = run the vocabulary GEMMs over the padding rows too (no ignored-token compaction)")
     ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for per-kernel times")
+    ap.add_argument("--dw-beside", default="0.5,0.5",
+                    help="N = 1: fractions of the vocabulary whose dW runs beside the decoder's / the encoder's backward recurrence, "
+                         "half the chip each (ops.VOCAB_DW_BESIDE); 0 = one whole-chip launch in front of the decoder recurrence")
     ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file", "off"],
                     help="roofline.traffic: measure = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short child run of "
                          "this script, before this process touches the GPU; file = the committed profiles/r03_pmc_traffic.json; "
@@ -173,6 +176,7 @@ def main():
     from pevae_amd.optim import FlatAdam
     if args.vocab_dense:
         ops.SKIP_IGNORED_TOKENS = False
+    ops.VOCAB_DW_BESIDE = None if args.dw_beside in ("", "0") else tuple(float(x) for x in args.dw_beside.split(","))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     # everything (warm-up, capture, replay, eager passes) runs on ONE non-default stream: autograd ties each node
@@ -418,8 +422,12 @@ def main():
     if rank == 0:
         select(0)
         ops.TIMERS = {}
+        # the roofline prices the kernels on the whole chip: the instrumented pass launches the dW kernel once, on all CUs, in
+        # front of the decoder recurrence (the timed steps above ran it in two half-chip launches beside the recurrences)
+        beside, ops.VOCAB_DW_BESIDE = ops.VOCAB_DW_BESIDE, None
         for _ in range(args.profile_steps):
             fwd_bwd()
+        ops.VOCAB_DW_BESIDE = beside
         torch.cuda.synchronize()
         for tag, evs in ops.TIMERS.items():
             per_step = len(evs) // args.profile_steps
@@ -455,6 +463,10 @@ def main():
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=traffic,
                     traffic_source=traffic_source, traffic_per_kernel=traffic_kernels,
+                    measured_on=("the instrumented eager pass (%d steps, HIP events on the launch stream), every kernel launched on "
+                                 "the whole chip" % args.profile_steps) +
+                                ("; the timed steps run vocab_dw_kernel as two half-vocabulary launches on half the CUs each, beside "
+                                 "the decoder's and the encoder's backward recurrence" if beside else ""),
                     kernel=("vocab_fwd_dh_kernel + vocab_fwd_combine_kernel + vocab_dw_kernel + vocab_dw_reduce_kernel "
                             "(fused vocabulary projection + softmax + NLL forward, dH and dW; no [T,V] matrix in HBM)") if fused
                     else "gemm_nt_kernel<EpiSoftmax|EpiProb|EpiStore> (vocab projection+softmax+NLL fwd+bwd group)",
@@ -485,6 +497,8 @@ def main():
                        "global_batch": args.batch * world, "seq_len": cfg.max_seq_len, "params": n_params,
                        "parallelism": "dp%d" % world, "rccl_ranks": rccl_ranks, "devices": devices,
                        "hip_graph": bool(args.graph),
+                       "vocab_dw_beside_recurrences": (list(ops.VOCAB_DW_BESIDE) if ops.VOCAB_DW_BESIDE and not split and not three
+                                                       else None),
                        "padding_rows_skipped": bool(ops.SKIP_IGNORED_TOKENS),
                        "live_target_fraction": round(float(sum((b["ans_ids"] != 0).float().mean() for b in batches)) / len(batches), 4)},
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kern_ms, "final_vae_nll": round(final_nll, 4),

@@ -160,6 +160,23 @@ SIDE_BLOCK_WGRAD = os.environ.get("PEVAE_SIDE_BLOCK_WGRAD", "1") == "1"
 # the decoder recurrence (a workgroup of it owns a whole CU, and the chain of small kernels it runs beside then waits for
 # CUs): off by default.
 VOCAB_DW_SIDE_WGS = int(os.environ.get("PEVAE_VOCAB_DW_SIDE_WGS", "0"))
+# The vocabulary dW in three vocabulary ranges: the first on the whole chip where it stands, the second and third beside the
+# decoder's and the encoder's backward recurrence (half the chip each).  "a,b": fractions of the rows given to ranges 2 and 3.
+VOCAB_DW_BESIDE = os.environ.get("PEVAE_VOCAB_DW_BESIDE", "0.5,0.5")
+VOCAB_DW_BESIDE = tuple(float(x) for x in VOCAB_DW_BESIDE.split(",")) if VOCAB_DW_BESIDE not in ("", "0") else None
+
+
+def _vocab_dw_cuts(V):
+    """-> (c1, c2): ranges [0, c1) now, [c1, c2) and [c2, V) beside the recurrences; multiples of 128 rows (the dW kernel's
+    unit).  None when the vocabulary is too small to be worth three launches."""
+    if VOCAB_DW_BESIDE is None or V < 4096:
+        return None
+    f2, f3 = VOCAB_DW_BESIDE
+    n2, n3 = int(V * f2) // 128 * 128, int(V * f3) // 128 * 128
+    c1 = (V - n2 - n3) // 128 * 128
+    if c1 < 0 or n2 <= 0 or n3 <= 0:
+        return None
+    return c1, c1 + n2
 _DEFERRED = []           # (event on the stream that queued it, closure): side work whose launch is postponed
 
 
@@ -177,6 +194,29 @@ def defer_side_work(fn, keep=()):
     _DEFERRED.append((ev, fn, keep))
 
 
+EAGER_FLUSH = os.environ.get("PEVAE_EAGER_FLUSH", "1") == "1"
+
+
+def flush_deferred():
+    """Launch the postponed side work NOW on the side stream, without joining: called by a node of the critical chain right
+    after it has queued its own kernels (which are then the first successors of what they share with the side work).  The
+    latent stack's backward is a chain of ~10 Block nodes; without this their parameter-gradient GEMMs all waited for the
+    join in front of the encoder recurrence and ran there one after another while the main stream idled (~290 us of the
+    round-2 step's timeline)."""
+    if not _DEFERRED or not EAGER_FLUSH:
+        return
+    cur, st = _side_state()
+    side = st["stream"]
+    if cur == side:
+        return
+    while _DEFERRED:
+        ev, fn, keep = _DEFERRED.pop(0)
+        st["keep"].append(keep)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            fn()
+
+
 _AFTER_RNN = []          # closures for the SECOND side stream, launched right after the next persistent recurrence kernel
 
 
@@ -189,6 +229,47 @@ def defer_after_recurrence(fn, keep=()):
         fn()
         return
     _AFTER_RNN.append((fn, keep))
+
+
+_BESIDE_RNN = []         # closures fn(wgs) that want to run BESIDE a persistent recurrence kernel, one per recurrence, FIFO
+
+
+def defer_beside_recurrence(fn, keep=()):
+    """fn(wgs) runs on the second side stream, forked right in front of the next persistent GRU / LSTM backward launch, on
+    wgs = half the CUs, while that recurrence runs on the other half (its step is a chain of cross-workgroup latencies: on
+    half the chip it loses ~10 %, and a full-chip kernel that nothing downstream reads gets the other half for free).
+    What is still waiting at the end of the backward pass runs there with wgs = 0 (the whole chip).  Without ASYNC_WGRAD:
+    at once, whole chip."""
+    if not ASYNC_WGRAD:
+        fn(0)
+        return
+    _BESIDE_RNN.append((fn, keep))
+
+
+def launch_beside_recurrence():
+    """Called by a recurrence's backward right before its launch, after join_side_work().  -> the workgroup budget of the
+    recurrence launch (0 = whole chip)."""
+    if not _BESIDE_RNN:
+        return 0
+    cur, st = _side_state()
+    s2 = _second_stream(st)
+    half = _half_chip(cur.device)
+    fn, keep = _BESIDE_RNN.pop(0)
+    st["keep"].append(keep)
+    s2.wait_stream(cur)
+    st["busy2"] = True
+    with torch.cuda.stream(s2):
+        fn(half)
+    return half
+
+
+_HALF = {}
+
+
+def _half_chip(dev):
+    if dev not in _HALF:
+        _HALF[dev] = torch.cuda.get_device_properties(dev).multi_processor_count // 2
+    return _HALF[dev]
 
 
 def _second_stream(st):
@@ -242,12 +323,16 @@ class fork_side(object):
 def join_side_work():
     """Launch postponed side work, then make the current stream wait for the side streams (before a persistent kernel
     that needs every CU, and at the end of the backward pass)."""
-    if not _SIDE and not _DEFERRED and not _AFTER_RNN:
+    if not _SIDE and not _DEFERRED and not _AFTER_RNN and not _BESIDE_RNN:
         return
     cur, st = _side_state()
     side = st["stream"]
     if cur == side:
         return
+    if _BESIDE_RNN and not ASYNC_WGRAD:          # the end of the backward pass: no recurrence came for these
+        while _BESIDE_RNN:
+            fn, _keep = _BESIDE_RNN.pop(0)
+            fn(0)
     while _DEFERRED:
         ev, fn, _keep = _DEFERRED.pop(0)
         side.wait_event(ev)
@@ -759,14 +844,32 @@ class VocabNLL(torch.autograd.Function):
             dbias = sink_b
         ws_bytes = _lib.load().pv_vocab_fused_dw_ws_bytes(V)
 
-        def launch(wgs=0):
-            ws = workspace("vocab_fused_dw", ws_bytes, torch.uint8, dev)         # (of the stream it runs on)
+        def launch(wgs=0, v0=0, v1=V, tag="vocab_fused_dw", t32_r=t32):
+            # rows [v0, v1) of the vocabulary: the same entry point on offset operands (targets shifted by v0: a target
+            # outside the range matches no row of it)
+            nv = v1 - v0
+            ws = workspace(tag, _lib.load().pv_vocab_fused_dw_ws_bytes(nv), torch.uint8, dev)      # (of the stream it runs on)
             with timed("vocab_fused_dw"):
-                _lib.call("pv_vocab_fused_dw_wgs", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(t32), _p(lse), _p(gscale), T, V, Hp,
-                          inv_temp, _p(ws), _p(dW), H, 1 if sink is not None else 0, _p(dbias), 1 if sink_b is not None else 0,
+                _lib.call("pv_vocab_fused_dw_wgs", _p(h_bf), ldh, w_bf.data_ptr() + v0 * Hp * 2, Hp, bias.data_ptr() + 4 * v0,
+                          _p(t32_r), _p(lse), _p(gscale), T, nv, Hp, inv_temp, _p(ws), dW.data_ptr() + 4 * v0 * H, H,
+                          1 if sink is not None else 0, dbias.data_ptr() + 4 * v0, 1 if sink_b is not None else 0,
                           _p(count), wgs, _stream())
 
-        if sink_b is not None and ASYNC_WGRAD and VOCAB_DW_SIDE_WGS > 0:
+        cuts = _vocab_dw_cuts(V) if (sink_b is not None and ASYNC_WGRAD and VOCAB_DW_BESIDE and dW.is_contiguous()
+                                      and bias.is_contiguous() and dbias.is_contiguous()) else None
+        if cuts is not None:
+            # Both gradients sink into the flat buffer and nothing downstream reads them before the optimizer.  The first
+            # rows run here on the whole chip; the other two ranges wait for the decoder's and the encoder's recurrence and
+            # run beside them, half the chip each (defer_beside_recurrence).
+            c1, c2 = cuts
+            if c1 > 0:
+                launch(0, 0, c1)
+            for k, (a, b) in enumerate(((c1, c2), (c2, V))):
+                t_r = t32 - a
+                held = (h_bf, w_bf, bias, t32, t_r, lse, gscale, count, dW, dbias)
+                defer_beside_recurrence(lambda wgs, a=a, b=b, k=k, t_r=t_r: launch(wgs, a, b, "vocab_fused_dw_r%d" % k, t_r),
+                                        keep=held)
+        elif sink_b is not None and ASYNC_WGRAD and VOCAB_DW_SIDE_WGS > 0:
             # both gradients sink into the flat buffer and nothing downstream reads them: off the critical path, on fewer
             # workgroups than CUs so that the latent stack's backward keeps the CUs it needs
             defer_after_recurrence(lambda: launch(VOCAB_DW_SIDE_WGS), keep=(h_bf, w_bf, bias, t32, lse, gscale, count, dW, dbias))
@@ -1077,11 +1180,13 @@ class GRULayer(torch.autograd.Function):
         if dout is not None:
             dout = dout if dout.stride(2) == 1 else dout.contiguous()
         dhn_c = None if dhn is None else dhn.contiguous()
-        join_side_work()        # the recurrence's workgroups wait for each other: nothing else may hold CUs
+        join_side_work()        # the recurrence's workgroups wait for each other: nothing else may hold CUs ...
+        beside = launch_beside_recurrence()      # ... but a long full-chip kernel that asked for it: half the chip each
         with timed("gru_bwd"):
             _lib.call("pv_gru_bwd", _p(dout), 0 if dout is None else dout.stride(0),
                       0 if dout is None else dout.stride(1), _p(dhn_c), _p(gsave), _p(hall), _p(whhT), L, B, H, 0,
-                      _p(dgi), _p(dgh), _p(dgx), _p(dh0), _p(dbp), _p(db_ih), _p(db_hh), _p(sync), GRU_MAX_WGS, _stream())
+                      _p(dgi), _p(dgh), _p(dgx), _p(dh0), _p(dbp), _p(db_ih), _p(db_hh), _p(sync),
+                      min(beside, GRU_MAX_WGS) if beside and GRU_MAX_WGS else (beside or GRU_MAX_WGS), _stream())
         LAST_GRU_SYNC.append((sync, NG, "pv_gru_bwd"))
         launch_after_recurrence()
         Tt = L * Bpad
@@ -1962,6 +2067,7 @@ class BlockGroupFn(torch.autograd.Function):
                 # the dx chain now; the parameter gradients (full-chip GEMMs into the gradient sinks, nothing downstream reads
                 # them) later on the side stream, beside the next Blocks' dx chains
                 _lib.call("pv_block_bwd_phase", C.byref(calls), len(live), 1, _stream())
+                flush_deferred()                    # the Blocks before this one: their GEMMs start beside this dx chain
                 nlive, held = len(live), (calls, keep, list(st), [douts[b] for b in live])
                 defer_side_work(lambda: _lib.call("pv_block_bwd_phase", C.byref(held[0]), nlive, 2, _stream()), keep=held)
             else:
