@@ -146,6 +146,12 @@ size_t pv_vocab_sample_ws_bytes(int T, int V);
 int pv_vocab_sample(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H, float inv_temp,
                     int mask_col, const float* noise_q, long noise_ld, const void* rng_state, int site,
                     void* workspace, int64_t* ids, float* logp, void* stream);
+/* Beam search's step without a [T][V] tensor (decoders.py:263-270: topk(beam) over cum_sum + the log-softmax rows): per row
+ * the k best columns != mask_col of the scaled logits (descending, lowest column first on ties) and their log-softmax
+ * values, ids / logp [T][k], 1 <= k <= 16.  Candidates come from the k slabs with the largest per-slab bests of the arg-max
+ * epilogue, whose 64 k logits are recomputed in fp32 from the bf16 operands.  workspace: pv_vocab_argmax_ws_bytes(T, V). */
+int pv_vocab_topk(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H, float inv_temp,
+                  int mask_col, int k, void* workspace, int64_t* ids, float* logp, void* stream);
 /* No counterpart in the reference: pv_vocab_argmax for callers that cannot allocate or pass a workspace (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  The per-slab partials live in a device array
  * built into the library (one copy per GPU, pv_vocab_argmax_noalloc_max_bytes() = 4 MiB, held until the process ends);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "pv_scatter_rows_scaled_drop_f32": (i32, [vp, vp, f32, vp, vp, i32, i32, vp, lng, i32, i32, lng, lng, f32, vp, vp, i32, vp]),
     "pv_vocab_argmax_ws_bytes": (sz, [i32, i32]),
     "pv_vocab_argmax": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp]),
+    "pv_vocab_topk": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp]),
     "pv_vocab_sample_ws_bytes": (sz, [i32, i32]),
     "pv_vocab_sample": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp, lng, vp, i32, vp, vp, vp, vp]),
     "pv_vocab_argmax_noalloc": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp, vp, vp]),

@@ -839,6 +839,113 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Beam search's step without a [rows, V] matrix (decoders.py:263-270: topk(beam) over cum_sum + log-softmax): the k best
+// symbols of every row and their log-probabilities.  The arg-max epilogue above already leaves, per 64-column slab, the
+// slab's best allowed value: the k best entries of a row lie inside the k slabs with the largest such values (any other slab
+// is dominated by k slabs that each hold an entry at least as large).  One workgroup per row: the log-sum-exp from the slab
+// partials, the k best slabs, their 64 k logits recomputed from the row's state (one wave per column: a coalesced 16-byte
+// read of the weight row per lane, fp32 accumulation), then the k best of those, lowest column first on ties.
+constexpr int TOPK_MAX = 16;
+__global__ __launch_bounds__(256) void vocab_topk_kernel(const ArgPart* __restrict__ part, int Tpad, int nslab,
+                                                         const bf16_t* __restrict__ h, int ldh, const bf16_t* __restrict__ W, int ldw,
+                                                         const float* __restrict__ bias, int V, int H, float inv_temp, int mask_col,
+                                                         int k, int64_t* __restrict__ ids, float* __restrict__ logp) {
+  extern __shared__ float tk_sm[];                    // [nslab] slab bests, then [H] the row's state, then [k * 64] candidates
+  __shared__ float red_v[4];
+  __shared__ int red_i[4];
+  __shared__ float red_m[4], red_s[4];
+  __shared__ int sel[TOPK_MAX];
+  float* sbest = tk_sm;
+  float* hrow = tk_sm + nslab;
+  float* cand = hrow + H;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // ---- log-sum-exp over the slabs; the slabs' best allowed values -------------------------------------------------------
+  float m = -INFINITY, sacc = 0.f;
+  for (int sl = tid; sl < nslab; sl += 256) {
+    const ArgPart p = part[(size_t)sl * Tpad + row];
+    const float mn = fmaxf(m, p.m);
+    sacc = (m == -INFINITY ? 0.f : sacc * __expf(m - mn)) + (p.m == -INFINITY ? 0.f : p.s * __expf(p.m - mn));
+    m = mn;
+    sbest[sl] = p.idx >= 0 ? p.best : -INFINITY;
+  }
+  for (int c = tid; c < H; c += 256) hrow[c] = bf2f(h[(size_t)row * ldh + c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(sacc, o);
+    const float mn = fmaxf(m, m2);
+    sacc = (m == -INFINITY ? 0.f : sacc * __expf(m - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+    m = mn;
+  }
+  if (lane == 0) { red_m[w] = m; red_s[w] = sacc; }
+  __syncthreads();
+  float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3])), S = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) S += red_m[i] == -INFINITY ? 0.f : red_s[i] * __expf(red_m[i] - M);
+  const float lse = M + __logf(S);
+  // block-wide arg-max over arr[0, n): largest value, lowest index on ties; the winner is struck out
+  auto pick = [&](float* arr, int n, float& best_v) -> int {
+    float v = -INFINITY;
+    int at = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+      const float x = arr[i];
+      if (x > v) { v = x; at = i; }                  // ascending i: the first maximum wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(v, o);
+      const int a2 = __shfl_xor(at, o);
+      if (v2 > v || (v2 == v && a2 < at)) { v = v2; at = a2; }
+    }
+    __syncthreads();                                   // (red_* of the round before have been read)
+    if (lane == 0) { red_v[w] = v; red_i[w] = at; }
+    __syncthreads();
+    v = red_v[0];
+    at = red_i[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (red_v[i] > v || (red_v[i] == v && red_i[i] < at)) { v = red_v[i]; at = red_i[i]; }
+    best_v = v;
+    if (tid == 0 && at != 0x7fffffff) arr[at] = -INFINITY;
+    __syncthreads();
+    return at;
+  };
+  const int ks = min(k, nslab);
+  for (int j = 0; j < ks; ++j) {
+    float bv;
+    const int at = pick(sbest, nslab, bv);
+    if (tid == 0) sel[j] = (at == 0x7fffffff || bv == -INFINITY) ? -1 : at;
+  }
+  __syncthreads();
+  // ---- the candidates: 64 columns of each chosen slab, one wave per column -------------------------------------------------
+  for (int c = w; c < ks * 64; c += 4) {
+    const int sl = sel[c >> 6], col = sl * 64 + (c & 63);
+    float x = -INFINITY;
+    if (sl >= 0 && col < V && col != mask_col) {       // (wave-uniform)
+      const bf16_t* wr = W + (size_t)col * ldw;
+      float acc = 0.f;
+      for (int p8 = lane * 8; p8 < H; p8 += 512) {
+        const bf16x8 wv = *(const bf16x8*)(wr + p8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf((float)wv[e], hrow[p8 + e], acc);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      x = (acc + bias[col]) * inv_temp;
+    }
+    if (lane == 0) cand[c] = x;
+  }
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {
+    float bv;
+    const int at = pick(cand, ks * 64, bv);
+    if (tid == 0) {
+      const bool ok = at != 0x7fffffff && bv > -INFINITY;
+      ids[(size_t)row * k + j] = ok ? (int64_t)sel[at >> 6] * 64 + (at & 63) : 0;
+      logp[(size_t)row * k + j] = ok ? bv - lse : -INFINITY;
+    }
+  }
+}
+
 // ---- scratch of pv_vocab_argmax_noalloc: one array per GPU, held until the process ends ----------------------------
 constexpr size_t ARGMAX_SCRATCH_BYTES = 4u << 20;      // e.g. 256 rows x 65 536 symbols, or 1 024 rows x 16 384
 static __device__ __align__(256) unsigned char scratch[ARGMAX_SCRATCH_BYTES];
@@ -1126,6 +1233,27 @@ int pv_vocab_argmax(const void* h, int ldh, const void* W, int ldw, const float*
   hipLaunchKernelGGL(vocab_argmax_reduce_kernel, dim3(cdiv(T, 16)), dim3(256), 0, st, (const ArgPart*)workspace,
                      (const float*)nullptr, T, Tpad, nslab, ids, logp);
   PV_LAUNCH_CHECK("vocab_argmax_reduce_kernel");
+  return PV_OK;
+}
+
+int pv_vocab_topk(const void* h, int ldh, const void* W, int ldw, const float* bias, int T, int V, int H, float inv_temp,
+                  int mask_col, int k, void* workspace, int64_t* ids, float* logp, void* stream) {
+  int rc = check_gemm(h, W, T, V, H, ldh, ldw, "pv_vocab_topk");
+  if (rc) return rc;
+  PV_REQUIRE(bias && workspace && ids && logp, "pv_vocab_topk: null argument");
+  PV_REQUIRE(k >= 1 && k <= TOPK_MAX, "pv_vocab_topk: k = %d outside 1..%d", k, TOPK_MAX);
+  PV_REQUIRE(H % 8 == 0 && ldw % 8 == 0, "pv_vocab_topk: H and ldw must be multiples of 8 (16-byte weight reads)");
+  const int Tpad = round_up(T, 64), nslab = cdiv(V, 64);
+  const size_t lds = ((size_t)nslab + H + (size_t)k * 64) * sizeof(float);
+  PV_REQUIRE(lds <= 60 * 1024, "pv_vocab_topk: V = %d, H = %d need %zu bytes of LDS (limit 60 KiB)", V, H, lds);
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g{(const bf16_t*)h, (const bf16_t*)W, T, V, H, ldh, ldw, 1, 0, nullptr, nullptr};
+  EpiArgmax e{bias, (ArgPart*)workspace, T, V, Tpad, mask_col, inv_temp};
+  rc = launch(g, e, st, "pv_vocab_topk");
+  if (rc) return rc;
+  hipLaunchKernelGGL(vocab_topk_kernel, dim3(T), dim3(256), lds, st, (const ArgPart*)workspace, Tpad, nslab, (const bf16_t*)h, ldh,
+                     (const bf16_t*)W, ldw, bias, V, H, inv_temp, mask_col, k, ids, logp);
+  PV_LAUNCH_CHECK("vocab_topk_kernel");
   return PV_OK;
 }
 

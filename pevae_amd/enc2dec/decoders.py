@@ -271,10 +271,11 @@ class DecoderRNN(BaseRNN):
                 and torch.is_tensor(init_state) and self.rnn.cell == "gru" and self.rnn.num_layers == 1
                 and not self.rnn.bidirectional):
             return self._persistent_greedy(batch_size, inputs, init_state, latent_variable)
-        if (mode == GEN and gen_type == 'greedy' and getattr(self, "graph_decode", False)
+        if (mode == GEN and (gen_type == 'greedy' or (gen_type == 'sample' and getattr(self, "sample_noise", None) is None))
+                and getattr(self, "graph_decode", False)
                 and getattr(self, "fused_greedy", False) and not self.training and not torch.is_grad_enabled()
                 and attn_context is None and not self.use_attention and torch.is_tensor(init_state)):
-            return self._graphed_greedy(batch_size, inputs, init_state, latent_variable)
+            return self._graphed_greedy(batch_size, inputs, init_state, latent_variable, gen_type)
         ret_dict = dict()
         self.max_length = inputs.size(1)                # decoders.py:201 (GEN still needs `inputs` for this)
         if self.use_attention:
@@ -320,6 +321,7 @@ class DecoderRNN(BaseRNN):
         else:
             step_outputs, cum_sum = [], None
             fused = getattr(self, "fused_greedy", False) and gen_type in ('greedy', 'sample')
+            fused_beam = getattr(self, "fused_greedy", False) and gen_type == 'beam' and beam_size <= ops.VOCAB_TOPK_MAX
             if fused and gen_type == 'sample' and getattr(self, "sample_noise", None) is None:
                 ops.rng_advance(dev)                 # a new decode draws new symbols; token di is call site SAMPLE_SITE + di
             # the projection / recurrence weights are packed to bf16 once for the whole decode, not once per token
@@ -345,6 +347,36 @@ class DecoderRNN(BaseRNN):
                                                            self.unk_id if self.mask_unk else -1)
                         symbols = symbols.view(-1, 1)
                         step_outputs.append(lp.view(-1, 1))
+                        if self.use_attention:
+                            ret_dict[DecoderRNN.KEY_ATTN_SCORE].append(step_attn)
+                        sequence_symbols.append(symbols)
+                        decoder_input = symbols
+                        continue
+                    if fused_beam:
+                        # opt-in (self.fused_greedy = True): the beam step without [B * beam, V] rows.  Per row the `beam` best
+                        # symbols and their log-probabilities come out of the projection GEMM's slab epilogue
+                        # (ops.vocab_topk); the beam * beam candidates of a batch element are ranked here.  Everything else
+                        # as below (:263-270): symbols / back pointers per step, states NOT re-ordered, as in the reference.
+                        output, decoder_hidden, step_attn, _ = self._hidden_states(decoder_input, decoder_hidden,
+                                                                                   attn_context, latent_variable)
+                        w, b = self._out_weights()
+                        k = beam_size
+                        ids_k, lp_k = ops.vocab_topk(output.reshape(-1, output.shape[-1]), w, b, k,
+                                                     1.0 / self.softmax_temperature, self.unk_id if self.mask_unk else -1)
+                        if di == 0:              # all beams hold the same state: the first beam's row (:264 [:, 0:V])
+                            top_v = lp_k.view(batch_size, beam_size, k)[:, 0]
+                            symbols = ids_k.view(batch_size, beam_size, k)[:, 0].reshape(-1, 1)
+                            back = torch.zeros((batch_size * beam_size, 1), dtype=torch.long, device=dev)
+                            emitted = top_v
+                        else:
+                            cand = (cum_sum.view(batch_size, beam_size, 1) + lp_k.view(batch_size, beam_size, k))
+                            top_v, pos = cand.view(batch_size, beam_size * k).topk(beam_size)
+                            back = torch.div(pos, k, rounding_mode='floor').view(-1, 1)
+                            symbols = ids_k.view(batch_size, beam_size * k).gather(1, pos).view(-1, 1)
+                            emitted = lp_k.view(batch_size, beam_size * k).gather(1, pos)
+                        back_pointers.append(back)
+                        cum_sum = top_v.reshape(-1, 1)
+                        step_outputs.append(emitted.reshape(-1, 1))
                         if self.use_attention:
                             ret_dict[DecoderRNN.KEY_ATTN_SCORE].append(step_attn)
                         sequence_symbols.append(symbols)
@@ -400,14 +432,16 @@ class DecoderRNN(BaseRNN):
         ret_dict[DecoderRNN.KEY_LENGTH] = lengths if getattr(self, "_device_lengths", False) else lengths.tolist()
         return decoder_outputs, decoder_hidden, ret_dict
 
-    def _graphed_greedy(self, batch_size, inputs, init_state, latent_variable):
+    def _graphed_greedy(self, batch_size, inputs, init_state, latent_variable, gen_type='greedy'):
         """Opt-in (self.graph_decode = self.fused_greedy = True, eval mode, no grad, GRU cell, no attention): the whole
-        free-running greedy decode -- max_length x (embedding, input projection, one recurrence step, projection +
-        arg-max) -- captured once per (batch, length) into a HIP graph and replayed; the only host work per decode is the
-        copy of the initial state in and one read-back of the lengths.  Weights are re-packed inside the graph, so a
-        replay follows parameter updates.  Same return value as the fused greedy path."""
+        free-running greedy (or `sample`) decode -- max_length x (embedding, input projection, one recurrence step,
+        projection + arg-max / multinomial draw) -- captured once per (batch, length) into a HIP graph and replayed; the only
+        host work per decode is the copy of the initial state in and one read-back of the lengths.  Weights are re-packed
+        inside the graph, so a replay follows parameter updates; the sampler's step counter lives in device memory and
+        is advanced inside the graph, so every replay of a `sample` decode draws anew.  Same return value as the fused
+        per-token path."""
         L = inputs.size(1)
-        key = (batch_size, L, tuple(init_state.shape), None if latent_variable is None else tuple(latent_variable.shape))
+        key = (gen_type, batch_size, L, tuple(init_state.shape), None if latent_variable is None else tuple(latent_variable.shape))
         cache = self.__dict__.setdefault("_decode_graphs", {})
         ent = cache.get(key)
         if ent is None:
@@ -416,11 +450,11 @@ class DecoderRNN(BaseRNN):
             width = torch.zeros((batch_size, L), dtype=torch.long, device=st.device)     # only its width is read
             self.graph_decode, self._device_lengths = False, True
             try:
-                self.forward(batch_size, width, st, None, GEN, 'greedy', 1, lt)            # warm-up: every workspace exists
+                self.forward(batch_size, width, st, None, GEN, gen_type, 1, lt)             # warm-up: every workspace exists
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    outs, hid, ret = self.forward(batch_size, width, st, None, GEN, 'greedy', 1, lt)
+                    outs, hid, ret = self.forward(batch_size, width, st, None, GEN, gen_type, 1, lt)
                     seq = torch.cat(ret[DecoderRNN.KEY_SEQUENCE], dim=1)
                     lens = ret[DecoderRNN.KEY_LENGTH]
             finally:

@@ -954,6 +954,24 @@ def vocab_argmax(hid, weight, bias, inv_temp=1.0, mask_col=-1):
         return ids, logp
 
 
+VOCAB_TOPK_MAX = 16
+
+
+def vocab_topk(hid, weight, bias, k, inv_temp=1.0, mask_col=-1):
+    """The k best symbols per row of hid [T,H] and their log-probabilities (the rows beam search ranks, decoders.py:263-270)
+    without a [T,V] tensor.  -> (ids int64 [T,k], logp fp32 [T,k], descending); no gradient."""
+    with torch.no_grad():
+        _need_cuda(hid, weight, bias)
+        T, H, V, Hp, h_bf, ldh, w_bf = _vocab_operands(hid, weight)
+        dev = weight.device
+        ws = workspace("vocab_argmax", _lib.load().pv_vocab_argmax_ws_bytes(T, V), torch.uint8, dev)
+        ids = torch.empty((T, k), dtype=torch.int64, device=dev)
+        logp = torch.empty((T, k), dtype=torch.float32, device=dev)
+        _lib.call("pv_vocab_topk", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias.contiguous()), T, V, Hp, inv_temp, int(mask_col), int(k),
+                  _p(ws), _p(ids), _p(logp), _stream())
+        return ids, logp
+
+
 def vocab_sample(hid, weight, bias, inv_temp=1.0, mask_col=-1, noise=None, site=0):
     """One multinomial draw per row of hid [T,H] from softmax((hid W^T + b) * inv_temp) (decoders.py:255-256 ->
     base_modules.py:54-59) without a [T,V] tensor: arg-max of (scaled logit - log q), q ~ Exp(1).  noise [T,V]: the q draws

@@ -376,6 +376,38 @@ def test_decoder_gen_graphed_greedy(dev):
     assert len(dec._decode_graphs) == 1
 
 
+def test_decoder_gen_graphed_sample(dev):
+    """graph_decode with gen_type 'sample': the whole sampling decode replayed from one HIP graph.  From the same generator
+    state a replay draws exactly what the eager fused path draws (the step counter is advanced inside the graph); the next
+    replay draws anew; symbols stay inside the vocabulary and a masked <unk> never appears."""
+    from pevae_amd.enc2dec import decoders as D
+    from pevae_amd import ops
+    g = load_golden("decoder_gen_sample")
+    V, L, E, H, B = 37, 7, 12, 16, 4
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb, mask_unk=True), g).to(dev)
+    dec.eval()
+    dec.fused_greedy = True
+    ids, h0 = T(g["ids"], dev), T(g["h0"], dev)
+    rng = ops.rng_state(dev)
+    with torch.no_grad():
+        dec.graph_decode = True
+        dec(B, ids, h0, mode=D.GEN, gen_type="sample")                      # warm-up + capture + first replay
+        for trial in range(2):
+            before = rng.clone()
+            dec.graph_decode = False
+            lp_e, _, ret_e = dec(B, ids, h0, mode=D.GEN, gen_type="sample")
+            rng.copy_(before)
+            dec.graph_decode = True
+            lp_g, _, ret_g = dec(B, ids, h0, mode=D.GEN, gen_type="sample")
+            seq_e, seq_g = torch.cat(ret_e["sequence"], 1), torch.cat(ret_g["sequence"], 1)
+            assert torch.equal(seq_e, seq_g) and torch.equal(lp_e, lp_g) and ret_e["length"] == ret_g["length"]
+            assert int(seq_g.min()) >= 0 and int(seq_g.max()) < V and not bool((seq_g == dec.unk_id).any())
+        seq_next = torch.cat(dec(B, ids, h0, mode=D.GEN, gen_type="sample")[2]["sequence"], 1)
+        assert not torch.equal(seq_next, seq_g)                              # the next replay: new draws
+    assert len(dec._decode_graphs) == 1
+
+
 @pytest.mark.parametrize("mask_unk", [False, True])
 def test_decoder_gen_persistent_greedy_golden(dev, mask_unk):
     """Opt-in persistent_decode (pv_greedy_decode: all tokens in one launch) on the reference's own greedy run: the emitted
@@ -566,6 +598,80 @@ def test_decoder_gen_beam_golden(dev):
         if margin > 0.1:
             assert torch.equal(seq, want) and ret["length"] == g["length"].tolist()
     assert seq.shape == want.shape and float((seq == want).float().mean()) >= 0.6
+
+
+def test_decoder_gen_fused_beam(dev):
+    """Opt-in fused beam step (pv_vocab_topk: per row the `beam` best symbols from the projection GEMM's slab epilogue, no
+    [B * beam, V] rows): the same raw beam symbols, back-tracked 1-best sequences and lengths as the dense path (which is
+    checked against the reference's golden above), per-symbol log-probabilities equal to the dense rows' entries; and
+    against the golden itself under the same margin rule."""
+    from pevae_amd.enc2dec import decoders as D
+    g = load_golden("decoder_gen_beam")
+    V, L, E, H, B, beam = 37, 7, 12, 16, 4, int(g["beam"])
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb), g).to(dev)
+    dec.eval()
+    for mask_unk in (False, True):
+        dec.mask_unk = mask_unk
+        with torch.no_grad():
+            dec.fused_greedy = False
+            logp, _, ret = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="beam", beam_size=beam)
+            dec.fused_greedy = True
+            lp_f, _, ret_f = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="beam", beam_size=beam)
+        seq, seq_f = torch.cat(ret["sequence"], 1).cpu(), torch.cat(ret_f["sequence"], 1).cpu()
+        assert tuple(lp_f.shape) == (B * beam, L) and seq_f.shape == seq.shape
+        # the dense path ranks fp32 rows of the same bf16 products: only near-ties of cumulative scores may reorder beams
+        lp = logp.cpu()
+        margin = min(float(lp[r, t].topk(beam + 1)[0][beam - 1] - lp[r, t].topk(beam + 1)[0][beam])
+                     for r in range(B * beam) for t in range(L))
+        if margin > 1e-3:
+            assert torch.equal(seq_f, seq) and ret_f["length"] == ret["length"]
+        assert float((seq_f == seq).float().mean()) >= 0.9
+        if mask_unk:
+            assert not bool((seq_f == dec.unk_id).any())
+    want = T(g["seq"])
+    dec.mask_unk = False
+    with torch.no_grad():
+        _, _, ret_f = dec(B, T(g["ids"], dev), T(g["h0"], dev), mode=D.GEN, gen_type="beam", beam_size=beam)
+    assert float((torch.cat(ret_f["sequence"], 1).cpu() == want).float().mean()) >= 0.6
+
+
+def test_vocab_topk_large(dev):
+    """pv_vocab_topk at the step's vocabulary (V = 20004, ragged last slab), k = 10 and 16, with and without a masked column,
+    against torch.topk on the log-softmax of the same bf16 operands: same symbols in the same order up to near-ties, same
+    log-probabilities; k = 1 agrees with pv_vocab_argmax."""
+    from pevae_amd import ops
+    gen = torch.Generator().manual_seed(10)
+    Tn, H, V = 160, 512, 20004
+    hid = (torch.randn(Tn, H, generator=gen) * 0.5).to(torch.bfloat16).float()
+    W = torch.randn(V, H, generator=gen) * 0.05
+    W[5000:5064] *= 3.0                                   # one slab holds several of a row's best entries
+    W = W.to(torch.bfloat16).float()
+    b = torch.randn(V, generator=gen) * 0.1
+    ref = torch.log_softmax((hid.double() @ W.double().t() + b.double()) / 0.7, -1)
+    for k, mask in ((10, -1), (16, 5003), (1, -1)):
+        r = ref.clone()
+        if mask >= 0:
+            r[:, mask] = -float("inf")
+        want_lp, want_id = r.topk(k, -1)
+        ids, lp = ops.vocab_topk(hid.to(dev), W.to(dev), b.to(dev), k, 1.0 / 0.7, mask)
+        ids, lp = ids.cpu(), lp.cpu()
+        assert ids.shape == (Tn, k)
+        np.testing.assert_allclose(lp.numpy(), want_lp.float().numpy(), rtol=0, atol=2e-3)
+        for t in range(Tn):
+            for j in range(k):                    # a flip is legitimate only between near-equal candidates
+                if ids[t, j] != want_id[t, j]:
+                    assert abs(float(want_lp[t, j] - r[t, ids[t, j]])) < 1e-3, (t, j)
+            assert len(set(ids[t].tolist())) == k and (mask < 0 or mask not in ids[t].tolist())
+        if k == 1:
+            ids1, lp1 = ops.vocab_argmax(hid.to(dev), W.to(dev), b.to(dev), 1.0 / 0.7, mask)
+            agree = (ids1.cpu() == ids[:, 0])
+            assert float(agree.float().mean()) > 0.98
+            np.testing.assert_allclose(lp1.cpu().numpy(), lp[:, 0].numpy(), rtol=0, atol=1e-4)
+    # a vocabulary smaller than k slabs, and k larger than the allowed columns of a tiny vocabulary
+    ids, lp = ops.vocab_topk(hid[:8, :64].contiguous().to(dev), W[:70, :64].contiguous().to(dev), b[:70].to(dev), 16, 1.0, -1)
+    r = torch.log_softmax(hid[:8, :64].double() @ W[:70, :64].double().t() + b[:70].double(), -1)
+    np.testing.assert_allclose(lp.cpu().numpy(), r.topk(16, -1)[0].float().numpy(), rtol=0, atol=2e-3)
 
 
 def test_vocab_argmax_large(dev):
