@@ -207,8 +207,11 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
   const int Hk = NKS_C ? NKS_C * 32 : a.Hk, H = a.H, nch = Hk / 8, mask = swz_mask_for(nch), NKS = Hk / 32;
   char* wl = smem;                                            // [NGT*U][Hk] bf16, swizzled
   bf16_t* tile = (bf16_t*)(smem + (size_t)NGT * U * Hk * 2);  // [RW][U] bf16: h_t of this slice
-  float* sg = (float*)(tile + RW * U);                      // [4][U][RW] fp32: r, z, n, hn | i, f, g, o (row fastest)
-  float* shv = sg + 4 * U * RW;                             // [RW][U] fp32: h_t
+  // [4][U][SGP] fp32: r, z, n, hn | i, f, g, o (row fastest).  SGP = RW + 4: the 16 lanes of a gate write (one unit each, 16
+  // bytes) would all start in the same bank at a row pitch of RW floats
+  constexpr int SGP = RW + 4;
+  float* sg = (float*)(tile + RW * U);
+  float* shv = sg + 4 * U * SGP;                            // [RW][U] fp32: h_t
   float* scv = shv + RW * U;                                // [RW][U] fp32: c_t (LSTM only)
   char* al = (char*)(scv + (LSTM ? RW * U : 0));            // [RW][Hk] bf16, swizzled: h_{t-1} of the group (a_lds)
 
@@ -426,10 +429,10 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
           if constexpr (LSTM) scv[(lr + j) * U + lu] = cv[j];
         }
         if (a.gsaveT) {
-          *(float4*)(sg + (0 * U + lu) * RW + lr) = make_float4(rr[0], rr[1], rr[2], rr[3]);
-          *(float4*)(sg + (1 * U + lu) * RW + lr) = make_float4(zz[0], zz[1], zz[2], zz[3]);
-          *(float4*)(sg + (2 * U + lu) * RW + lr) = make_float4(nn[0], nn[1], nn[2], nn[3]);
-          *(float4*)(sg + (3 * U + lu) * RW + lr) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+          *(float4*)(sg + (0 * U + lu) * SGP + lr) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+          *(float4*)(sg + (1 * U + lu) * SGP + lr) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+          *(float4*)(sg + (2 * U + lu) * SGP + lr) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+          *(float4*)(sg + (3 * U + lu) * SGP + lr) = make_float4(hn[0], hn[1], hn[2], hn[3]);
         }
       }
       STAMP(9);
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(NT_F, 2) void gru_fwd_kernel(GruFwdArgs a) {
             const int i = sid + k * NSTORE;          // float4 index into sg: [(q*U + unit)][row/4]
             if (i < NG4) {
               const int qu = i / (RW / 4), r4 = i % (RW / 4), q = qu / U, lu = qu % U;
-              *(float4*)(a.gsaveT + (((size_t)t * 4 + q) * H + u0 + lu) * a.Bpad + row0 + r4 * 4) = *(const float4*)(sg + i * 4);
+              *(float4*)(a.gsaveT + (((size_t)t * 4 + q) * H + u0 + lu) * a.Bpad + row0 + r4 * 4) = *(const float4*)(sg + qu * SGP + r4 * 4);
             }
           }
         }
@@ -997,7 +1000,7 @@ int rnn_fwd(int ngt, const float* xprojT, long ldx, const void* whh_bf16, const 
   int UT = (H % 32 == 0) ? 2 : 1;
   // the weight slice, the staging areas and (preferably) the shared h_{t-1} copy must fit the 160 KiB LDS
   const size_t nstage = ngt == 4 ? 6 : 5;
-  if (UT == 2 && (size_t)ngt * 32 * Hk * 2 + ROWS * 32 * 2 + nstage * 32 * ROWS * 4 + (ngt == 4 ? (size_t)ROWS * Hk * 2 : 0) > 160 * 1024) UT = 1;
+  if (UT == 2 && (size_t)ngt * 32 * Hk * 2 + ROWS * 32 * 2 + nstage * 32 * ROWS * 4 + 4 * 32 * 4 * 4 + (ngt == 4 ? (size_t)ROWS * Hk * 2 : 0) > 160 * 1024) UT = 1;
   const int U = UT * 16, S = H / U;
   const int cap = max_wgs > 0 ? max_wgs : cu_count();
   PV_REQUIRE(S <= cap, "pv_gru_fwd: %d unit slices exceed the %d co-resident workgroups available", S, cap);
@@ -1026,7 +1029,7 @@ int rnn_fwd(int ngt, const float* xprojT, long ldx, const void* whh_bf16, const 
     hipLaunchKernelGGL(lstm_pack_c0_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, c0, B, H, cn, call);
     PV_LAUNCH_CHECK("lstm_pack_c0_kernel");
   }
-  const size_t smem_base = (size_t)ngt * U * Hk * 2 + (size_t)RW * U * 2 + nstage * U * RW * 4,
+  const size_t smem_base = (size_t)ngt * U * Hk * 2 + (size_t)RW * U * 2 + nstage * U * RW * 4 + (size_t)4 * U * 4 * 4,   // (+ the pitch padding of sg)
                smem_a = (size_t)RW * Hk * 2;
   const int a_lds = smem_base + smem_a <= 160 * 1024;       // share the group's h_{t-1} through LDS when it fits
   const size_t smem = smem_base + (a_lds ? smem_a : 0);
