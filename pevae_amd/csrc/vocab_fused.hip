@@ -108,9 +108,13 @@ __device__ __forceinline__ int phase_sorted_range(long N, int G, int period, int
 // matrix are outside the descriptor and arrive as zeros: no address is clamped) -- issued ONE piece at a time between the
 // MFMAs of the item before (an LDS-DMA piece costs its wave 60-90 cycles of issue; back to back at the head of an item they
 // were 15 % of the kernel).
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// The buffer descriptor as four plain words (base, base high | stride 0, bytes, format word): the asm below wants it in
+// SGPRs, and with an opaque descriptor type hipcc once kept a loop-invariant descriptor in VGPRs under scalar-register
+// pressure (the assembler then rejects the instruction).  As words each one can be broadcast where it is used.
+typedef unsigned int rsrc_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, long bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+  const unsigned long long b = (unsigned long long)p;
+  return rsrc_t{(unsigned)b, (unsigned)(b >> 32) & 0xffffu, (unsigned)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000u};
 }
 // One LDS-DMA piece, issued from asm: hipcc must assume that an LDS-DMA builtin in flight aliases every later LDS read of the
 // one dynamic LDS array and puts s_waitcnt vmcnt(0) in front of those reads -- each piece then cost its wave a full
@@ -119,7 +123,10 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, long bytes) {
 // destination and is restored (the compiler does not expect it to change).  SIZE: 16 or 4 bytes per lane.
 template <int SIZE>
 __device__ __forceinline__ void lds_dma(rsrc_t src, int voff, const void* lds_dst) {
-  const unsigned dst = (unsigned)(unsigned long)(lptr_t)lds_dst;
+  // (wave-uniform by construction; the explicit broadcast keeps it in an SGPR where hipcc's divergence analysis gives up)
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lptr_t)lds_dst);
+  src = rsrc_t{(unsigned)__builtin_amdgcn_readfirstlane(src.x), (unsigned)__builtin_amdgcn_readfirstlane(src.y),
+               (unsigned)__builtin_amdgcn_readfirstlane(src.z), (unsigned)__builtin_amdgcn_readfirstlane(src.w)};
   unsigned keep;
   if constexpr (SIZE == 16)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
@@ -303,6 +310,7 @@ __device__ __forceinline__ void half_tile_landed() {
 #define PV_DEPTH 6
 #endif
 constexpr int DEPTH = PV_DEPTH;
+constexpr int DECIDE_AT = 34;      // the step of a second product beside which the forward kernel decides about the maximum
 // =====================================================================================================================
 // forward + dH:  per row t   lse, target logit, O[t] = sum_v exp(s_tv - m) W[v]  (partial over a vocabulary range)
 // =====================================================================================================================
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
       f32x16 XA, XB;
       // the bias rides in as the initial accumulator: X = bias + W h^T needs no add pass (element j of a lane: row
       // 8 (j >> 2) + 4 hh + (j & 3) of the sub-tile)
-      auto init_x = [&](f32x16& X, int sub) {
+      auto init_x = [&](f32x16& X, int sub) __attribute__((always_inline)) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const f32x4 b4 = *(const f32x4*)(bias_t + 32 * sub + 8 * g4 + 4 * hh);
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
       PV_SCHED_FENCE();
 
       // one step of the stream: request the fragment of step i + DEPTH, run MFMA i, now and then issue a staging piece
-      auto mfma_step = [&](auto I) {
+      auto mfma_step = [&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         using M = StepMap<i>;
         if constexpr (i + DEPTH == 64) half_tile_landed();       // sub-tile B, ahead of the stream's first read of it
@@ -423,15 +431,18 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
         }
       };
       // element J of an accumulator -> probability at the maximum in use, its row sum, bf16
-      auto exp_elem = [&](f32x16& X, bf16x8 (&pf)[2], auto J) {
+      auto exp_elem = [&](f32x16& X, bf16x8 (&pf)[2], auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
         const float p = __builtin_amdgcn_exp2f(fmaf(X[j], c_l2, -m_used));   // <= 2^RESCALE_THR; masked columns: 2^(-huge) = 0
         l_sum += p;
         pf[j >> 3][j & 7] = (__bf16)p;
       };
       // what stands between a sub-tile's first product and its transform: no MFMA runs beside this section
-      auto decide = [&](f32x16& X, int vs, bf16x8 (&pending)[2], bool nothing_yet) {
+      auto decide = [&](f32x16& X, int vs, bf16x8 (&pending)[2], bool nothing_yet) __attribute__((always_inline)) {
+        // (no wait for X here: two further MFMA steps -- 64+ cycles of the matrix pipe -- have been issued since its last one)
+#ifdef PV_DBG_WAITX
         mfma_v_done(X);
+#endif
         // ---- rare, wave-uniform: columns past V (the last tile) and the target pick (a row of this wave has its target here)
         if (__builtin_expect(vs + 32 > a.V || __any((unsigned)(y - vs) < 32u), 0)) {
 #pragma unroll
@@ -479,13 +490,17 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
       // ---- steps 0..31: first product of A ------------------------------------------------------------------------------------
       static_for<0, 32>([&](auto I) { mfma_step(I); PV_SCHED_FENCE(); });
       PV_STAMP(2)
-      decide(XA, v0, pfB, k == 0);
-      PV_STAMP(3)
-      // ---- steps 32..63: second product of the sub-tile before | transform of A; B's bias into its accumulator near the end ----
+      // ---- steps 32..63: second product of the sub-tile before.  Beside it: from its third step on (the first product's last
+      // MFMA has left the pipe by then) the decision about A's maximum, then A's transform; B's bias into its accumulator near
+      // the end.  The decision used to stand BETWEEN the two products, a stretch with no MFMA in flight; a rescale it asks for
+      // (rare) waits for the second product's MFMAs in flight and scales O between two of its steps -- the products already
+      // added are scaled with O, the ones to come use the scaled pending probabilities: the same sum.
       static_for<32, 64>([&](auto I) {
         constexpr int i = decltype(I)::value;
         mfma_step(I);
-        if constexpr ((i & 1) == 0) exp_elem(XA, pfA, std::integral_constant<int, (i - 32) / 2>{});
+        if constexpr (i == DECIDE_AT) decide(XA, v0, pfB, k == 0);
+        if constexpr (i > DECIDE_AT && (i & 1) == 1) exp_elem(XA, pfA, std::integral_constant<int, (i - DECIDE_AT - 1) / 2>{});
+        if constexpr (i == 62) exp_elem(XA, pfA, std::integral_constant<int, 15>{});
         if constexpr (i == 63) init_x(XB, 1);
         PV_SCHED_FENCE();
       });
@@ -493,13 +508,13 @@ __global__ __launch_bounds__(256, 1) void vocab_fwd_dh_kernel(FwdArgs a) {
       // ---- steps 64..95: first product of B ------------------------------------------------------------------------------------
       static_for<64, 96>([&](auto I) { mfma_step(I); PV_SCHED_FENCE(); });
       PV_STAMP(2)
-      decide(XB, v0 + 32, pfA, false);
-      PV_STAMP(3)
-      // ---- steps 96..127: second product of A | transform of B ------------------------------------------------------------------
+      // ---- steps 96..127: second product of A | decision about and transform of B -----------------------------------------------
       static_for<96, 128>([&](auto I) {
         constexpr int i = decltype(I)::value;
         mfma_step(I);
-        if constexpr ((i & 1) == 0) exp_elem(XB, pfB, std::integral_constant<int, (i - 96) / 2>{});
+        if constexpr (i == 64 + DECIDE_AT) decide(XB, v0 + 32, pfA, false);
+        if constexpr (i > 64 + DECIDE_AT && (i & 1) == 1) exp_elem(XB, pfB, std::integral_constant<int, (i - 64 - DECIDE_AT - 1) / 2>{});
+        if constexpr (i == 126) exp_elem(XB, pfB, std::integral_constant<int, 15>{});
         PV_SCHED_FENCE();
       });
       PV_STAMP(4)
@@ -726,7 +741,7 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
       static_for<0, DEPTH>([&](auto I) { f[decltype(I)::value & 7] = item_frag<decltype(I)::value>(smem, fb, dprev, fa); });
       PV_SCHED_FENCE();
 
-      auto mfma_step = [&](auto I) {
+      auto mfma_step = [&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         using M = StepMap<i>;
         if constexpr (i + DEPTH == 64) half_tile_landed();
@@ -751,7 +766,7 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
       f32x4 l4, g4;
       int4 y4;
       float p_half;
-      auto elem_a = [&](int sub, auto J) {
+      auto elem_a = [&](int sub, auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
 #ifndef PV_ABL_NOEXP
         if constexpr ((j & 3) == 0) {
@@ -767,7 +782,7 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
         p_half = X[j];
 #endif
       };
-      auto elem_b = [&](bf16x8 (&pf)[2], auto J) {
+      auto elem_b = [&](bf16x8 (&pf)[2], auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
 #ifndef PV_ABL_NOEXP
         const int yy = (j & 3) == 0 ? y4.x : (j & 3) == 1 ? y4.y : (j & 3) == 2 ? y4.z : y4.w;
@@ -780,28 +795,37 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
         pf[j >> 3][j & 7] = (__bf16)q;
       };
       // ---- steps 0..31: first product of A; 32..63: second product of the sub-tile before | transform of A --------------------
+      // (the transform starts at the second product's third step: the first product's last MFMA has left the pipe by then, so
+      // no wait with an idle matrix pipe stands between the two products; the two halves of an element alternate, the last two
+      // steps take two halves each)
       static_for<0, 32>([&](auto I) { mfma_step(I); PV_SCHED_FENCE(); });
       PV_STAMP(2)
-      mfma_v_done(X);
-      PV_STAMP(3)
       static_for<32, 64>([&](auto I) {
-        constexpr int i = decltype(I)::value;
+        constexpr int i = decltype(I)::value, sl = i - 34;
         mfma_step(I);
-        if constexpr ((i & 1) == 0) elem_a(0, std::integral_constant<int, (i - 32) / 2>{});
-        else elem_b(pfA, std::integral_constant<int, (i - 32) / 2>{});
+        if constexpr (sl >= 0 && sl < 28) {
+          if constexpr ((sl & 1) == 0) elem_a(0, std::integral_constant<int, sl / 2>{});
+          else elem_b(pfA, std::integral_constant<int, sl / 2>{});
+        } else if constexpr (sl >= 28) {
+          elem_a(0, std::integral_constant<int, sl - 14>{});
+          elem_b(pfA, std::integral_constant<int, sl - 14>{});
+        }
         PV_SCHED_FENCE();
       });
       PV_STAMP(4)
       // ---- steps 64..95: first product of B; 96..127: second product of A | transform of B ------------------------------------
       static_for<64, 96>([&](auto I) { mfma_step(I); PV_SCHED_FENCE(); });
       PV_STAMP(2)
-      mfma_v_done(X);
-      PV_STAMP(3)
       static_for<96, 128>([&](auto I) {
-        constexpr int i = decltype(I)::value;
+        constexpr int i = decltype(I)::value, sl = i - 98;
         mfma_step(I);
-        if constexpr ((i & 1) == 0) elem_a(1, std::integral_constant<int, (i - 96) / 2>{});
-        else elem_b(pfB, std::integral_constant<int, (i - 96) / 2>{});
+        if constexpr (sl >= 0 && sl < 28) {
+          if constexpr ((sl & 1) == 0) elem_a(1, std::integral_constant<int, sl / 2>{});
+          else elem_b(pfB, std::integral_constant<int, sl / 2>{});
+        } else if constexpr (sl >= 28) {
+          elem_a(1, std::integral_constant<int, sl - 14>{});
+          elem_b(pfB, std::integral_constant<int, sl - 14>{});
+        }
         PV_SCHED_FENCE();
       });
       PV_STAMP(4)
