@@ -259,11 +259,12 @@ def launch_beside_recurrence():
     s2.wait_stream(cur)
     st["busy2"] = True
     with torch.cuda.stream(s2):
-        fn(half)
+        fn(BESIDE_WGS or half)
     return half
 
 
 _HALF = {}
+BESIDE_WGS = int(os.environ.get("PEVAE_BESIDE_WGS", "0"))      # experiments: workgroups of the kernel beside the recurrence
 
 
 def _half_chip(dev):
