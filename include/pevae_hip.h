@@ -243,6 +243,14 @@ size_t pv_embedding_bwd_ws_bytes(int n, int D);
 int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n, int n1, int n1p, long s0, long s1,
                      long num_rows, int D, long padding_idx, int accumulate, float* dtable, void* workspace,
                      size_t ws_bytes, void* stream);
+/* The same in two calls, for callers that know the ids long before the gradient (embedding_dense_backward sorts inside the
+ * backward pass; the ids of a training step are known when it starts): pv_embedding_sort leaves the sorted (row id,
+ * gradient row) pairs in `workspace` (pv_embedding_bwd_ws_bytes(n, D) bytes, kept by the caller in between), pv_embedding_bwd_sorted
+ * does the segmented sum from them.  pv_embedding_bwd == the two back to back. */
+int pv_embedding_sort(const int64_t* ids, int n, int n1, int n1p, long s0, long s1, long num_rows, int D, void* workspace,
+                      size_t ws_bytes, void* stream);
+int pv_embedding_bwd_sorted(const float* grad_rows, int ldg, int n, long num_rows, int D, long padding_idx, int accumulate,
+                            float* dtable, void* workspace, size_t ws_bytes, void* stream);
 /* No counterpart in the reference (it is single-process): the data-parallel exchange of a table whose local gradient is
  * non-zero only in the n rows looked up this step (user / item tables, dialog_models.py:758-759), as (ids, rows) instead
  * of an all-reduce of the whole table.  pv_sparse_pack: occurrence r sends its id (as fp32, exact: num_rows <= 2^24) and

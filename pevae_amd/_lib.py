@@ -93,6 +93,8 @@ SIGNATURES = {
     "pv_embedding_gather": (i32, [vp, lng, i32, vp, i32, i32, i32, lng, lng, vp, i32, vp, i32, vp, vp]),
     "pv_embedding_bwd_ws_bytes": (sz, [i32, i32]),
     "pv_embedding_bwd": (i32, [vp, i32, vp, i32, i32, i32, lng, lng, lng, i32, lng, i32, vp, vp, sz, vp]),
+    "pv_embedding_sort": (i32, [vp, i32, i32, i32, lng, lng, lng, i32, vp, sz, vp]),
+    "pv_embedding_bwd_sorted": (i32, [vp, i32, i32, lng, i32, lng, i32, vp, vp, sz, vp]),
     "pv_sparse_pack": (i32, [vp, lng, i32, vp, i32, vp, vp, vp]),
     "pv_sparse_merge": (i32, [vp, i32, lng, i32, i32, lng, vp, vp]),
     "pv_cast_pack_bf16": (i32, [vp, i32, i32, i32, i32, lng, lng, lng, vp, i32, vp]),

@@ -297,25 +297,16 @@ size_t pv_embedding_bwd_ws_bytes(int n, int D) {
   return 4 * a + ((sort_temp_bytes(n) + 255) & ~(size_t)255) + 256 + ((size_t)(n / SEG_CH + 1) * D * sizeof(float));
 }
 
-int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n, int n1, int n1p, long s0, long s1,
-                     long num_rows, int D, long padding_idx, int accumulate, float* dtable, void* workspace,
-                     size_t ws_bytes, void* stream) {
-  PV_REQUIRE(grad_rows && ids && dtable && workspace, "pv_embedding_bwd: null argument");
-  PV_REQUIRE(n >= 0 && n1 > 0 && n1p >= n1 && D > 0 && ldg >= D, "pv_embedding_bwd: bad sizes");
-  PV_REQUIRE(ws_bytes >= pv_embedding_bwd_ws_bytes(n, D), "pv_embedding_bwd: workspace too small");
-  PV_REQUIRE(num_rows < (1l << 30), "pv_embedding_bwd: table rows must fit int32 sort keys");
-  hipStream_t st = (hipStream_t)stream;
-  if (!accumulate) PV_HIP(hipMemsetAsync(dtable, 0, (size_t)num_rows * D * sizeof(float), st));
-  if (n == 0) return PV_OK;
+// keys + stable sort of one lookup's (row id, occurrence) pairs into the workspace (sorted keys at 2a, sorted gradient-row
+// numbers at 3a, a = round_up(n, 64) ints)
+static int embedding_sort(const int64_t* ids, int n, int n1, int n1p, long s0, long s1, long num_rows, char* ws, hipStream_t st) {
   const size_t a = round_up(n, 64) * sizeof(int);
-  char* ws = (char*)workspace;
   int* keys = (int*)ws;
   int* vals = (int*)(ws + a);
   int* skeys = (int*)(ws + 2 * a);
   int* svals = (int*)(ws + 3 * a);
   void* temp = ws + 4 * a;
   size_t temp_bytes = sort_temp_bytes(n);
-  float* part = (float*)(ws + 4 * a + ((temp_bytes + 255) & ~(size_t)255) + 256);   // one row per multiple of SEG_CH
   int bits = 1;
   while ((1l << bits) <= num_rows && bits < 31) ++bits;
   static const int own_sort = getenv("PV_EMB_OWN_SORT") ? atoi(getenv("PV_EMB_OWN_SORT")) : 1;
@@ -335,6 +326,32 @@ int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n,
     PV_LAUNCH_CHECK("fill_keys_kernel");
     PV_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, skeys, vals, svals, n, 0, bits, st));
   }
+  return PV_OK;
+}
+
+int pv_embedding_sort(const int64_t* ids, int n, int n1, int n1p, long s0, long s1, long num_rows, int D, void* workspace,
+                      size_t ws_bytes, void* stream) {
+  PV_REQUIRE(ids && workspace, "pv_embedding_sort: null argument");
+  PV_REQUIRE(n >= 0 && n1 > 0 && n1p >= n1 && D > 0, "pv_embedding_sort: bad sizes");
+  PV_REQUIRE(ws_bytes >= pv_embedding_bwd_ws_bytes(n, D), "pv_embedding_sort: workspace too small");
+  PV_REQUIRE(num_rows < (1l << 30), "pv_embedding_sort: table rows must fit int32 sort keys");
+  if (n == 0) return PV_OK;
+  return embedding_sort(ids, n, n1, n1p, s0, s1, num_rows, (char*)workspace, (hipStream_t)stream);
+}
+
+int pv_embedding_bwd_sorted(const float* grad_rows, int ldg, int n, long num_rows, int D, long padding_idx, int accumulate,
+                            float* dtable, void* workspace, size_t ws_bytes, void* stream) {
+  PV_REQUIRE(grad_rows && dtable && workspace, "pv_embedding_bwd_sorted: null argument");
+  PV_REQUIRE(n >= 0 && D > 0 && ldg >= D, "pv_embedding_bwd_sorted: bad sizes");
+  PV_REQUIRE(ws_bytes >= pv_embedding_bwd_ws_bytes(n, D), "pv_embedding_bwd_sorted: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) PV_HIP(hipMemsetAsync(dtable, 0, (size_t)num_rows * D * sizeof(float), st));
+  if (n == 0) return PV_OK;
+  const size_t a = round_up(n, 64) * sizeof(int);
+  char* ws = (char*)workspace;
+  const int* skeys = (const int*)(ws + 2 * a);
+  const int* svals = (const int*)(ws + 3 * a);
+  float* part = (float*)(ws + 4 * a + ((sort_temp_bytes(n) + 255) & ~(size_t)255) + 256);   // one row per multiple of SEG_CH
   hipLaunchKernelGGL(segment_sum_kernel, dim3(cdiv(n, 4), cdiv(D, 64)), dim3(256), 0, st, skeys, svals, n, grad_rows, ldg, D,
                      num_rows, padding_idx, accumulate, dtable, part);
   PV_LAUNCH_CHECK("segment_sum_kernel");
@@ -344,6 +361,20 @@ int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n,
     PV_LAUNCH_CHECK("segment_combine_kernel");
   }
   return PV_OK;
+}
+
+int pv_embedding_bwd(const float* grad_rows, int ldg, const int64_t* ids, int n, int n1, int n1p, long s0, long s1,
+                     long num_rows, int D, long padding_idx, int accumulate, float* dtable, void* workspace,
+                     size_t ws_bytes, void* stream) {
+  PV_REQUIRE(grad_rows && ids && dtable && workspace, "pv_embedding_bwd: null argument");
+  PV_REQUIRE(n >= 0 && n1 > 0 && n1p >= n1 && D > 0 && ldg >= D, "pv_embedding_bwd: bad sizes");
+  PV_REQUIRE(ws_bytes >= pv_embedding_bwd_ws_bytes(n, D), "pv_embedding_bwd: workspace too small");
+  PV_REQUIRE(num_rows < (1l << 30), "pv_embedding_bwd: table rows must fit int32 sort keys");
+  if (n > 0) {
+    int rc = embedding_sort(ids, n, n1, n1p, s0, s1, num_rows, (char*)workspace, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return pv_embedding_bwd_sorted(grad_rows, ldg, n, num_rows, D, padding_idx, accumulate, dtable, workspace, ws_bytes, stream);
 }
 
 int pv_sparse_pack(const float* table_grad, long num_rows, int D, const int64_t* ids, int n, float* out_ids,

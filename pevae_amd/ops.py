@@ -176,6 +176,8 @@ def _vocab_dw_cuts(V):
     c1 = (V - n2 - n3) // 128 * 128
     if c1 < 0 or n2 <= 0 or n3 <= 0:
         return None
+    if c1 < 1024:                # a first range of a few units is a whole-chip launch for nothing: the second takes its rows
+        n2, c1 = n2 + c1, 0
     return c1, c1 + n2
 _DEFERRED = []           # (event on the stream that queued it, closure): side work whose launch is postponed
 
@@ -1342,6 +1344,23 @@ class LSTMLayer(torch.autograd.Function):
 # embedding
 # ------------------------------------------------------------------------------------------------------------
 
+# The ids of a lookup are known when the step starts, the gradient of its rows only at the tail of the backward pass (the
+# encoder-side tables come last).  With a gradient sink and PRESORT on, the stable sort of the (row id, occurrence) pairs
+# runs at FORWARD time on a background stream that only the lookup's own backward waits for -- beside the encoder
+# recurrence, which leaves half the chip idle -- and the backward pass is left with the segmented sum.  PRESORT_OK is
+# cleared by callers whose forward and backward are captured into different HIP graphs (a fork must join inside its graph).
+PRESORT = os.environ.get("PEVAE_EMB_PRESORT", "0") == "1"      # measured at the Yelp shape: 2.963 vs 2.891 ms per step WITH it (five more cross-queue edges in the replayed graph cost more than the sorts at the tail): off
+PRESORT_OK = True
+_BG = {}
+
+
+def _bg_stream(dev):
+    st = _BG.get(dev)
+    if st is None:
+        st = _BG[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class EmbeddingLookup(torch.autograd.Function):
     """nn.Embedding forward/backward (dialog_models.py:758-765, decoders.py:174): coalesced row gather;
     backward = stable sort + segmented sum (no atomics, bitwise reproducible); padding row gets zero grad."""
@@ -1356,6 +1375,19 @@ class EmbeddingLookup(torch.autograd.Function):
         if n:
             _lib.call("pv_embedding_gather", _p(w), w.shape[0], D, _p(ids_c), n, n, n, 0, 1, _p(out), D, None, 0,
                       None, _stream())
+        ctx.presorted = None
+        if (PRESORT and PRESORT_OK and n and ctx.needs_input_grad[0]       # (grad mode is off inside a Function's forward)
+                and grad_sink(weight, tuple(weight.shape)) is not None):
+            dev = weight.device
+            nbytes = _lib.load().pv_embedding_bwd_ws_bytes(n, D)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)         # this lookup's own: it lives until its backward
+            cur, bg = torch.cuda.current_stream(dev), _bg_stream(dev)
+            bg.wait_stream(cur)
+            with torch.cuda.stream(bg):
+                _lib.call("pv_embedding_sort", _p(ids_c), n, n, n, 0, 1, w.shape[0], D, _p(ws), nbytes, _stream())
+                ev = torch.cuda.Event()
+                ev.record(bg)
+            ctx.presorted = (ws, nbytes, ev)
         ctx.save_for_backward(ids_c)
         ctx.meta = (w.shape[0], D, -1 if padding_idx is None else padding_idx)
         ctx.param = weight
@@ -1366,21 +1398,29 @@ class EmbeddingLookup(torch.autograd.Function):
         (ids_c,) = ctx.saved_tensors
         rows, D, pad = ctx.meta
         sink = grad_sink(ctx.param, (rows, D))
-        dw = embedding_backward(dout, ids_c, rows, D, pad, sink)
+        dw = embedding_backward(dout, ids_c, rows, D, pad, sink, ctx.presorted if sink is not None else None)
+        ctx.presorted = None
         return (None if sink is not None else dw), None, None
 
 
-def embedding_backward(dout, ids_c, rows, D, pad, sink):
-    """Table gradient of a lookup: stable sort + segmented sum, accumulated into `sink` when given (else returned)."""
+def embedding_backward(dout, ids_c, rows, D, pad, sink, presorted=None):
+    """Table gradient of a lookup: stable sort + segmented sum, accumulated into `sink` when given (else returned).
+    presorted = (workspace, bytes, event) of a pv_embedding_sort made at forward time: only the segmented sum is left."""
     n = ids_c.numel()
     dev = dout.device
     dw = sink if sink is not None else torch.empty((rows, D), dtype=torch.float32, device=dev)
-    nbytes = _lib.load().pv_embedding_bwd_ws_bytes(max(n, 1), D)
-    ws = workspace("emb_bwd", nbytes, torch.uint8, dev)
     if dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= D and dout.stride(0) % 4 == 0:
         g, ldg = dout, dout.stride(0)         # a column slice of a wider gradient (torch.cat backward): no copy
     else:
         g, ldg = dout.contiguous().view(-1, D), D
+    if presorted is not None:
+        ws, nbytes, ev = presorted
+        torch.cuda.current_stream(dev).wait_event(ev)
+        _lib.call("pv_embedding_bwd_sorted", _p(g), ldg, n, rows, D, pad, 1 if sink is not None else 0, _p(dw), _p(ws), nbytes,
+                  _stream())
+        return dw
+    nbytes = _lib.load().pv_embedding_bwd_ws_bytes(max(n, 1), D)
+    ws = workspace("emb_bwd", nbytes, torch.uint8, dev)
     _lib.call("pv_embedding_bwd", _p(g), ldg, _p(ids_c), n, max(n, 1), max(n, 1), 0, 1, rows, D, pad,
               1 if sink is not None else 0, _p(dw), _p(ws), nbytes, _stream())
     return dw

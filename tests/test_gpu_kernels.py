@@ -351,6 +351,31 @@ def test_embedding_scatter_long_segments(dev):
     assert np.array_equal(tw.grad.cpu().numpy(), got)
 
 
+def test_embedding_forward_time_sort_gives_the_same_bits(dev):
+    """ops.PRESORT: the (row id, occurrence) sort made at forward time on a background stream (pv_embedding_sort) and the
+    backward left with pv_embedding_bwd_sorted accumulate into a gradient sink exactly what the one-call backward does."""
+    from pevae_amd import ops
+    g = torch.Generator().manual_seed(8)
+    rows, D = 5000, 100
+    ids = torch.randint(0, rows, (64, 50), generator=g)
+    ids[:, ::3] = 17
+    grad = torch.randn(64, 50, D, generator=g).to(dev)
+    got = []
+    for presort in (False, True):
+        w = torch.nn.Parameter(torch.randn(rows, D, generator=torch.Generator().manual_seed(1)).to(dev))
+        w.grad = torch.full((rows, D), 0.25, device=dev)              # a sink with earlier contents: the sum accumulates
+        prev, ops.PRESORT = ops.PRESORT, presort
+        try:
+            out = ops.embedding(w, ids.to(dev), 0)
+            assert (out.grad_fn.presorted is not None) == presort
+            out.backward(grad)
+        finally:
+            ops.PRESORT = prev
+        torch.cuda.synchronize()
+        got.append(w.grad.clone())
+    assert torch.equal(got[0], got[1]) and float((got[0] - 0.25).abs().max()) > 0
+
+
 @pytest.mark.parametrize("rows,n,n1,n1p", [(262143, 16384, 64, 64), (200001, 12800, 50, 50), (20004, 16385, 16385, 16385),
                                             (262144, 4096, 16, 32), (30000, 256, 256, 256), (5, 1, 1, 1), (1000, 777, 7, 9)])
 def test_embedding_backward_sort_limits(dev, rows, n, n1, n1p):
