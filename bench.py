@@ -97,7 +97,8 @@ def measure_traffic(args):
     """HBM bytes per step of the vocabulary group, measured NOW: one rocprofv3 --pmc pass per counter (the guide's
     prescription: separate passes, no trace domains beside --pmc) over a short eager child run of this script, the program
     itself behind `--`.  Per kernel the median over its launches of FETCH_SIZE x 2 (gfx950 counts 64-byte halves of its
-    128-byte fetches once) + WRITE_SIZE, both in KiB; each of the four kernels runs once per step.  Runs before this
+    128-byte fetches once) + WRITE_SIZE, both in KiB; the child launches each of the four kernels once per step, on the
+    whole chip (--dw-beside 0), as the roofline's instrumented pass does.  Runs before this
     process initialises the GPU.  -> (bytes per step, per-kernel dict) or (None, reason)."""
     import csv
     import glob
@@ -110,7 +111,7 @@ def measure_traffic(args):
     if prof is None:
         return None, "rocprofv3 is not on PATH"
     child = ["python3", os.path.abspath(__file__), "--cpu-baseline", "0", "--graph", "0", "--steps", "3", "--warmup", "1",
-             "--profile-steps", "1", "--traffic", "off", "--batch", str(args.batch), "--dropout", str(args.dropout)]
+             "--profile-steps", "1", "--traffic", "off", "--dw-beside", "0", "--batch", str(args.batch), "--dropout", str(args.dropout)]
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="pevae_pmc_", dir="/tmp")

@@ -57,12 +57,15 @@ __global__ void fill_keys_kernel(const int64_t* __restrict__ ids, int n, int n1,
 // one exclusive scan over the whole workgroup, and each thread scatters its elements in order to the offsets of its own
 // column: equal digits keep their order.  Element p lives at word p + p / 32, so that the threads' chunks start in different
 // banks.  Elements past n are all-ones: they stay last in every pass and are never written out.
-constexpr int SORT_T = 512, SORT_E_MAX = 32, SORT_N_MAX = SORT_T * SORT_E_MAX, SORT_OCC_BITS = 14, SORT_KEY_BITS = 18;
+// 1 024 threads when the images fit the 160 KiB of LDS beside their count matrix (n <= 13 312: the step's 12 800-occurrence
+// lookups), 512 otherwise: the scatter is a serial chain per thread, so threads are what shortens a pass.
+constexpr int SORT_N_MAX = 16384, SORT_OCC_BITS = 14, SORT_KEY_BITS = 18;
 __device__ __forceinline__ int sort_at(int p) { return p + (p >> 5); }
-static inline size_t sort_lds_bytes(int n) {
-  const int span = cdiv(n, SORT_T) * SORT_T;
-  return (size_t)2 * (span + (span >> 5) + 1) * 4 + 16 * SORT_T * 2 + 64;
+static inline size_t sort_lds_bytes(int n, int threads) {
+  const int span = cdiv(n, threads) * threads;
+  return (size_t)2 * (span + (span >> 5) + 1) * 4 + 16 * threads * 2 + 64;
 }
+template <int SORT_T>
 __global__ __launch_bounds__(SORT_T) void sort_pairs_lds_kernel(const int64_t* __restrict__ ids, int n, int n1, int n1p, long s0,
                                                                long s1, long num_rows, int bits, int* __restrict__ skeys,
                                                                int* __restrict__ svals) {
@@ -312,13 +315,18 @@ static int embedding_sort(const int64_t* ids, int n, int n1, int n1p, long s0, l
   static const int own_sort = getenv("PV_EMB_OWN_SORT") ? atoi(getenv("PV_EMB_OWN_SORT")) : 1;
   if (own_sort && n <= SORT_N_MAX && bits <= SORT_KEY_BITS) {
     // the hot path: keys and the stable sort in one single-workgroup launch
-    static size_t seen = 0;
-    const size_t lds = sort_lds_bytes(n);
-    if (lds > 64 * 1024 && lds > seen) {
-      PV_HIP(hipFuncSetAttribute((const void*)sort_pairs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      seen = lds;
+    static size_t seen[2] = {0, 0};
+    const int wide = n > 512 && sort_lds_bytes(n, 1024) <= 160 * 1024;
+    const size_t lds = sort_lds_bytes(n, wide ? 1024 : 512);
+    if (lds > 64 * 1024 && lds > seen[wide]) {
+      PV_HIP(hipFuncSetAttribute(wide ? (const void*)sort_pairs_lds_kernel<1024> : (const void*)sort_pairs_lds_kernel<512>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      seen[wide] = lds;
     }
-    hipLaunchKernelGGL(sort_pairs_lds_kernel, dim3(1), dim3(SORT_T), lds, st, ids, n, n1, n1p, s0, s1, num_rows, bits, skeys, svals);
+    if (wide)
+      hipLaunchKernelGGL(sort_pairs_lds_kernel<1024>, dim3(1), dim3(1024), lds, st, ids, n, n1, n1p, s0, s1, num_rows, bits, skeys, svals);
+    else
+      hipLaunchKernelGGL(sort_pairs_lds_kernel<512>, dim3(1), dim3(512), lds, st, ids, n, n1, n1p, s0, s1, num_rows, bits, skeys, svals);
     PV_LAUNCH_CHECK("sort_pairs_lds_kernel");
   } else {
     // lookups beyond 16 384 occurrences or tables of 2^18 rows and more: the library's device-wide sort
