@@ -50,8 +50,9 @@ print("T = %d live rows; fwd %.1f us, dw %.1f us per call (pair of launches each
 if not hasattr(lib, "pv_vocab_stamps_copy"):
     sys.exit(0)
 names = ["prologue (stationary loads, first tile)", "barrier (tile landed)", "first products (2 x 32 steps + staging)",
-         "transform, first half (no MFMA beside it)", "second products k-step 0 (2 x 16 steps + transform)",
-         "second products k-step 1 (2 x 16 steps)", "epilogue (slab stores)", "-"]
+         "between the products (no MFMA in flight; 0 since the decision moved beside the second product)",
+         "second products (2 x 32 steps) + decision + transform + staging", "segment tail (last sub-tile's second product)",
+         "epilogue (slab stores)", "-"]
 buf = np.zeros((2, 256, 4, 8), dtype=np.uint64)
 lib.pv_vocab_stamps_copy.restype = C.c_int
 lib.pv_vocab_stamps_copy.argtypes = [C.c_void_p, C.c_size_t]
