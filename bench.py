@@ -110,6 +110,9 @@ def measure_traffic(args):
     prof = shutil.which("rocprofv3")
     if prof is None:
         return None, "rocprofv3 is not on PATH"
+    # never nest profilers: a --pmc child under a tracing parent is the combination the pool's guide warns about
+    if any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler (ROCPROF* / LD_PRELOAD): no nested counter passes"
     child = ["python3", os.path.abspath(__file__), "--cpu-baseline", "0", "--graph", "0", "--steps", "3", "--warmup", "1",
              "--profile-steps", "1", "--traffic", "off", "--dw-beside", "0", "--batch", str(args.batch), "--dropout", str(args.dropout)]
     vals = {}
@@ -120,11 +123,11 @@ def measure_traffic(args):
             p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                  stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                rc = p.wait(timeout=240)
+                rc = p.wait(timeout=180)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL)
                 p.wait()
-                return None, "the %s pass did not finish in 240 s" % counter
+                return None, "the %s pass did not finish in 180 s" % counter
             files = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
             if rc != 0 or not files:
                 return None, "the %s pass left no counter file (exit status %d)" % (counter, rc)
