@@ -114,6 +114,14 @@ int pv_vocab_fused_dw(const void* h, int ldh, const void* W, int ldw, const floa
 int pv_vocab_fused_dw_wgs(const void* h, int ldh, const void* W, int ldw, const float* bias, const int* target32, const float* lse,
                           const float* gscale, int T, int V, int H, float inv_temp, void* workspace, float* dW, int lddw,
                           int accumulate, float* dbias, int accumulate_bias, const int* live_rows, int wgs, void* stream);
+/* The same for rows [v0, v1) of the vocabulary only (v0 a multiple of 128): W, bias, dW and dbias are the WHOLE arrays, the
+ * targets keep their global numbers; workspace: pv_vocab_fused_dw_ws_bytes(v1 - v0).  Several ranges may run at the same
+ * time on different streams with their own workspaces (ops.VOCAB_DW_BESIDE: half the vocabulary beside each backward
+ * recurrence).  No counterpart in the reference. */
+int pv_vocab_fused_dw_range(const void* h, int ldh, const void* W, int ldw, const float* bias, const int* target32,
+                            const float* lse, const float* gscale, int T, int V, int H, float inv_temp, int v0, int v1,
+                            void* workspace, float* dW, int lddw, int accumulate, float* dbias, int accumulate_bias,
+                            const int* live_rows, int wgs, void* stream);
 /* pv_vocab_gather with the targets also as int32; perm == NULL: identity order (h_c / target_c may be NULL). */
 int pv_vocab_gather32(const void* h, int ldh, const int64_t* target, const int64_t* perm, int T, int H, void* h_c, int ldc,
                       int64_t* target_c, int* target32, void* stream);

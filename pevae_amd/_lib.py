@@ -54,6 +54,8 @@ SIGNATURES = {
     "pv_vocab_fused_dw_ws_bytes": (sz, [i32]),
     "pv_vocab_fused_dw": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, i32, i32, vp, vp, vp]),
     "pv_vocab_fused_dw_wgs": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, i32, i32, vp, i32, vp, i32, vp]),
+    "pv_vocab_fused_dw_range": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp, vp, i32, i32, vp, i32, vp,
+                                      i32, vp]),
     "pv_vocab_gather32": (i32, [vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp]),
     "pv_scatter_rows_scaled_f32": (i32, [vp, vp, f32, vp, vp, i32, i32, vp, lng, vp]),
     "pv_scatter_rows_scaled_drop_f32": (i32, [vp, vp, f32, vp, vp, i32, i32, vp, lng, i32, i32, lng, lng, f32, vp, vp, i32, vp]),

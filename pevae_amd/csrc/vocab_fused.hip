@@ -659,6 +659,7 @@ struct DwArgs {
   const int* live;
   int T, V, ldh, ldw, max_seg;
   float inv_temp;
+  int v_base;           // vocabulary row of W[0] (a launch on a row range: the targets keep their global numbers)
   float* z_slab;        // [G * max_seg][UNIT][HD]
   float* b_slab;        // [G * max_seg][UNIT]
 };
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
     const int nri = (int)min((long)NRI - ri0, end - at);
     at += nri;
     // ---- this wave's 32 rows of W as 32 B-operand fragments ------------------------------------------------------------
-    const int vbase = ct * UNIT + 32 * w, v_mine = vbase + r32;
+    const int vbase = ct * UNIT + 32 * w, v_mine = vbase + r32, v_tgt = v_mine + a.v_base;
     const bf16_t* wrow = a.W + (long)min(v_mine, a.V - 1) * a.ldw + 8 * hh;
     bf16x8 wf[NKS];
 #pragma unroll
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void vocab_dw_kernel(DwArgs a) {
 #ifndef PV_ABL_NOEXP
         const int yy = (j & 3) == 0 ? y4.x : (j & 3) == 1 ? y4.y : (j & 3) == 2 ? y4.z : y4.w;
         const float g = g4[j & 3];
-        const float q = fmaf(p_half, g, yy == v_mine ? -g : 0.f);
+        const float q = fmaf(p_half, g, yy == v_tgt ? -g : 0.f);
 #else
         const float q = p_half;
 #endif
@@ -1053,6 +1054,22 @@ int pv_vocab_fused_dw(const void* h, int ldh, const void* W, int ldw, const floa
 int pv_vocab_fused_dw_wgs(const void* h, int ldh, const void* W, int ldw, const float* bias, const int* target32, const float* lse,
                           const float* gscale, int T, int V, int H, float inv_temp, void* workspace, float* dW, int lddw,
                           int accumulate, float* dbias, int accumulate_bias, const int* live_rows, int wgs, void* stream) {
+  return pv_vocab_fused_dw_range(h, ldh, W, ldw, bias, target32, lse, gscale, T, V, H, inv_temp, 0, V, workspace, dW, lddw,
+                                 accumulate, dbias, accumulate_bias, live_rows, wgs, stream);
+}
+
+int pv_vocab_fused_dw_range(const void* h, int ldh, const void* W_all, int ldw, const float* bias_all, const int* target32,
+                            const float* lse, const float* gscale, int T, int V_all, int H, float inv_temp, int v0, int v1,
+                            void* workspace, float* dW_all, int lddw, int accumulate, float* dbias_all, int accumulate_bias,
+                            const int* live_rows, int wgs, void* stream) {
+  PV_REQUIRE(W_all && bias_all && dW_all && dbias_all, "pv_vocab_fused_dw: null argument");
+  PV_REQUIRE(0 <= v0 && v0 < v1 && v1 <= V_all && v0 % UNIT == 0, "pv_vocab_fused_dw_range: rows [%d, %d) of %d (v0 must be a multiple of %d)",
+             v0, v1, V_all, UNIT);
+  const int V = v1 - v0;
+  const void* W = (const char*)W_all + (size_t)v0 * ldw * sizeof(bf16_t);
+  const float* bias = bias_all + v0;
+  float* dW = dW_all + (size_t)v0 * lddw;
+  float* dbias = dbias_all + v0;
   int rc = check_common(h, ldh, W, ldw, T, V, H, "pv_vocab_fused_dw");
   if (rc) return rc;
   PV_REQUIRE(bias && target32 && lse && gscale && workspace && dW && dbias, "pv_vocab_fused_dw: null argument");
@@ -1071,7 +1088,7 @@ int pv_vocab_fused_dw_wgs(const void* h, int ldh, const void* W, int ldw, const 
   float* z_slab = (float*)workspace;
   float* b_slab = z_slab + (size_t)G * ms * UNIT * HD;
   hipStream_t st = (hipStream_t)stream;
-  DwArgs a{(const bf16_t*)h, (const bf16_t*)W, bias, target32, lse, gscale, live_rows, T, V, ldh, ldw, ms, inv_temp, z_slab, b_slab};
+  DwArgs a{(const bf16_t*)h, (const bf16_t*)W, bias, target32, lse, gscale, live_rows, T, V, ldh, ldw, ms, inv_temp, v0, z_slab, b_slab};
   hipLaunchKernelGGL(vocab_dw_kernel, dim3(G), dim3(256), SMEM_BYTES, st, a);
   PV_LAUNCH_CHECK("vocab_dw_kernel");
   DwReduceArgs r{z_slab, b_slab, live_rows, T, V, ms, G, lddw, accumulate, accumulate_bias, inv_temp, dW, dbias};

@@ -847,16 +847,13 @@ class VocabNLL(torch.autograd.Function):
             dbias = sink_b
         ws_bytes = _lib.load().pv_vocab_fused_dw_ws_bytes(V)
 
-        def launch(wgs=0, v0=0, v1=V, tag="vocab_fused_dw", t32_r=t32):
-            # rows [v0, v1) of the vocabulary: the same entry point on offset operands (targets shifted by v0: a target
-            # outside the range matches no row of it)
-            nv = v1 - v0
-            ws = workspace(tag, _lib.load().pv_vocab_fused_dw_ws_bytes(nv), torch.uint8, dev)      # (of the stream it runs on)
+        def launch(wgs=0, v0=0, v1=V, tag="vocab_fused_dw"):
+            # rows [v0, v1) of the vocabulary (pv_vocab_fused_dw_range; the whole vocabulary: the same call)
+            ws = workspace(tag, _lib.load().pv_vocab_fused_dw_ws_bytes(v1 - v0), torch.uint8, dev)     # (of the stream it runs on)
             with timed("vocab_fused_dw"):
-                _lib.call("pv_vocab_fused_dw_wgs", _p(h_bf), ldh, w_bf.data_ptr() + v0 * Hp * 2, Hp, bias.data_ptr() + 4 * v0,
-                          _p(t32_r), _p(lse), _p(gscale), T, nv, Hp, inv_temp, _p(ws), dW.data_ptr() + 4 * v0 * H, H,
-                          1 if sink is not None else 0, dbias.data_ptr() + 4 * v0, 1 if sink_b is not None else 0,
-                          _p(count), wgs, _stream())
+                _lib.call("pv_vocab_fused_dw_range", _p(h_bf), ldh, _p(w_bf), Hp, _p(bias), _p(t32), _p(lse), _p(gscale), T, V, Hp,
+                          inv_temp, v0, v1, _p(ws), _p(dW), H, 1 if sink is not None else 0, _p(dbias),
+                          1 if sink_b is not None else 0, _p(count), wgs, _stream())
 
         cuts = _vocab_dw_cuts(V) if (sink_b is not None and ASYNC_WGRAD and VOCAB_DW_BESIDE and dW.is_contiguous()
                                       and bias.is_contiguous() and dbias.is_contiguous()) else None
@@ -868,10 +865,8 @@ class VocabNLL(torch.autograd.Function):
             if c1 > 0:
                 launch(0, 0, c1)
             for k, (a, b) in enumerate(((c1, c2), (c2, V))):
-                t_r = t32 - a
-                held = (h_bf, w_bf, bias, t32, t_r, lse, gscale, count, dW, dbias)
-                defer_beside_recurrence(lambda wgs, a=a, b=b, k=k, t_r=t_r: launch(wgs, a, b, "vocab_fused_dw_r%d" % k, t_r),
-                                        keep=held)
+                held = (h_bf, w_bf, bias, t32, lse, gscale, count, dW, dbias)
+                defer_beside_recurrence(lambda wgs, a=a, b=b, k=k: launch(wgs, a, b, "vocab_fused_dw_r%d" % k), keep=held)
         elif sink_b is not None and ASYNC_WGRAD and VOCAB_DW_SIDE_WGS > 0:
             # both gradients sink into the flat buffer and nothing downstream reads them: off the critical path, on fewer
             # workgroups than CUs so that the latent stack's backward keeps the CUs it needs

@@ -213,6 +213,55 @@ def test_vocab_fused_dw_on_fewer_workgroups_into_sinks(dev):
     assert torch.equal(dw_b, dw_c) and torch.equal(db_b, db_c)
 
 
+@pytest.mark.parametrize("fractions", [(0.5, 0.5), (0.3, 0.3)])
+def test_vocab_dw_in_row_ranges_beside_recurrences(dev, fractions):
+    """ops.VOCAB_DW_BESIDE / pv_vocab_fused_dw_range: the weight gradient of the vocabulary projection in two (or three) row
+    ranges -- launched where a backward recurrence would start (ops.launch_beside_recurrence: second side stream, half the
+    chip) or, if none comes, at the end of the backward pass on the whole chip -- accumulates into the sinks what the single
+    launch does, up to the order of the stream-K segment folds, bit-identically from run to run; targets of every range hit
+    their one-hot rows (the bias gradient sums to zero over the vocabulary)."""
+    from pevae_amd import ops
+    T, V, H = 900, 5003, 512
+    g = torch.Generator().manual_seed(6)
+    hid = (torch.randn(T, H, generator=g) * 0.5).to(dev)
+    W0 = (torch.randn(V, H, generator=g) * 0.05).to(dev)
+    b0 = (torch.randn(V, generator=g) * 0.1).to(dev)
+    tgt = torch.randint(1, V, (T,), generator=g)
+    tgt[::5] = 0
+    tgt = tgt.to(dev)
+
+    def run(beside, recurrences):
+        W, b = torch.nn.Parameter(W0.clone()), torch.nn.Parameter(b0.clone())
+        W.grad, b.grad = torch.full_like(W, 0.5), torch.full_like(b, -0.25)
+        hd = hid.clone().requires_grad_()
+        prev = ops.VOCAB_DW_BESIDE, ops.ASYNC_WGRAD
+        ops.VOCAB_DW_BESIDE, ops.ASYNC_WGRAD = beside, True
+        budgets = []
+        try:
+            nll, _ = ops.VocabNLL.apply(hd, W, b, tgt, 1.0, 0, None, None)
+            nll.sum().backward()
+            for _ in range(recurrences):                  # what GRULayer.backward does in front of its launch
+                ops.join_side_work()
+                budgets.append(ops.launch_beside_recurrence())
+        finally:
+            ops.VOCAB_DW_BESIDE, ops.ASYNC_WGRAD = prev
+            ops.join_side_work()                          # the end of the backward pass: what still waits runs here
+        torch.cuda.synchronize()
+        return W.grad.clone(), b.grad.clone(), hd.grad.clone(), budgets
+
+    dw_a, db_a, dh_a, _ = run(None, 0)
+    half = torch.cuda.get_device_properties(dev).multi_processor_count // 2
+    for recurrences in (2, 1, 0):
+        dw_b, db_b, dh_b, budgets = run(fractions, recurrences)
+        assert budgets == [half] * recurrences
+        assert torch.equal(dh_a, dh_b)
+        assert relerr(dw_b - 0.5, dw_a - 0.5) < 1e-5 and relerr(db_b + 0.25, db_a + 0.25) < 1e-5
+        assert abs(float((db_b + 0.25).sum())) < 1e-3
+        dw_c, db_c, _, _ = run(fractions, recurrences)
+        assert torch.equal(dw_b, dw_c) and torch.equal(db_b, db_c)
+    assert ops.launch_beside_recurrence() == 0            # nothing is left waiting
+
+
 def gru_ref(x, h0, w_ih, w_hh, b_ih, b_hh, emulate_bf16):
     """oracle GRU (R.gru_cell arithmetic) with optional bf16 rounding of the MFMA operands (straight-through)."""
     def q(t):
