@@ -315,15 +315,21 @@ static int embedding_sort(const int64_t* ids, int n, int n1, int n1p, long s0, l
   static const int own_sort = getenv("PV_EMB_OWN_SORT") ? atoi(getenv("PV_EMB_OWN_SORT")) : 1;
   if (own_sort && n <= SORT_N_MAX && bits <= SORT_KEY_BITS) {
     // the hot path: keys and the stable sort in one single-workgroup launch
-    static size_t seen[2] = {0, 0};
-    const int wide = n > 512 && sort_lds_bytes(n, 1024) <= 160 * 1024;
-    const size_t lds = sort_lds_bytes(n, wide ? 1024 : 512);
-    if (lds > 64 * 1024 && lds > seen[wide]) {
-      PV_HIP(hipFuncSetAttribute(wide ? (const void*)sort_pairs_lds_kernel<1024> : (const void*)sort_pairs_lds_kernel<512>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      seen[wide] = lds;
+    // threads: one wave up to 512 occurrences (the user / item lookups of a batch: no cross-wave steps), 1 024 when the
+    // images fit the LDS beside their count matrix (n <= 13 312), 512 otherwise
+    static size_t seen[3] = {0, 0, 0};
+    const int shape = n <= 512 ? 0 : sort_lds_bytes(n, 1024) <= 160 * 1024 ? 2 : 1;
+    const int threads = shape == 0 ? 64 : shape == 2 ? 1024 : 512;
+    const void* fn = shape == 0 ? (const void*)sort_pairs_lds_kernel<64>
+                                : shape == 2 ? (const void*)sort_pairs_lds_kernel<1024> : (const void*)sort_pairs_lds_kernel<512>;
+    const size_t lds = sort_lds_bytes(n, threads);
+    if (lds > 64 * 1024 && lds > seen[shape]) {
+      PV_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      seen[shape] = lds;
     }
-    if (wide)
+    if (shape == 0)
+      hipLaunchKernelGGL(sort_pairs_lds_kernel<64>, dim3(1), dim3(64), lds, st, ids, n, n1, n1p, s0, s1, num_rows, bits, skeys, svals);
+    else if (shape == 2)
       hipLaunchKernelGGL(sort_pairs_lds_kernel<1024>, dim3(1), dim3(1024), lds, st, ids, n, n1, n1p, s0, s1, num_rows, bits, skeys, svals);
     else
       hipLaunchKernelGGL(sort_pairs_lds_kernel<512>, dim3(1), dim3(512), lds, st, ids, n, n1, n1p, s0, s1, num_rows, bits, skeys, svals);
