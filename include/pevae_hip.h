@@ -187,6 +187,15 @@ int pv_greedy_decode(const float* gx_table, const float* gx_const, const void* w
                      int sos_id, int mask_col, float inv_temp, void* workspace, int64_t* seq, float* logp, float* hn,
                      void* stream);
 int pv_greedy_decode_error(const void* workspace, int* flag);   /* host out-param; synchronises */
+/* The same launch with gen_type 'sample' (decoders.py:255-256 -> base_modules.py:54-59, one torch.multinomial draw per row
+ * and token): the emitted symbol is arg-max over columns != mask_col of (scaled logit - log q), q ~ Exp(1) from Philox keyed
+ * by (rng_state {seed, step}, site0 + token, row, column) -- token by token the draws of pv_vocab_sample(site = site0 +
+ * token) --, logp its log-softmax value.  workspace: pv_sample_decode_ws_bytes(B, H, V, L); error flag and limits as above. */
+size_t pv_sample_decode_ws_bytes(int B, int H, int V, int L);
+int pv_sample_decode(const float* gx_table, const float* gx_const, const void* whh_bf16, const float* bhh,
+                     const void* wproj_bf16, int ldwp, const float* bproj, const float* h0, int B, int H, int V, int L,
+                     int sos_id, int mask_col, float inv_temp, const void* rng_state, int site0, void* workspace,
+                     int64_t* seq, float* logp, float* hn, void* stream);
 /* Backward of the dense path: P = (dlogp - exp(logp) * rowsum(dlogp)) * inv_temp as bf16 [T][ldp] (+ dbias). */
 int pv_logsoftmax_bwd_bf16(const float* logp, const float* dlogp, int T, int V, float inv_temp, void* P, int ldp,
                            float* dbias, void* stream);

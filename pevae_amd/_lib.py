@@ -69,6 +69,8 @@ SIGNATURES = {
     "pv_greedy_decode_ws_bytes": (sz, [i32, i32, i32, i32]),
     "pv_greedy_decode": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "pv_greedy_decode_error": (i32, [vp, vp]),
+    "pv_sample_decode_ws_bytes": (sz, [i32, i32, i32, i32]),
+    "pv_sample_decode": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp, vp, vp, vp, vp]),
     "pv_vocab_logprob_dense": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, vp, vp]),
     "pv_logsoftmax_bwd_bf16": (i32, [vp, vp, i32, i32, f32, vp, i32, vp, vp]),
     "pv_gru_geometry": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),

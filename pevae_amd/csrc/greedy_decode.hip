@@ -79,6 +79,12 @@ struct DecodeArgs {
   int L, B, H, Hk, Bpad, V, G, S, NV, NC, nwg, sos, mask_col, ldwp;
   float inv_temp;
   unsigned hb_bytes, part_bytes, part_b;   // part_b: byte offset of the (max, sum-exp) records inside `part`
+  // `sample` decoding (decoders.py:255-256 -> base_modules.py:54-59): the record's value is the scaled logit MINUS log q,
+  // q ~ Exp(1) from Philox keyed by (seed, step, site0 + token, row, column) -- the draws of pv_vocab_sample --, and the
+  // unperturbed logit of each workgroup's candidate goes to `xsel` [L][NV][Bpad] for the emitted symbol's log-probability
+  const RngState* rng;     // NULL: greedy
+  float* xsel;
+  unsigned site0;
   int dbg;                 // timing ablation bits (diagnostic build only, env PV_DECODE_DBG; results are wrong when set)
 };
 
@@ -396,8 +402,10 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
       // record is published first; max / sum-exp (the log-probability's normaliser: 40 exponentials and twice the
       // reductions per lane) follow AFTER the hand-off when the share is one chunk, from the accumulators still in
       // registers, and are folded once, after the last token.
-      float km = -INFINITY, ksum = 0.f, kb = -INFINITY;
+      float km = -INFINITY, ksum = 0.f, kb = -INFINITY, kx = 0.f;
       int ki = -1;
+      RngState rst{0, 0};
+      if (a.rng) rst = *a.rng;
       // which 32 rows this wave takes is rotated by the workgroup's index within its XCD
       const int wr = (w + (r >> 3)) % (a.Bpad / 32);
       const bool vwave = w * 32 < a.Bpad, defer = NCT <= CT;
@@ -484,19 +492,47 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int mt = i >> 2, j = i & 3;
-            float bst = -INFINITY;
+            float bst = -INFINITY, bx = 0.f;
             int bi = -1;
+            if (a.rng) {                                     // (wave-uniform) the multinomial draw: arg-max of x - log q
+              const uint32_t row = (uint32_t)(wr * 32 + mt * 16 + q4 * 4 + j);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              const float x = (acc[mt][ct][j] + bv[ct]) * a.inv_temp;
-              if (colv[ct] >= 0 && colv[ct] != a.mask_col && x > bst) {   // ascending: the first maximum stays
-                bst = x;
-                bi = colv[ct];
+              for (int ct = 0; ct < CT; ++ct) {
+                const float x = (acc[mt][ct][j] + bv[ct]) * a.inv_temp;
+                if (colv[ct] >= 0 && colv[ct] != a.mask_col) {
+                  uint32_t rnd[4];
+                  philox4x32_10((uint32_t)colv[ct], row, a.site0 + (uint32_t)t,
+                                (uint32_t)rst.step ^ (uint32_t)(rst.step >> 32) * 0x9E3779B9u, (uint32_t)rst.seed,
+                                (uint32_t)(rst.seed >> 32), rnd);
+                  const float q = -__logf(((float)(rnd[0] >> 8) + 0.5f) * (1.0f / 16777216.0f));     // Exp(1), u in (0, 1)
+                  const float xs = x - __logf(q);
+                  if (xs > bst) {                            // ascending: the first maximum stays
+                    bst = xs;
+                    bx = x;
+                    bi = colv[ct];
+                  }
+                }
+              }
+            } else {
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) {
+                const float x = (acc[mt][ct][j] + bv[ct]) * a.inv_temp;
+                if (colv[ct] >= 0 && colv[ct] != a.mask_col && x > bst) {   // ascending: the first maximum stays
+                  bst = x;
+                  bi = colv[ct];
+                }
               }
             }
             const float brow = row16_max(bst);
+            const int mine = bi;
             bi = row16_min_int((bst == brow && bi >= 0) ? bi : 0x7fffffff);
-            if (c16 == i) fold_best(kb, ki, brow, bi == 0x7fffffff ? -1 : bi);
+            float xw = 0.f;
+            if (a.rng) xw = row16_max((mine == bi && bi != 0x7fffffff) ? bx : -INFINITY);   // the winner's own logit
+            if (c16 == i) {
+              const int cand = bi == 0x7fffffff ? -1 : bi;
+              if (a.rng && cand >= 0 && (brow > kb || (brow == kb && (ki < 0 || cand < ki)))) kx = xw;   // fold_best's rule
+              fold_best(kb, ki, brow, cand);
+            }
           }
           if (!defer) sumexp();
         }
@@ -517,6 +553,8 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
           const u32x2 v = {__builtin_bit_cast(u32, km), __builtin_bit_cast(u32, ksum)};
           __builtin_amdgcn_raw_buffer_store_b64(v, prs, a.part_b + (unsigned)((((size_t)t * a.NV + r) * a.Bpad + row) * 8), 0,
                                                 AUX_SC1);
+          // (agent scope = write-through, like the records: the reader sits behind another XCD's L2)
+          if (a.rng) __hip_atomic_store(a.xsel + ((size_t)t * a.NV + r) * a.Bpad + row, kx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       STAMP(7);
@@ -569,7 +607,12 @@ __global__ __launch_bounds__(NT, 1) void greedy_decode_kernel(DecodeArgs a) {
         fold(m, sm, best, idx, f[0], f[1], f[2], (int)o[3]);
       }
       const int row = rb * GROWS + tid;
-      if (row < a.B) a.logp[(size_t)row * a.L + tt] = best - (m + __logf(sm));
+      if (row < a.B) {
+        // sample: `best` is the perturbed score; the drawn symbol's own logit is in the x image of the workgroup that owns it
+        const float xv = (a.rng && idx >= 0) ? __hip_atomic_load(a.xsel + ((size_t)tt * a.NV + idx / a.NC) * a.Bpad + row,
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : best;
+        a.logp[(size_t)row * a.L + tt] = xv - (m + __logf(sm));
+      }
     }
     __syncthreads();
   }
@@ -656,10 +699,37 @@ size_t pv_greedy_decode_ws_bytes(int B, int H, int V, int L) {
   return SYNC_BYTES + ((size_t)(L + 1) * Bpad * Hk * 2 + 255) / 256 * 256 + (size_t)L * Bpad * MAX_WGS * sizeof(DecPart);
 }
 
+size_t pv_sample_decode_ws_bytes(int B, int H, int V, int L) {
+  if (B <= 0 || H <= 0 || V <= 0 || L <= 0) return 0;
+  return (pv_greedy_decode_ws_bytes(B, H, V, L) + 255) / 256 * 256 + (size_t)L * round_up(B, GROWS) * MAX_WGS * sizeof(float);
+}
+
+static int decode_impl(const float* gx_table, const float* gx_const, const void* whh_bf16, const float* bhh,
+                       const void* wproj_bf16, int ldwp, const float* bproj, const float* h0, int B, int H, int V, int L,
+                       int sos_id, int mask_col, float inv_temp, const void* rng_state, int site0, void* workspace,
+                       int64_t* seq, float* logp, float* hn, void* stream);
+
 int pv_greedy_decode(const float* gx_table, const float* gx_const, const void* whh_bf16, const float* bhh,
                      const void* wproj_bf16, int ldwp, const float* bproj, const float* h0, int B, int H, int V, int L,
                      int sos_id, int mask_col, float inv_temp, void* workspace, int64_t* seq, float* logp, float* hn,
                      void* stream) {
+  return decode_impl(gx_table, gx_const, whh_bf16, bhh, wproj_bf16, ldwp, bproj, h0, B, H, V, L, sos_id, mask_col, inv_temp,
+                     nullptr, 0, workspace, seq, logp, hn, stream);
+}
+
+int pv_sample_decode(const float* gx_table, const float* gx_const, const void* whh_bf16, const float* bhh,
+                     const void* wproj_bf16, int ldwp, const float* bproj, const float* h0, int B, int H, int V, int L,
+                     int sos_id, int mask_col, float inv_temp, const void* rng_state, int site0, void* workspace,
+                     int64_t* seq, float* logp, float* hn, void* stream) {
+  PV_REQUIRE(rng_state, "pv_sample_decode: null generator state");
+  return decode_impl(gx_table, gx_const, whh_bf16, bhh, wproj_bf16, ldwp, bproj, h0, B, H, V, L, sos_id, mask_col, inv_temp,
+                     rng_state, site0, workspace, seq, logp, hn, stream);
+}
+
+static int decode_impl(const float* gx_table, const float* gx_const, const void* whh_bf16, const float* bhh,
+                       const void* wproj_bf16, int ldwp, const float* bproj, const float* h0, int B, int H, int V, int L,
+                       int sos_id, int mask_col, float inv_temp, const void* rng_state, int site0, void* workspace,
+                       int64_t* seq, float* logp, float* hn, void* stream) {
   PV_REQUIRE(gx_table && whh_bf16 && bhh && wproj_bf16 && bproj && workspace && seq && logp && hn,
              "pv_greedy_decode: null argument");
   PV_REQUIRE(sos_id >= 0 && sos_id < V, "pv_greedy_decode: sos_id %d outside the vocabulary of %d", sos_id, V);
@@ -691,6 +761,10 @@ int pv_greedy_decode(const float* gx_table, const float* gx_const, const void* w
   a.L = L, a.B = B, a.H = H, a.Hk = p.Hk, a.Bpad = p.Bpad, a.V = V, a.G = p.G, a.S = p.S, a.NV = p.NV, a.NC = p.NC;
   a.nwg = p.nwg, a.sos = sos_id, a.mask_col = mask_col, a.ldwp = ldwp, a.inv_temp = inv_temp;
   a.hb_bytes = (unsigned)p.hb_bytes, a.part_bytes = (unsigned)p.part_bytes, a.part_b = (unsigned)(p.part_bytes / 2);
+  a.rng = (const RngState*)rng_state;
+  a.site0 = (unsigned)site0;
+  // (the x image of a sampling decode lies behind the greedy workspace: pv_sample_decode_ws_bytes)
+  a.xsel = rng_state ? (float*)(ws + (pv_greedy_decode_ws_bytes(B, H, V, L) + 255) / 256 * 256) : nullptr;
   static const int dbg = getenv("PV_DECODE_DBG") ? atoi(getenv("PV_DECODE_DBG")) : 0;
   a.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;

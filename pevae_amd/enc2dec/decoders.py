@@ -266,11 +266,12 @@ class DecoderRNN(BaseRNN):
 
     def forward(self, batch_size, inputs=None, init_state=None, attn_context=None, mode=TEACH_FORCE,
                 gen_type='greedy', beam_size=4, latent_variable=None, feature_input=None):
-        if (mode == GEN and gen_type == 'greedy' and getattr(self, "persistent_decode", False) and not self.training
+        if (mode == GEN and (gen_type == 'greedy' or (gen_type == 'sample' and getattr(self, "sample_noise", None) is None))
+                and getattr(self, "persistent_decode", False) and not self.training
                 and not torch.is_grad_enabled() and attn_context is None and not self.use_attention
                 and torch.is_tensor(init_state) and self.rnn.cell == "gru" and self.rnn.num_layers == 1
                 and not self.rnn.bidirectional):
-            return self._persistent_greedy(batch_size, inputs, init_state, latent_variable)
+            return self._persistent_greedy(batch_size, inputs, init_state, latent_variable, gen_type)
         if (mode == GEN and (gen_type == 'greedy' or (gen_type == 'sample' and getattr(self, "sample_noise", None) is None))
                 and getattr(self, "graph_decode", False)
                 and getattr(self, "fused_greedy", False) and not self.training and not torch.is_grad_enabled()
@@ -469,19 +470,24 @@ class DecoderRNN(BaseRNN):
         ret_dict = {DecoderRNN.KEY_SEQUENCE: list(seq_out.split(1, dim=1)), DecoderRNN.KEY_LENGTH: lens.cpu().tolist()}
         return outs.clone(), hid.clone(), ret_dict
 
-    def _persistent_greedy(self, batch_size, inputs, init_state, latent_variable):
+    def _persistent_greedy(self, batch_size, inputs, init_state, latent_variable, gen_type='greedy'):
         """Opt-in (self.persistent_decode = True; eval mode, no grad, one-layer GRU, no attention): the whole free-running
-        greedy decode as ONE persistent kernel launch (ops.greedy_decode / pv_greedy_decode) --
-        no per-token launches at all, W_hh and W_proj resident in LDS across tokens.  Same return value as the fused
-        greedy path: decoder_outputs [B, L] = log-probability of each emitted symbol."""
+        greedy (or `sample`) decode as ONE persistent kernel launch (ops.greedy_decode / pv_greedy_decode / pv_sample_decode,
+        SURVEY section 8 row f3) -- no per-token launches at all, W_hh and W_proj resident in LDS across tokens.  Same return
+        value as the fused per-token path: decoder_outputs [B, L] = log-probability of each emitted symbol; a `sample`
+        decode advances the device generator first and draws token t at call site SAMPLE_SITE + t, exactly as the per-token
+        fused path does."""
         L = inputs.size(1)
+        sample = gen_type == 'sample'
+        if sample:
+            ops.rng_advance(self.embedding.weight.device)
         self.max_length = L
         w_ih, w_hh, b_ih, b_hh = self.rnn.layer_weights(0, 0)
         w, b = self._out_weights()
         h0 = init_state.reshape(-1, init_state.shape[-1])[:batch_size]
         seq, lp, hn = ops.greedy_decode(self.embedding.weight, w_ih, w_hh, b_ih, b_hh, w, b, h0, L, self.sos_id,
                                         latent=latent_variable, inv_temp=1.0 / self.softmax_temperature,
-                                        mask_col=self.unk_id if self.mask_unk else -1)
+                                        mask_col=self.unk_id if self.mask_unk else -1, sample=sample, site0=SAMPLE_SITE)
         before_eos = (seq.eq(self.eos_id).cumsum(1) == 0).sum(1)
         lengths = torch.clamp(before_eos + 1, max=L)
         ret_dict = {DecoderRNN.KEY_SEQUENCE: list(seq.split(1, dim=1)),

@@ -993,11 +993,13 @@ LAST_DECODE_WS = []     # workspace of the most recent pv_greedy_decode launch, 
 
 
 def greedy_decode(emb_weight, w_ih, w_hh, b_ih, b_hh, proj_weight, proj_bias, h0, L, sos_id, latent=None, inv_temp=1.0,
-                  mask_col=-1):
+                  mask_col=-1, sample=False, site0=0):
     """All L tokens of a free-running greedy decode in one persistent launch (pv_greedy_decode; decoders.py:236-262 for a
     one-layer GRU decoder without attention).  The input projection of every vocabulary entry is one GEMM per call
     (gx_table = emb W_ih[:, :E]^T + b_ih), a latent input adds a per-row constant.  h0 [B,H] ->
-    (seq int64 [B,L], logp fp32 [B,L], h_n fp32 [B,H]); no gradient."""
+    (seq int64 [B,L], logp fp32 [B,L], h_n fp32 [B,H]); no gradient.
+    sample=True: gen_type 'sample' in the same launch (pv_sample_decode): token t draws with the device generator
+    (ops.rng_state; advance it between decodes) at call site site0 + t -- the draws of ops.vocab_sample(site=site0 + t)."""
     with torch.no_grad():
         _need_cuda(emb_weight, w_ih, w_hh, b_ih, b_hh, proj_weight, proj_bias, h0)
         B, H = h0.shape
@@ -1023,14 +1025,20 @@ def greedy_decode(emb_weight, w_ih, w_hh, b_ih, b_hh, proj_weight, proj_bias, h0
         whh_bf = pack_matrix(w_hh, Hk)
         Hp = round_up(H, 64)
         wp_bf = pack_matrix(proj_weight, Hp)
-        ws = workspace("greedy_decode", _lib.load().pv_greedy_decode_ws_bytes(B, H, V, L), torch.uint8, dev)
+        nbytes = (_lib.load().pv_sample_decode_ws_bytes if sample else _lib.load().pv_greedy_decode_ws_bytes)(B, H, V, L)
+        ws = workspace("greedy_decode", nbytes, torch.uint8, dev)
         seq = torch.empty((B, L), dtype=torch.int64, device=dev)
         logp = torch.empty((B, L), dtype=torch.float32, device=dev)
         hn = torch.empty((B, H), dtype=torch.float32, device=dev)
         join_side_work()                                   # the grid needs every CU
-        _lib.call("pv_greedy_decode", _p(table), _p(const), _p(whh_bf), _p(b_hh.contiguous()), _p(wp_bf), Hp,
-                  _p(proj_bias.contiguous()), _p(h0.contiguous()), B, H, V, L, int(sos_id), int(mask_col), float(inv_temp),
-                  _p(ws), _p(seq), _p(logp), _p(hn), _stream())
+        if sample:
+            _lib.call("pv_sample_decode", _p(table), _p(const), _p(whh_bf), _p(b_hh.contiguous()), _p(wp_bf), Hp,
+                      _p(proj_bias.contiguous()), _p(h0.contiguous()), B, H, V, L, int(sos_id), int(mask_col), float(inv_temp),
+                      _p(rng_state(dev)), int(site0), _p(ws), _p(seq), _p(logp), _p(hn), _stream())
+        else:
+            _lib.call("pv_greedy_decode", _p(table), _p(const), _p(whh_bf), _p(b_hh.contiguous()), _p(wp_bf), Hp,
+                      _p(proj_bias.contiguous()), _p(h0.contiguous()), B, H, V, L, int(sos_id), int(mask_col), float(inv_temp),
+                      _p(ws), _p(seq), _p(logp), _p(hn), _stream())
         del LAST_DECODE_WS[:]
         LAST_DECODE_WS.append(ws)
         return seq, logp, hn

@@ -408,6 +408,52 @@ def test_decoder_gen_graphed_sample(dev):
     assert len(dec._decode_graphs) == 1
 
 
+@pytest.mark.parametrize("shape", ["golden", "baseline"])
+def test_decoder_gen_persistent_sample(dev, shape):
+    """persistent_decode with gen_type 'sample' (pv_sample_decode: the multinomial draw inside the one-launch decode): from
+    the same generator state the kernel draws what the per-token fused path draws (pv_vocab_sample at call site
+    SAMPLE_SITE + token) -- rows may part only where two perturbed scores nearly tie, since the two paths accumulate their
+    logits in different orders --, the log-probabilities of the emitted symbols agree, a masked <unk> never appears, and the
+    next decode draws anew."""
+    from pevae_amd.enc2dec import decoders as D
+    from pevae_amd import ops
+    if shape == "golden":
+        g = load_golden("decoder_gen_sample")
+        V, L, E, H, B = 37, 7, 12, 16, 4
+        emb = torch.nn.Embedding(V, E, padding_idx=0)
+        dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb, mask_unk=True), g).to(dev)
+        ids, h0 = T(g["ids"], dev), T(g["h0"], dev)
+    else:
+        V, L, E, H, B = 20004, 50, 100, 512, 256
+        torch.manual_seed(4)
+        emb = torch.nn.Embedding(V, E, padding_idx=0)
+        dec = D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb, mask_unk=True).to(dev)
+        with torch.no_grad():
+            dec.project.weight.mul_(3.0)                  # a peaked distribution: sequences are not pure noise
+        ids = torch.zeros((B, L), dtype=torch.long, device=dev)
+        h0 = (torch.randn(1, B, H) * 0.5).to(dev)
+    dec.eval()
+    dec.fused_greedy = True
+    rng = ops.rng_state(dev)
+    with torch.no_grad():
+        before = rng.clone()
+        lp_e, _, ret_e = dec(B, ids, h0, mode=D.GEN, gen_type="sample")
+        rng.copy_(before)
+        dec.persistent_decode = True
+        lp_p, hid_p, ret_p = dec(B, ids, h0, mode=D.GEN, gen_type="sample")
+        seq_next = torch.cat(dec(B, ids, h0, mode=D.GEN, gen_type="sample")[2]["sequence"], 1)
+    torch.cuda.synchronize()
+    ops.greedy_decode_check()
+    seq_e, seq_p = torch.cat(ret_e["sequence"], 1), torch.cat(ret_p["sequence"], 1)
+    same = (seq_e == seq_p).all(1)
+    assert int(same.sum()) >= (B if shape == "golden" else B - 6), int(same.sum())
+    assert tuple(lp_p.shape) == (B, L) and int(seq_p.min()) >= 0 and int(seq_p.max()) < V
+    assert not bool((seq_p == dec.unk_id).any()) and not torch.equal(seq_next, seq_p)
+    close(lp_p[same], lp_e[same].cpu(), rtol=0, atol=2e-3)
+    lens_e, lens_p = np.asarray(ret_e["length"]), np.asarray(ret_p["length"])
+    assert (lens_e[same.cpu().numpy()] == lens_p[same.cpu().numpy()]).all()
+
+
 @pytest.mark.parametrize("mask_unk", [False, True])
 def test_decoder_gen_persistent_greedy_golden(dev, mask_unk):
     """Opt-in persistent_decode (pv_greedy_decode: all tokens in one launch) on the reference's own greedy run: the emitted
