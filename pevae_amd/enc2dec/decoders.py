@@ -272,11 +272,13 @@ class DecoderRNN(BaseRNN):
                 and torch.is_tensor(init_state) and self.rnn.cell == "gru" and self.rnn.num_layers == 1
                 and not self.rnn.bidirectional):
             return self._persistent_greedy(batch_size, inputs, init_state, latent_variable, gen_type)
-        if (mode == GEN and (gen_type == 'greedy' or (gen_type == 'sample' and getattr(self, "sample_noise", None) is None))
+        if (mode == GEN and (gen_type == 'greedy' or (gen_type == 'sample' and getattr(self, "sample_noise", None) is None)
+                             or (gen_type == 'beam' and beam_size <= ops.VOCAB_TOPK_MAX))
                 and getattr(self, "graph_decode", False)
                 and getattr(self, "fused_greedy", False) and not self.training and not torch.is_grad_enabled()
                 and attn_context is None and not self.use_attention and torch.is_tensor(init_state)):
-            return self._graphed_greedy(batch_size, inputs, init_state, latent_variable, gen_type)
+            return self._graphed_greedy(batch_size, inputs, init_state, latent_variable, gen_type,
+                                        beam_size if gen_type == 'beam' else 1)
         ret_dict = dict()
         self.max_length = inputs.size(1)                # decoders.py:201 (GEN still needs `inputs` for this)
         if self.use_attention:
@@ -433,16 +435,18 @@ class DecoderRNN(BaseRNN):
         ret_dict[DecoderRNN.KEY_LENGTH] = lengths if getattr(self, "_device_lengths", False) else lengths.tolist()
         return decoder_outputs, decoder_hidden, ret_dict
 
-    def _graphed_greedy(self, batch_size, inputs, init_state, latent_variable, gen_type='greedy'):
+    def _graphed_greedy(self, batch_size, inputs, init_state, latent_variable, gen_type='greedy', beam_size=1):
         """Opt-in (self.graph_decode = self.fused_greedy = True, eval mode, no grad, GRU cell, no attention): the whole
-        free-running greedy (or `sample`) decode -- max_length x (embedding, input projection, one recurrence step,
-        projection + arg-max / multinomial draw) -- captured once per (batch, length) into a HIP graph and replayed; the only
+        free-running greedy (or `sample`, or fused `beam`) decode -- max_length x (embedding, input projection, one recurrence
+        step, projection + arg-max / multinomial draw / top-k and candidate ranking; for beam also the back-tracking) --
+        captured once per (mode, batch, length) into a HIP graph and replayed; the only
         host work per decode is the copy of the initial state in and one read-back of the lengths.  Weights are re-packed
         inside the graph, so a replay follows parameter updates; the sampler's step counter lives in device memory and
         is advanced inside the graph, so every replay of a `sample` decode draws anew.  Same return value as the fused
         per-token path."""
         L = inputs.size(1)
-        key = (gen_type, batch_size, L, tuple(init_state.shape), None if latent_variable is None else tuple(latent_variable.shape))
+        key = (gen_type, beam_size, batch_size, L, tuple(init_state.shape),
+               None if latent_variable is None else tuple(latent_variable.shape))
         cache = self.__dict__.setdefault("_decode_graphs", {})
         ent = cache.get(key)
         if ent is None:
@@ -451,11 +455,11 @@ class DecoderRNN(BaseRNN):
             width = torch.zeros((batch_size, L), dtype=torch.long, device=st.device)     # only its width is read
             self.graph_decode, self._device_lengths = False, True
             try:
-                self.forward(batch_size, width, st, None, GEN, gen_type, 1, lt)             # warm-up: every workspace exists
+                self.forward(batch_size, width, st, None, GEN, gen_type, beam_size, lt)     # warm-up: every workspace exists
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    outs, hid, ret = self.forward(batch_size, width, st, None, GEN, gen_type, 1, lt)
+                    outs, hid, ret = self.forward(batch_size, width, st, None, GEN, gen_type, beam_size, lt)
                     seq = torch.cat(ret[DecoderRNN.KEY_SEQUENCE], dim=1)
                     lens = ret[DecoderRNN.KEY_LENGTH]
             finally:

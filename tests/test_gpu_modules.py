@@ -682,6 +682,30 @@ def test_decoder_gen_fused_beam(dev):
     assert float((torch.cat(ret_f["sequence"], 1).cpu() == want).float().mean()) >= 0.6
 
 
+def test_decoder_gen_graphed_beam(dev):
+    """graph_decode with gen_type 'beam' (fused step): the whole beam decode -- per-token top-k, candidate ranking, back
+    pointers and the final back-tracking -- replayed from one HIP graph equals the eager fused decode, for the inputs it
+    was captured with and for new ones."""
+    from pevae_amd.enc2dec import decoders as D
+    g = load_golden("decoder_gen_beam")
+    V, L, E, H, B, beam = 37, 7, 12, 16, 4, int(g["beam"])
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    dec = load_params(D.DecoderRNN(V, L, E, H, 1, 2, 3, rnn_cell="gru", embedding=emb), g).to(dev)
+    dec.eval()
+    dec.fused_greedy = True
+    ids = T(g["ids"], dev)
+    gen = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for k, h0 in enumerate((T(g["h0"], dev), torch.randn(g["h0"].shape, generator=gen).to(dev))):
+            dec.graph_decode = False
+            lp_e, hid_e, ret_e = dec(B, ids, h0, mode=D.GEN, gen_type="beam", beam_size=beam)
+            dec.graph_decode = True
+            lp_g, hid_g, ret_g = dec(B, ids, h0, mode=D.GEN, gen_type="beam", beam_size=beam)
+            assert torch.equal(torch.cat(ret_e["sequence"], 1), torch.cat(ret_g["sequence"], 1)), k
+            assert ret_e["length"] == ret_g["length"] and torch.equal(lp_e, lp_g) and torch.equal(hid_e, hid_g), k
+    assert len(dec._decode_graphs) == 1
+
+
 def test_vocab_topk_large(dev):
     """pv_vocab_topk at the step's vocabulary (V = 20004, ragged last slab), k = 10 and 16, with and without a masked column,
     against torch.topk on the log-softmax of the same bf16 operands: same symbols in the same order up to near-ties, same

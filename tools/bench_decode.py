@@ -17,7 +17,7 @@ from pevae_amd import ops
 cases = [("greedy", 1, False, False, False), ("greedy", 1, True, False, False), ("greedy", 1, True, True, False),
          ("greedy", 1, True, False, True), ("sample", 1, False, False, False), ("sample", 1, True, False, False),
          ("sample", 1, True, True, False), ("sample", 1, True, False, True), ("beam", 4, False, False, False),
-         ("beam", 4, True, False, False)]
+         ("beam", 4, True, False, False), ("beam", 4, True, True, False)]
 for gen_type, beam, fused, graphed, persistent in cases:
     dec.fused_greedy, dec.graph_decode, dec.persistent_decode = fused, graphed, persistent
     Bq = B // beam                                  # beam: the same B x L token steps in all
