@@ -127,7 +127,12 @@ class DLSVAE(nn.Module):
         if self._cut is not None:
             self.backward_vocab(loss)
             return self.backward_rest(loss)
-        self._run_backward(lambda: self.valid_loss(loss, batch_cnt, step=step).backward())
+        total = self.valid_loss(loss, batch_cnt, step=step)
+        # the backward seed is a cached scalar one: `total.backward()` alone fills a fresh one-element tensor every step
+        seed = self.__dict__.get("_one")
+        if seed is None or seed.device != total.device or seed.dtype != total.dtype:
+            seed = self.__dict__["_one"] = torch.ones((), dtype=total.dtype, device=total.device)
+        self._run_backward(lambda: total.backward(seed))
 
     @staticmethod
     def _run_backward(fn):
