@@ -389,6 +389,7 @@ def test_decoder_gen_graphed_sample(dev):
     dec.eval()
     dec.fused_greedy = True
     ids, h0 = T(g["ids"], dev), T(g["h0"], dev)
+    ops.rng_seed(20240608, dev)                       # the draws do not depend on what ran before this test
     rng = ops.rng_state(dev)
     with torch.no_grad():
         dec.graph_decode = True
@@ -434,6 +435,7 @@ def test_decoder_gen_persistent_sample(dev, shape):
         h0 = (torch.randn(1, B, H) * 0.5).to(dev)
     dec.eval()
     dec.fused_greedy = True
+    ops.rng_seed(20240607, dev)                       # the draws do not depend on what ran before this test
     rng = ops.rng_state(dev)
     with torch.no_grad():
         before = rng.clone()
@@ -446,6 +448,7 @@ def test_decoder_gen_persistent_sample(dev, shape):
     ops.greedy_decode_check()
     seq_e, seq_p = torch.cat(ret_e["sequence"], 1), torch.cat(ret_p["sequence"], 1)
     same = (seq_e == seq_p).all(1)
+    print("rows with the per-token path's symbols:", int(same.sum()), "of", B)
     assert int(same.sum()) >= (B if shape == "golden" else B - 6), int(same.sum())
     assert tuple(lp_p.shape) == (B, L) and int(seq_p.min()) >= 0 and int(seq_p.max()) < V
     assert not bool((seq_p == dec.unk_id).any()) and not torch.equal(seq_next, seq_p)
