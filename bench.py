@@ -332,16 +332,23 @@ def main():
         torch.cuda.synchronize()
         CAPTURE_MODE = "thread_local"
         ga, gb, gc_, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # N = 1 without the cut schedule: nothing happens between the backward pass and the optimizer, so zero_grad + forward +
+        # backward + guards + clip + Adam are ONE graph (as engine.GraphedStep replays them); a second graph for the optimizer
+        # costs the host's launch latency between the two replays once per step
+        one_graph = world == 1 and not split and not three and not rehearse and not reducer.external_sparse
         with torch.cuda.graph(ga, stream=side, capture_error_mode=CAPTURE_MODE):
             static_loss = part_a()
+            if one_graph:
+                optimizer_step()
         if split:
             with torch.cuda.graph(gb, pool=ga.pool(), stream=side, capture_error_mode=CAPTURE_MODE):
                 part_b()
         if three:
             with torch.cuda.graph(gc_, pool=ga.pool(), stream=side, capture_error_mode=CAPTURE_MODE):
                 part_c()
-        with torch.cuda.graph(g2, pool=ga.pool(), stream=side, capture_error_mode=CAPTURE_MODE):
-            optimizer_step()
+        if not one_graph:
+            with torch.cuda.graph(g2, pool=ga.pool(), stream=side, capture_error_mode=CAPTURE_MODE):
+                optimizer_step()
         ops.LAST_GRU_SYNC.clear()
 
         import collections
@@ -366,9 +373,11 @@ def main():
             if three:
                 gc_.replay()
             t6 = time.perf_counter(); T["gc"] += t6 - t5
-            reducer.finish(sparse_ids)
+            if not one_graph:
+                reducer.finish(sparse_ids)
             t7 = time.perf_counter(); T["finish"] += t7 - t6
-            g2.replay()
+            if not one_graph:
+                g2.replay()
             T["g2"] += time.perf_counter() - t7; T["n"] += 1
             return static_loss
     for i in range(args.warmup):
@@ -470,7 +479,7 @@ def main():
                     measured_on=("the instrumented eager pass (%d steps, HIP events on the launch stream), every kernel launched on "
                                  "the whole chip" % args.profile_steps) +
                                 ("; the timed steps run vocab_dw_kernel as two half-vocabulary launches on half the CUs each, beside "
-                                 "the decoder's and the encoder's backward recurrence" if beside else ""),
+                                 "the decoder's and the encoder's backward recurrence" if (beside and not split and not three) else ""),
                     kernel=("vocab_fwd_dh_kernel + vocab_fwd_combine_kernel + vocab_dw_kernel + vocab_dw_reduce_kernel "
                             "(fused vocabulary projection + softmax + NLL forward, dH and dW; no [T,V] matrix in HBM)") if fused
                     else "gemm_nt_kernel<EpiSoftmax|EpiProb|EpiStore> (vocab projection+softmax+NLL fwd+bwd group)",
