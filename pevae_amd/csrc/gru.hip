@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
                   0, AUX_SC1);
           }
       }
+      STAMP(9);
       // (a) independent of the exchange: saved gates / states / upstream gradients of this lane's 4 rows.  Everything is
       //     loaded unconditionally from clamped (always valid) addresses and masked where it is used: loads under
       //     data-dependent branches made the compiler wait for each one at the branch merge -- five serial round trips,

@@ -14,7 +14,7 @@ w_hh = (torch.randn(3 * H, H, device=dev) * 0.05).requires_grad_()
 b = torch.zeros(3 * H, device=dev, requires_grad=True)
 h0 = (torch.randn(B, H, device=dev) * 0.1).requires_grad_()
 names = ["(a) loads issue", "poll", "barrier", "A loads+mfma", "part barrier", "combine+gates+barrier", "publish+drain",
-         "barrier+arrive", "dgi stores issue"]
+         "barrier+arrive", "dgi stores issue", "(b) fragment loads issue"]
 ops.TIMERS = {}
 for _ in range(5):
     out, hn, _ = ops.GRULayer.apply(x, h0, w_ih, w_hh, b, b, True)
