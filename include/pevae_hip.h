@@ -411,18 +411,19 @@ typedef struct pv_block_call {      /* one Block of a launch; arrays are in the 
   long lddx;
   float* dY;                        /* scratch [M][grad_width] */
   float* cpart;                     /* scratch 5 * 4 * cdiv(M,16) floats (one partial per member of a 4-workgroup cluster) */
-  float* ppart;                     /* scratch cdiv(M,16) * part_width floats */
+  float* ppart;                     /* scratch cdiv(M,4) * part_width floats (one row per 4-row slab) */
   float* dW[5];
   float* db[5];
   float* dgamma;
   float* dbeta;
 } pv_block_call;
 /* Up to PV_BLOCK_GROUP_MAX INDEPENDENT Blocks per launch (the two pyramids' Blocks of a level, or the three Blocks of a
- * DLS_Auto level, run side by side).  Blocks 512 wide are walked by clusters of 4 workgroups per 16-row slab that split
- * every layer's columns and hand their slices to each other through `save` (forward) / `dx` and `dY` (backward), with
- * bounded waits (pv_block_sync_error reports one that gave up).  Launches of pv_block_fwd on ONE device must not overlap
- * each other, nor launches of pv_block_bwd each other (each kind shares the device's hand-off counters); stream order,
- * as every caller here uses, is enough. */
+ * DLS_Auto level, run side by side).  Default kernels (round 3): one workgroup per FOUR batch rows walks the whole Block
+ * alone (v_mfma_f32_4x4x1_16b_f32, exact fp32; cdiv(M,4) workgroups per Block, no hand-offs).  With pv_block_rows(16, ..)
+ * the round-2 kernels run instead: 16-row slabs, and Blocks 512 wide walked by clusters of 4 workgroups per slab that
+ * split every layer's columns and hand their slices to each other through `save` (forward) / `dx` and `dY` (backward),
+ * with bounded waits (pv_block_sync_error reports one that gave up); launches of those on ONE device must not overlap
+ * each other (each kind shares the device's hand-off counters); stream order, as every caller here uses, is enough. */
 int pv_block_fwd(const pv_block_call* calls, int n, void* stream);
 int pv_block_bwd(const pv_block_call* calls, int n, void* stream);
 /* pv_block_bwd in two launches: phase 1 = the dx chain (block_bwd_dx_kernel: dL/dx, dY, the per-workgroup partials),
@@ -434,6 +435,12 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
 /* *flag = 1 if an inter-workgroup wait of pv_block_fwd has timed out since the library was loaded (synchronises the
  * device; tests and debugging -- a timed-out launch has produced garbage).  No counterpart in the reference. */
 int pv_block_sync_error(int* flag);
+/* Which kernels pv_block_fwd / pv_block_bwd* launch: rows = 4 (default) or 16, wide != 0 (default) = the 4-row kernels also
+ * for launches holding a 512-wide Block (0: those keep the 16-row clusters); a negative argument leaves that setting as
+ * it is (environment at load: PEVAE_BLOCK_ROWS, PEVAE_BLOCK_ROWS_WIDE).  Returns the rows value now in force.  The forward
+ * pass, the dx chain and the parameter-gradient launch of one step must run under one setting (the number of
+ * per-workgroup partial rows in cpart / ppart follows it).  No counterpart in the reference (tests and A/B timing). */
+int pv_block_rows(int rows, int wide);
 /* One level of DLS_Auto's train branch (:3285-3311) as two elementwise launches.  Q / Pr [B][2n]: outputs of dis_layer /
  * dis_layer2 (mean | log sigma halves).  ls = mean + exp(logsigma) * eps + a2 (:3299-3300), out = lay + ls (:3310),
  * kl[0] = (ew + cw) * mean_b sum_d KL(prior || posterior) (:3305-3306; the backward gives the prior's gradient the

@@ -84,6 +84,7 @@ SIGNATURES = {
     "pv_block_bwd": (i32, [vp, i32, vp]),
     "pv_block_bwd_phase": (i32, [vp, i32, i32, vp]),
     "pv_block_sync_error": (i32, [C.POINTER(i32)]),
+    "pv_block_rows": (i32, [i32, i32]),
     "pv_dls_level_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
     "pv_dls_level_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
     "pv_dls_level_next_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),

@@ -1277,6 +1277,8 @@ __global__ __launch_bounds__(NT) void block_bwd_dx_cluster_kernel(BlockBwdGroup 
   if (tid < 5) a.cpart[(size_t)tid * nwg * G + slab * G + g] = cred[0][tid] + cred[1][tid] + cred[2][tid] + cred[3][tid];
 }
 
+#include "block_rows.h"
+
 struct ParamReduceArgs {
   const float* ppart;    // [nwg][width]
   int nwg, width;
@@ -1317,6 +1319,31 @@ int fill_desc(BlockDesc& d, const pv_block_call& c, bool transposed, const char*
 }
 
 int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+// Which kernels walk a launch's Blocks: 4-row slabs (block_rows.h) unless PEVAE_BLOCK_ROWS=16 asks for the 16-row kernels
+// (single workgroups below 512 columns, clusters of four at 512).  PEVAE_BLOCK_ROWS_WIDE=0 keeps the clusters for launches
+// with a 512-wide Block (a workgroup of the 4-row kernel streams all 2.9 MB of such a Block through its own L1, ~25 us,
+// against 55-70 us for the cluster launch with its hand-offs: 2.759 vs 2.771 ms per step, twice).  Read once: forward, dx
+// chain and parameter-gradient launch of a process must agree on the number of per-workgroup partial rows.
+// Which kernels walk a launch's Blocks (pv_block_rows; environment at first use): 4-row slabs (block_rows.h) unless 16 is
+// asked for (single workgroups below 512 columns, clusters of four at 512).  wide = 0 keeps the clusters for launches
+// with a 512-wide Block: a workgroup of the 4-row kernel streams all 2.9 MB of such a Block through its own L1, ~25 us,
+// against 55-70 us for the cluster launch with its hand-offs -- 2.759 vs 2.771 ms per step, twice, so wide = 1 by default.
+int g_rows = -1, g_rows_wide = -1;
+void rows_init() {
+  if (g_rows < 0) {
+    const char* e = getenv("PEVAE_BLOCK_ROWS");
+    g_rows = e && atoi(e) == 16 ? 16 : 4;
+  }
+  if (g_rows_wide < 0) {
+    const char* f = getenv("PEVAE_BLOCK_ROWS_WIDE");
+    g_rows_wide = f ? (atoi(f) != 0) : 1;
+  }
+}
+bool rows_mode(int gmax) {
+  rows_init();
+  return g_rows == 4 && (gmax == 1 || g_rows_wide != 0);
+}
 
 // Cluster size of a Block's forward launch: as many members as leave every one of them at least 64 columns of the
 // narrowest layer and whole 32-column tiles of every layer; only Blocks wide enough to be bound by one CU's MFMA and
@@ -1390,6 +1417,24 @@ int pv_block_fwd(const pv_block_call* calls, int n, void* stream) {
     if (a.G > gmax) gmax = a.G;
   }
   for (int b = n; b < PV_BLOCK_GROUP_MAX; ++b) g.a[b] = g.a[0];
+  if (rows_mode(gmax)) {                        // 4-row slabs: cdiv(M, 4) workgroups per Block
+    BlockFwdGroup1 g1;
+    size_t smem4 = 0;
+    int nslab4 = 0;
+    for (int b = 0; b < PV_BLOCK_GROUP_MAX; ++b) {
+      const BlockFwdArgs& a = g.a[b];
+      g1.a[b] = BlockFwdArgs1{a.x, a.ldx, a.M, a.d, a.save, a.mean, a.rstd, a.out, a.ldo, a.LD};
+      const size_t need = (size_t)rows_fwd_lds_floats(a.LD, PartLayout(a.d.Din, a.d.mid, a.d.Dout).width) * sizeof(float);
+      if (need > smem4) smem4 = need;
+      if (cdiv(a.M, RR) > nslab4) nslab4 = cdiv(a.M, RR);
+    }
+    static size_t seen4 = 0;
+    int rc = set_lds(block_fwd_rows_kernel, smem4, &seen4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(block_fwd_rows_kernel, dim3(nslab4, n), dim3(NTR), smem4, (hipStream_t)stream, g1);
+    PV_LAUNCH_CHECK("block_fwd_rows_kernel");
+    return PV_OK;
+  }
   if (gmax == 1) {                              // nothing to split: the single-workgroup kernel (64-column tiles)
     BlockFwdGroup1 g1;
     size_t smem1 = 0;
@@ -1415,6 +1460,14 @@ int pv_block_fwd(const pv_block_call* calls, int n, void* stream) {
   return PV_OK;
 }
 
+int pv_block_rows(int rows, int wide) {
+  PV_REQUIRE(rows < 0 || rows == 4 || rows == 16, "pv_block_rows: rows is 4 or 16 (negative: unchanged)");
+  rows_init();
+  if (rows > 0) g_rows = rows;
+  if (wide >= 0) g_rows_wide = wide != 0;
+  return g_rows;
+}
+
 int pv_block_sync_error(int* flag) {
   PV_REQUIRE(flag, "pv_block_sync_error: null argument");
   unsigned v = 0;
@@ -1433,8 +1486,13 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
   BlockBwdGroup g;
   ParamReduceGroup pr;
   LinGroupItem it[5 * PV_BLOCK_GROUP_MAX];
-  size_t smem = 0;
+  size_t smem = 0, smem4 = 0;
   int nwg_max = 0, width_max = 0, gmax = 1;
+  for (int b = 0; b < n; ++b) {
+    const int G = block_cluster(calls[b].M, calls[b].Din, calls[b].mid, calls[b].Dout);
+    if (G > gmax) gmax = G;
+  }
+  const bool rows4 = rows_mode(gmax);            // 4-row slabs: cdiv(M, 4) partial rows per Block, no clusters
   for (int b = 0; b < n; ++b) {
     const pv_block_call& c = calls[b];
     int rc = check_dims(c.M, c.Din, c.mid, c.Dout, "pv_block_bwd");
@@ -1451,14 +1509,15 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
     a.dout = c.dout; a.lddo = c.lddo; a.x = c.x; a.ldx = c.ldx; a.out = c.out; a.ldo = c.ldo; a.M = c.M; a.save = c.save;
     a.mean = c.mean; a.rstd = c.rstd; a.dx = c.dx; a.lddx = c.lddx; a.dY = c.dY; a.cpart = c.cpart; a.ppart = c.ppart;
     a.LD = max3(c.Din, c.mid, c.Dout) + 4;
-    a.G = block_cluster(c.M, c.Din, c.mid, c.Dout);
+    a.G = rows4 ? 1 : block_cluster(c.M, c.Din, c.mid, c.Dout);
     a.dx_bytes = (unsigned)((size_t)c.M * c.lddx * sizeof(float));
     a.dY_bytes = (unsigned)((size_t)c.M * GradLayout(c.Din, c.mid).width * sizeof(float));
-    if (a.G > gmax) gmax = a.G;
-    const int nwg = cdiv(c.M, RB);
+    const int nwg = cdiv(c.M, rows4 ? RR : RB);
     const PartLayout P(c.Din, c.mid, c.Dout);
     const size_t need = ((size_t)4 * RB * a.LD + P.width + 8 + 2 * RB + 24 + 8) * sizeof(float);
     if (need > smem) smem = need;
+    const size_t need4 = (size_t)rows_bwd_lds_floats(a.LD, P.width) * sizeof(float);
+    if (need4 > smem4) smem4 = need4;
     if (nwg > nwg_max) nwg_max = nwg;
     if (P.width > width_max) width_max = P.width;
 
@@ -1489,7 +1548,19 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
     g.a[b] = g.a[0];
     pr.r[b] = pr.r[0];
   }
-  if (phase & 1) {
+  if ((phase & 1) && rows4) {
+    static size_t seen4 = 0;
+    int rc = set_lds(block_bwd_dx_rows_kernel, smem4, &seen4);
+    if (rc) return rc;
+    BlockBwdGroup1 g1;
+    for (int b = 0; b < PV_BLOCK_GROUP_MAX; ++b) {
+      const BlockBwdArgs& a = g.a[b];
+      g1.a[b] = BlockBwdArgs1{a.dout, a.lddo, a.x, a.ldx, a.out, a.ldo, a.M, a.d, a.save, a.mean, a.rstd, a.dx, a.lddx, a.dY,
+                              a.cpart, a.ppart, a.LD};
+    }
+    hipLaunchKernelGGL(block_bwd_dx_rows_kernel, dim3(nwg_max, n), dim3(NTR), smem4, st, g1);
+    PV_LAUNCH_CHECK("block_bwd_dx_rows_kernel");
+  } else if (phase & 1) {
     static size_t seen = 0, seen_c = 0;
     int rc = gmax == 1 ? set_lds(block_bwd_dx_kernel, smem, &seen) : set_lds(block_bwd_dx_cluster_kernel, smem, &seen_c);
     if (rc) return rc;

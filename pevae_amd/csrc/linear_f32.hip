@@ -208,7 +208,11 @@ __device__ __forceinline__ void linear_tile(const LinArgs& g, const int m0, cons
   const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
   float r1 = 0.f;
   if (g.r1_c) {
-    for (int i = 0; i < g.r1_nc; ++i) r1 += g.r1_c[i];       // fixed order
+    // sum of the per-workgroup partials, the same fixed order in every wave of every tile: lane l adds partials l, l + 64, ...,
+    // then a butterfly over the lanes (64 partials per Block with 4-row slabs: a serial loop of dependent loads cost ~10 us)
+    for (int i = tid & 63; i < g.r1_nc; i += 64) r1 += g.r1_c[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r1 += __shfl_xor(r1, o, 64);
     r1 *= g.alpha_dev ? g.alpha_dev[0] : 1.f;
   }
 #pragma unroll
@@ -261,8 +265,15 @@ __global__ __launch_bounds__(256) void linear_f32_group_kernel(LinGroup G) {
     const ColReduceJob& a = G.jobs[j];
     const int c = ((int)blockIdx.x - gemm_tiles - (j ? G.job_end[j - 1] : 0)) * 256 + threadIdx.x;
     if (c >= a.width) return;
-    float s = 0.f;
-    for (int g = 0; g < a.nrows; ++g) s += a.part[(size_t)g * a.width + c];     // fixed order
+    // fixed order: eight interleaved partial sums (independent loads in flight), then their sum
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int g = 0;
+    for (; g + 8 <= a.nrows; g += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] += a.part[(size_t)(g + j) * a.width + c];
+    }
+    for (int j = 0; g < a.nrows; ++g, ++j) p[j] += a.part[(size_t)g * a.width + c];
+    const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     int seg = 0;
     while (c >= a.seg_end[seg]) ++seg;
     float* d = a.dst[seg] + (c - (seg ? a.seg_end[seg - 1] : 0));

@@ -1135,6 +1135,15 @@ def block_check():
         raise _lib.PevaeHipError("pv_block_fwd: a bounded inter-workgroup wait timed out")
 
 
+def block_rows(rows=-1, wide=-1):
+    """Select the fused Block kernels: rows 4 (default: 4-row slabs) or 16 (the round-2 16-row slabs / clusters); wide: 4-row
+    kernels also for launches with a 512-wide Block.  -> rows now in force.  Not between a forward pass and its backward."""
+    r = _lib.load().pv_block_rows(int(rows), int(wide))
+    if r < 0:
+        raise _lib.PevaeHipError("pv_block_rows: rows must be 4 or 16")
+    return r
+
+
 def gru_check_sync(sync, NG, what):
     """Raise if the persistent kernel reported a timed-out spin (debug / tests; forces a device sync)."""
     flag = int(sync.view(torch.int32)[NG].item())
@@ -2106,7 +2115,7 @@ class BlockGroupFn(torch.autograd.Function):
             dx = torch.empty((M, din), dtype=torch.float32, device=dev)
             dY = torch.empty((M, gw), dtype=torch.float32, device=dev)
             cpart = torch.empty(5 * 4 * nwg, dtype=torch.float32, device=dev)      # (a cluster member each: pevae_hip.h)
-            ppart = torch.empty((nwg, pw), dtype=torch.float32, device=dev)
+            ppart = torch.empty(((M + 3) // 4, pw), dtype=torch.float32, device=dev)      # a row per 4-row slab
             params = list(p_W) + list(p_bias) + [p_g, p_b]
             sinks = [grad_sink(p, tuple(p.shape)) for p in params]
             fused = all(s is not None for s in sinks)      # all-or-nothing: one accumulate flag per Block

@@ -19,6 +19,14 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def default_block_kernels():
+    """Every test starts and ends with the default fused Block kernels (a test may select the 16-row ones)."""
+    yield
+    from pevae_amd import ops
+    ops.block_rows(4, 1)
+
+
 def T(a, dev):
     return torch.from_numpy(np.array(a)).to(dev)
 
@@ -51,12 +59,15 @@ def test_block_golden(dev):
 @pytest.mark.parametrize("M,din,dout,mid,sinks", [(37, 48, 32, 96, False), (256, 128, 64, 64, True), (16, 16, 16, 16, False),
                                                   (70, 512, 256, 256, True), (256, 256, 512, 512, False),
                                                   (250, 192, 256, 256, True)])
-def test_block_fused_matches_unfused(dev, M, din, dout, mid, sinks):
-    """The one-launch Block kernels (pv_block_fwd / pv_block_bwd) against the per-linear path that the reference goldens
-    pin (test_block_golden), on ragged row counts, with gradients returned and accumulated into existing .grad."""
+@pytest.mark.parametrize("rows", [4, 16])
+def test_block_fused_matches_unfused(dev, M, din, dout, mid, sinks, rows):
+    """The one-launch Block kernels (pv_block_fwd / pv_block_bwd; rows = 4: the 4-row slabs that are the default, 16: the
+    round-2 16-row slabs and clusters) against the per-linear path that the reference goldens pin (test_block_golden), on
+    ragged row counts, with gradients returned and accumulated into existing .grad."""
     import copy
     from pevae_amd import dls_latent as L, ops
     torch.manual_seed(3)
+    ops.block_rows(rows)
     blk_a = L.Block(din, dout, mid).to(dev).train()
     blk_b = copy.deepcopy(blk_a)
     assert ops.block_fusable(din, mid, dout)

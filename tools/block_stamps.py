@@ -29,11 +29,13 @@ def main():
         for k, nm in ((0, "fwd"), (1, "bwd")):
             t = [buf[k * 32 + i] for i in range(13)]
             order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 10] if k == 0 else [0, 1, 2, 3, 12, 4, 5, 6, 7, 8, 9, 10]
+            if k == 0 and t[11] >= t[10]:          # the 4-row kernel: [even] = products done, [odd] = epilogue + barrier, [11] = end
+                order.append(11)
             seq = [(i, t[i]) for i in order]
             print("Block(%d,%d,%d) %s: total %.2f us" % (din, dout, mid, nm, (seq[-1][1] - seq[0][1]) / 100.0))
             if k == 0:
                 cyc = buf[15] - buf[14]
-                print("   shader clock during the kernel: %.0f MHz" % (cyc / ((seq[-1][1] - seq[0][1]) / 100.0)))
+                print("   shader clock during the kernel: %.0f MHz" % (cyc / ((max(t[10], t[11]) - t[0]) / 100.0)))
             print("   " + "  ".join("[%d]+%.2f" % (seq[j][0], (seq[j][1] - seq[j - 1][1]) / 100.0) for j in range(1, len(seq))))
 
 
