@@ -58,7 +58,7 @@ def test_block_golden(dev):
 
 @pytest.mark.parametrize("M,din,dout,mid,sinks", [(37, 48, 32, 96, False), (256, 128, 64, 64, True), (16, 16, 16, 16, False),
                                                   (70, 512, 256, 256, True), (256, 256, 512, 512, False),
-                                                  (250, 192, 256, 256, True)])
+                                                  (250, 192, 256, 256, True), (3, 32, 16, 16, True), (129, 96, 128, 128, False)])
 @pytest.mark.parametrize("rows", [4, 16])
 def test_block_fused_matches_unfused(dev, M, din, dout, mid, sinks, rows):
     """The one-launch Block kernels (pv_block_fwd / pv_block_bwd; rows = 4: the 4-row slabs that are the default, 16: the
