@@ -263,7 +263,7 @@ def main():
     state = {}
 
     def part_a():                                   # zero_grad, forward, vocabulary backward (N = 1: the whole backward)
-        opt.zero_grad()
+        opt.zero_grad(beside_forward=True)
         state["loss"] = loss = model(feed)
         if split:
             model.backward_vocab(loss)

@@ -184,6 +184,8 @@ class DLSVAE(nn.Module):
         if self.training and self.config.dropout > 0:
             ops.rng_advance(self.x_embedding.weight.device)      # new dropout masks every step, also under graph replay
         prep_late = PREPARE_LATE and self.latent_stack == "dls"
+        rating_ids = data_feed["ratings"].ge(3).long()                                    # :760
+        self.__dict__["_rating_ids"] = rating_ids
         if data_feed["user_ids"].is_cuda and mode == TEACH_FORCE and PREPARE_ON_SIDE and not prep_late:
             self._prepare_on_side(data_feed)
         early_sn = self.latent_stack == "dls" and data_feed["user_ids"].is_cuda
@@ -196,7 +198,7 @@ class DLSVAE(nn.Module):
                 ops.spectral_prepass(self._sn_modules, self.training, cache=self._sn_cache)
         user = ops.embedding(self.user_embedding.weight, data_feed["user_ids"])          # :758
         item = ops.embedding(self.item_embedding.weight, data_feed["item_ids"])          # :759
-        rating = ops.embedding(self.rating_embedding.weight, data_feed["ratings"].ge(3).long())   # :760
+        rating = ops.embedding(self.rating_embedding.weight, rating_ids)                  # :760
         words = ops.embedding(self.x_embedding.weight, data_feed["sentence_embeddings"], self.pad_id)
         enc_outs, enc_last = self.x_encoder(words)                                        # :765
         h = enc_last.transpose(0, 1).contiguous().squeeze(1)                              # :766
@@ -286,6 +288,16 @@ class DLSVAE(nn.Module):
                                  (w_ih, ops.round_up(w_ih.shape[1], 64))])
             if not (self.config.use_attention) and torch.is_grad_enabled():
                 ops.precompact_targets(labels, (Ld, B, Bpad), self.pad_id)
+            if not self.use_feature and self.training:
+                dec.prepare_teacher_forced(data_feed["input_ids"])        # input embedding + dropout + input projection
+            if torch.is_grad_enabled():
+                # the id sorts of the table gradients (the lookups' backward passes are left with their segmented sums)
+                ops.presort_lookup(data_feed["sentence_embeddings"], self.x_embedding.weight, "words")
+                ops.presort_lookup(data_feed["user_ids"], self.user_embedding.weight, "user")
+                ops.presort_lookup(data_feed["item_ids"], self.item_embedding.weight, "item")
+                ops.presort_lookup(self.__dict__["_rating_ids"], self.rating_embedding.weight, "rating")
+                if not self.use_feature and self.training:
+                    ops.presort_lookup(data_feed["input_ids"], dec.embedding.weight, "dec_in")
 
     def _rating(self, user, item):
         x = torch.cat([user, item], -1)

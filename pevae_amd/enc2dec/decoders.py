@@ -227,7 +227,10 @@ class DecoderRNN(BaseRNN):
         # for) then runs beside the latent stack's backward instead of in front of it
         side = latent_variable is None and input_var.size(1) > 1 and torch.is_grad_enabled() and input_var.is_cuda
         leaf = None
-        if (side and ops.LEAF_DECODER_INPUT and self.rnn.cell == "gru" and self.rnn.num_layers == 1
+        ahead = self.__dict__.pop("_input_ahead", None)
+        if ahead is not None and ahead[0] == (input_var.data_ptr(), input_var._version, tuple(input_var.shape)) and side:
+            leaf = ahead[1]                 # prepare_teacher_forced() made it beside the latent stack
+        elif (side and ops.LEAF_DECODER_INPUT and self.rnn.cell == "gru" and self.rnn.num_layers == 1
                 and not self.rnn.bidirectional):
             # with a gradient sink on the table: no autograd nodes for the input at all, its gradient is taken to the table
             # inside the recurrence's postponed side-stream work
@@ -255,6 +258,22 @@ class DecoderRNN(BaseRNN):
             hseq = None
         output = self.output_dropout(output)
         return output, hidden, attn, hseq
+
+    def prepare_teacher_forced(self, input_var):
+        """Ahead of forward(), on whatever stream the caller is on (DLSVAE._prepare_on_side: the side stream, beside the
+        latent stack): the teacher-forced input dropout(embedding(ids)) as a leaf value and the recurrence's input projection
+        of it -- neither depends on the latent.  _hidden_states() / GRULayer.forward pick them up once; nothing happens when
+        the leaf path does not apply (no gradient sink on the table, LSTM, stacked or attention-fed inputs)."""
+        self.__dict__.pop("_input_ahead", None)
+        if not (ops.LEAF_DECODER_INPUT and ops.HOIST_DECODER_INPUT and self.rnn.cell == "gru" and self.rnn.num_layers == 1
+                and not self.rnn.bidirectional and input_var.is_cuda and input_var.size(1) > 1 and torch.is_grad_enabled()):
+            return
+        leaf = ops.embed_dropout_leaf(self.embedding.weight, input_var, self.embedding.padding_idx, self.input_dropout)
+        if leaf is None:
+            return
+        w_ih, _w_hh, b_ih, _b_hh = self.rnn.layer_weights(0, 0)
+        ops.preproject_gru_input(leaf[0], w_ih, b_ih, self.rnn.hidden_size)
+        self.__dict__["_input_ahead"] = ((input_var.data_ptr(), input_var._version, tuple(input_var.shape)), leaf)
 
     def forward_step(self, input_var, hidden, encoder_outputs, latent_variable=None):
         """Dense variant with the reference's return value (log-probs [B,Lout,V], hidden, attn)."""

@@ -145,7 +145,10 @@ class GraphedStep(object):
         return (mode, bool(getattr(model, "restarted", False)), sig)
 
     def _eager(self, optimizer, batch, mode, batch_cnt, with_step=False):
-        optimizer.zero_grad()
+        if hasattr(optimizer, "flat_g"):
+            optimizer.zero_grad(beside_forward=True)       # FlatAdam: the fill runs beside the head of the forward pass
+        else:
+            optimizer.zero_grad()
         loss = self.model(batch, mode=mode)
         self.model.backward(batch_cnt, loss, step=batch_cnt)
         if with_step:

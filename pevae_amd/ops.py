@@ -154,6 +154,8 @@ class on_side(object):
 
 SIDE_DX = os.environ.get("PEVAE_SIDE_DX", "1") == "1"
 LEAF_DECODER_INPUT = os.environ.get("PEVAE_LEAF_DECODER_INPUT", "1") == "1"
+# the decoder's teacher-forced input (embedding, dropout, input projection) made beside the latent stack (A/B switch)
+HOIST_DECODER_INPUT = os.environ.get("PEVAE_HOIST_DECODER_INPUT", "1") == "1"
 SIDE_BLOCK_WGRAD = os.environ.get("PEVAE_SIDE_BLOCK_WGRAD", "1") == "1"
 # > 0: the vocabulary dW runs on that many workgroups on a second stream beside the latent stack's backward.  Measured at
 # the Yelp shape: 128 / 160 / 192 workgroups -> 3.94 / 3.83 / 3.77 ms per step against 3.68 with the kernel left in front of
@@ -416,9 +418,53 @@ _PREPACK = {}           # (data_ptr, shape, ld) -> bf16 operand made ahead of it
 _PRECOMPACT = {}        # see precompact_targets()
 
 
+_PREPROJ = {}           # see preproject_gru_input()
+
+
+_PRESORTED = {}         # see presort_lookup()
+PRESORT_SIDE = os.environ.get("PEVAE_PRESORT_SIDE", "1") == "1"     # A/B switch
+
+
 def clear_prepared():
     _PREPACK.clear()
     _PRECOMPACT.clear()
+    _PREPROJ.clear()
+    _PRESORTED.clear()
+
+
+def presort_lookup(ids, weight, tag):
+    """The stable (row id, occurrence) sort of a lookup's table gradient, made NOW -- the ids are inputs of the step, the
+    gradient rows arrive at the tail of the backward pass, where the sort otherwise stands in a serial chain of small
+    kernels in front of the optimizer.  The caller runs this under fork_side() (DLSVAE._prepare_on_side: beside the latent
+    stack, joined in front of the decoder), so the backward pass needs no event of its own: embedding_backward() finds the
+    entry by the ids' storage and is left with the segmented sum.  One persistent workspace per `tag` (a lookup site)."""
+    rows, D = weight.shape
+    if not PRESORT_SIDE or grad_sink(weight, (rows, D)) is None:
+        return
+    ids_c = ids.contiguous()
+    n = ids_c.numel()
+    if not n:
+        return
+    nbytes = _lib.load().pv_embedding_bwd_ws_bytes(n, D)
+    ws = workspace("emb_presort_" + tag, nbytes, torch.uint8, weight.device)
+    _lib.call("pv_embedding_sort", _p(ids_c), n, n, n, 0, 1, rows, D, _p(ws), nbytes, _stream())
+    _PRESORTED[(ids_c.data_ptr(), ids_c._version, n, rows, D)] = (ws, nbytes, ids_c)     # (ids_c held: its storage stays its own)
+
+
+def preproject_gru_input(x, w_ih, b_ih, H):
+    """The part of a GRU layer's forward that does not depend on its initial state -- the bf16 operand copy of x [B,L,E] and
+    the input projection x W_ih^T + b_ih -- made NOW (the caller runs this under fork_side(), beside the latent stack) for
+    GRULayer.forward to pick up ONCE later in the same pass, behind a join_side_work(): the decoder's teacher-forced input
+    is known at the start of the step, and its 40 us of gather / cast / GEMM launches otherwise stand between the latent
+    stack and the decoder recurrence."""
+    B, L, E = x.shape
+    Hk, K3, Bpad, NG = gru_geometry(B, H)
+    Ep = round_up(E, 64)
+    x_bf = cast_pack(x, L, B, Bpad, E, x.stride(1), x.stride(0), x.stride(2), Ep)
+    wih_bf = pack_matrix(w_ih, Ep)
+    xprojT = gemm_nt_ct(x_bf, Ep, wih_bf, Ep, L * Bpad, 3 * H, Ep, b_ih.contiguous(),
+                        workspace("gru_xprojT", 3 * H * L * Bpad, torch.float32, x.device).view(3 * H, L * Bpad))
+    _PREPROJ[(x.data_ptr(), tuple(x.shape), w_ih.data_ptr())] = (x_bf, xprojT)
 
 
 def prepack_weights(pairs):
@@ -1166,12 +1212,16 @@ class GRULayer(torch.autograd.Function):
         ctx.dx_consumer = dx_consumer       # x is a leaf value (embed_dropout_leaf): this closure takes dL/dx
         Hk, K3, Bpad, NG = gru_geometry(B, H)
         Ep = round_up(E, 64)
-        x_bf = cast_pack(x, L, B, Bpad, E, x.stride(1), x.stride(0), x.stride(2), Ep)
-        wih_bf = pack_matrix(w_ih, Ep)
+        pre = _PREPROJ.pop((x.data_ptr(), tuple(x.shape), w_ih.data_ptr()), None) if _PREPROJ else None
         whh_bf = pack_matrix(w_hh, Hk)
-        # xproj^T [3H][L*Bpad]: the weight is the A operand, so a lane of the recurrence finds its 4 batch rows in 16 bytes
-        xprojT = gemm_nt_ct(x_bf, Ep, wih_bf, Ep, L * Bpad, 3 * H, Ep, b_ih.contiguous(),
-                            workspace("gru_xprojT", 3 * H * L * Bpad, torch.float32, dev).view(3 * H, L * Bpad))
+        if pre is not None:                 # made ahead on the side stream (preproject_gru_input): joined below
+            x_bf, xprojT = pre
+        else:
+            x_bf = cast_pack(x, L, B, Bpad, E, x.stride(1), x.stride(0), x.stride(2), Ep)
+            wih_bf = pack_matrix(w_ih, Ep)
+            # xproj^T [3H][L*Bpad]: the weight is the A operand, so a lane of the recurrence finds its 4 batch rows in 16 bytes
+            xprojT = gemm_nt_ct(x_bf, Ep, wih_bf, Ep, L * Bpad, 3 * H, Ep, b_ih.contiguous(),
+                                workspace("gru_xprojT", 3 * H * L * Bpad, torch.float32, dev).view(3 * H, L * Bpad))
         hseq = torch.empty(((L + 1) * Bpad, Hk), dtype=BF16, device=dev)
         hn = torch.empty((B, H), dtype=torch.float32, device=dev)
         gsave = torch.empty((L * 4 * H, Bpad), dtype=torch.float32, device=dev) if save else None
@@ -1425,6 +1475,11 @@ def embedding_backward(dout, ids_c, rows, D, pad, sink, presorted=None):
         g, ldg = dout, dout.stride(0)         # a column slice of a wider gradient (torch.cat backward): no copy
     else:
         g, ldg = dout.contiguous().view(-1, D), D
+    if presorted is None and _PRESORTED and sink is not None:
+        hit = _PRESORTED.pop((ids_c.data_ptr(), ids_c._version, n, rows, D), None)
+        if hit is not None:                # presort_lookup(): ordered by the forward pass's own join, no event
+            _lib.call("pv_embedding_bwd_sorted", _p(g), ldg, n, rows, D, pad, 1, _p(dw), _p(hit[0]), hit[1], _stream())
+            return dw
     if presorted is not None:
         ws, nbytes, ev = presorted
         torch.cuda.current_stream(dev).wait_event(ev)

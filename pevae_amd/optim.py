@@ -1,12 +1,15 @@
 """Optimizer tail of the training step on device: global-norm clip, the reference's skip guards and Adam over
 ONE flat buffer (main_pretrain.py:207-225,268-269; dialog_models.py:122-131), two kernel launches + one small
 guard kernel per step and no host synchronisation."""
+import os
 import struct
 
 import torch
 
 from . import _lib
 from .ops import _p, _stream
+
+ZERO_BESIDE = os.environ.get("PEVAE_ZERO_BESIDE", "1") == "1"      # A/B switch of zero_grad(beside_forward=True)
 
 
 class SkipFlag(object):
@@ -107,8 +110,17 @@ class FlatAdam(object):
                     out.append((o, e))
         return out
 
-    def zero_grad(self):
-        self.flat_g.zero_()
+    def zero_grad(self, beside_forward=False):
+        """beside_forward: the 124 MB fill runs on the ops side stream, forked here and joined by the first join_side_work()
+        of the forward pass that MUST follow (every recurrence launch makes one) -- it then runs beside the launches at the
+        head of the step instead of in front of them.  Only for callers that run a forward pass between this call and the
+        backward pass (bench.py, engine.GraphedStep)."""
+        if beside_forward and self.flat_g.is_cuda and ZERO_BESIDE:
+            from . import ops
+            with ops.fork_side():
+                self.flat_g.zero_()
+        else:
+            self.flat_g.zero_()
         for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-attach the view
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
