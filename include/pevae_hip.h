@@ -56,6 +56,14 @@ size_t pv_gemm_splitk_ws_bytes(int M, int N, int splits);
 int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits,
                            void* workspace, float* C, int ldc, int accumulate, const int* m_live, const int* k_live,
                            void* stream);
+/* C[M][N] (+)= A^T B with BOTH operands K-major: A [K][lda] bf16 (element (m, k) at A[k * lda + m]), B [K][ldb] -- the form
+ * of a weight gradient dy^T x over token-major operands (dW_ih = dgi^T x, dW_hh = dgh^T h_prev of BaseRNN's backward,
+ * base_modules.py:42; autograd's mm(dy.t(), x)).  The kernel reads the MFMA fragments out of the [k][x] LDS images with
+ * transposed reads, so no transposed copy of dy or x is made.  K % 64 == 0; lda >= M and ldb >= N, multiples of 8 (what
+ * lies between M / N and the leading dimension is read and must be finite or zero only where it lies below N / M of a
+ * tile that is stored); splits > 1: split-K through `workspace` (pv_gemm_splitk_ws_bytes) with the fixed-order fold. */
+int pv_gemm_bf16_tn_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits,
+                           void* workspace, float* C, int ldc, int accumulate, void* stream);
 
 /* ---- fused vocabulary projection + log-softmax + NLL -----------------------------------------------------
  * Forward: logits = (h W^T + bias) * inv_temp are produced tile-wise by the MFMA GEMM and reduced on the fly

@@ -42,6 +42,7 @@ SIGNATURES = {
     "pv_gemm_splitk_ws_bytes": (sz, [i32, i32, i32]),
     "pv_gemm_bf16_nt_ct": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp]),
     "pv_gemm_bf16_nt_splitk": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
+    "pv_gemm_bf16_tn_splitk": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
     "pv_vocab_nll_fwd_ws_bytes": (sz, [i32, i32]),
     "pv_vocab_nll_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i64, vp, vp, vp, vp, vp]),
     "pv_vocab_nll_bwd_prob": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, i32, vp, i32, vp, vp, vp, vp]),

@@ -41,6 +41,8 @@ struct GemmArgs {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((address_space(3))) bf16x4* ltr_t;
 
 // Tile walk.  The grid is a multiple of 8 workgroups; workgroups b and b+8 share an XCD (one L2), so XCD x owns the
 // contiguous range [xbeg, xbeg+xcnt) of tile ids and its gridDim.x/8 workgroups stride through it.  Tile ids follow
@@ -64,8 +66,16 @@ __device__ __forceinline__ void tile_of(int id, int nbm, int nbn, int& pm, int& 
 //                                   4 -> a 256x128 tile, 8 waves, 3 LDS stages (144 KiB), 1 workgroup per CU: 85 instead of
 //                                        64 flop per byte staged and two K-tiles in flight, for the K = 512 kernels.
 // Every wave owns a 64x64 sub-tile either way, so the epilogues are the same.
-template <class Epi, int WM>
+// TN (WM = 2 only): both operands are K-MAJOR -- A [K][lda] holds A^T (element (m, k) at A[k * lda + m]), B [K][ldb]
+// likewise: C = A^T B with K the leading (row) index of both, the form of a weight gradient dy^T x whose operands sit in
+// memory token-major.  A stage is then two [64 k][128 x] images of 256-byte rows; the MFMA fragments (8 consecutive k of
+// one row / column) come out of them through ds_read_b64_tr_b16 -- a 16-lane group reads a 4 (k) x 16 (x) block and every
+// lane receives one x's four k -- so no transposed copy of either operand is ever made (round 2 spent 12 launches per
+// step on them).  Swizzle: 16-byte chunk c of row r sits at c ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3)): the 8 rows a
+// half-wave's transposed read touches land in 8 different 32-byte bank groups.
+template <class Epi, int WM, bool TN = false>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_nt_kernel(GemmArgs g, Epi epi) {
+  static_assert(!TN || WM == 2, "the K-major operand form is built for the 128 x 128 tile");
   constexpr int BMT = WM * 64, NW = WM * 2, NST = WM == 2 ? 2 : 3, PB = 16 / NW, STAGE = (BMT + BN) * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -88,6 +98,13 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_nt_kernel(Gemm
     offA[i] = ra * 128;
     offB[i] = BMT * BK * 2 + rb * 128;
     swz[i] = (c16 >> 1) & 7;   // (row>>1)&7 : rows are 16-aligned + c16, so only c16 matters
+    if constexpr (TN) {
+      // transposed read of the 4 x 16 block (k rows 8 q4 + q [+ 4], columns x0 + 16 i ..): lane (q = c16 >> 2, p = c16 & 3)
+      // addresses 4 columns of row q; k-step ks adds 32 rows, the fragment's second half 4 rows
+      const int q = c16 >> 2, pp = c16 & 3, sw = (q << 1) | ((q4 & 1) << 3);
+      offA[i] = (8 * q4 + q) * 256 + (((wm * 8 + i * 2 + (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1);
+      offB[i] = BMT * BK * 2 + (8 * q4 + q) * 256 + (((wn * 8 + i * 2 + (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1);
+    }
   }
   const int nk_all = g.k_live ? min(g.K / BK, (*g.k_live + BK - 1) / BK) : g.K / BK;
   const int per_split = (nk_all + splits - 1) / splits;
@@ -104,26 +121,35 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_nt_kernel(Gemm
   const bf16_t* srcB[PB];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = (w * 4 + i) * 8 + (lane >> 3);          // tile row this lane fills
-    const int c = (lane & 7) ^ ((r >> 1) & 7);            // logical 16-B chunk stored at phys lane&7
-    srcA[i] = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda + c * 8;
+    if constexpr (TN) {
+      const int r = (w * 4 + i) * 4 + (lane >> 4);        // k row of the stage this lane fills (a piece = 4 rows of 256 B)
+      const int c = (lane & 15) ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3));
+      srcA[i] = g.A + (size_t)r * g.lda + min(m0 + c * 8, g.lda - 8);   // (columns past M feed rows past M only)
+      srcB[i] = g.B + (size_t)r * g.ldb + min(n0 + c * 8, g.ldb - 8);
+    } else {
+      const int r = (w * 4 + i) * 8 + (lane >> 3);          // tile row this lane fills
+      const int c = (lane & 7) ^ ((r >> 1) & 7);            // logical 16-B chunk stored at phys lane&7
+      srcA[i] = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda + c * 8;
+    }
   }
+  if constexpr (!TN) {
 #pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    const int r = (w * PB + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    srcB[i] = g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb + c * 8;
+    for (int i = 0; i < PB; ++i) {
+      const int r = (w * PB + i) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      srcB[i] = g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb + c * 8;
+    }
   }
   auto stage = [&](int s, int kt) {
     char* base = smem + s * STAGE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + kt * BK),
+      __builtin_amdgcn_global_load_lds((gptr_t)(TN ? srcA[i] + (size_t)kt * BK * g.lda : srcA[i] + kt * BK),
                                        (lptr_t)(base + (w * 4 + i) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + kt * BK),
+      __builtin_amdgcn_global_load_lds((gptr_t)(TN ? srcB[i] + (size_t)kt * BK * g.ldb : srcB[i] + kt * BK),
                                        (lptr_t)(base + BMT * BK * 2 + (w * PB + i) * 1024), 16, 0, 0);
     }
   };
@@ -158,9 +184,18 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_nt_kernel(Gemm
       bf16x8 af[4], bfr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ch = ((ks * 4 + q4) ^ swz[i]) * 16;
-        af[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + offA[i] + ch));
-        bfr[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + offB[i] + ch));
+        if constexpr (TN) {
+          const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ltr_t)(base + offA[i] + ks * 8192));
+          const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ltr_t)(base + offA[i] + ks * 8192 + 1024));
+          const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ltr_t)(base + offB[i] + ks * 8192));
+          const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ltr_t)(base + offB[i] + ks * 8192 + 1024));
+          af[i] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          bfr[i] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        } else {
+          const int ch = ((ks * 4 + q4) ^ swz[i]) * 16;
+          af[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + offA[i] + ch));
+          bfr[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + offB[i] + ch));
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -979,18 +1014,18 @@ int persistent_grid() {
   return grid;
 }
 
-template <class Epi, int WM = 2>
+template <class Epi, int WM = 2, bool TN = false>
 int launch(const GemmArgs& g, const Epi& epi, hipStream_t st, const char* who) {
   constexpr int BMT = WM * 64, LDS = (WM == 2 ? 2 : 3) * (BMT + BN) * BK * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    PV_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<Epi, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    PV_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<Epi, WM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
   // one work item per workgroup while that fills the chip about once; beyond it the resident workgroups (two per CU
   // for the 128-row tile, one for the 256-row tile) walk the items
   const int gx = std::min((cdiv(g.M, BMT) * cdiv(g.N, BN) * g.splits + 7) & ~7, persistent_grid() * 2 / WM);
-  hipLaunchKernelGGL((gemm_nt_kernel<Epi, WM>), dim3(gx), dim3(WM * 128), LDS, st, g, epi);
+  hipLaunchKernelGGL((gemm_nt_kernel<Epi, WM, TN>), dim3(gx), dim3(WM * 128), LDS, st, g, epi);
   PV_LAUNCH_CHECK(who);
   return PV_OK;
 }
@@ -1104,6 +1139,30 @@ int pv_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, int M
   const long n = (long)M * N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (const float*)workspace,
                      splits, n, M, N, C, ldc, accumulate, m_live, slots);
+  PV_LAUNCH_CHECK("splitk_reduce_kernel");
+  return PV_OK;
+}
+
+int pv_gemm_bf16_tn_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits,
+                           void* workspace, float* C, int ldc, int accumulate, void* stream) {
+  PV_REQUIRE(A && B && C, "pv_gemm_bf16_tn_splitk: null argument");
+  PV_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0, "pv_gemm_bf16_tn_splitk: K=%d must be a positive multiple of %d", K, BK);
+  PV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N && lda >= 8 && ldb >= 8 && ldc >= N,
+             "pv_gemm_bf16_tn_splitk: lda=%d ldb=%d must be multiples of 8 and >= M=%d / N=%d, ldc=%d >= N", lda, ldb, M, N, ldc);
+  PV_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "pv_gemm_bf16_tn_splitk: operands must be 16-byte aligned");
+  PV_REQUIRE(splits >= 1 && splits <= K / BK && (splits == 1 || workspace), "pv_gemm_bf16_tn_splitk: bad split count %d", splits);
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, splits, 0, nullptr, nullptr};
+  if (splits == 1) {
+    EpiStore e{C, nullptr, nullptr, M, N, ldc, 0, accumulate, 0, 0, 0};
+    return launch<EpiStore, 2, true>(g, e, st, "pv_gemm_bf16_tn_splitk");
+  }
+  EpiStore e{(float*)workspace, nullptr, nullptr, M, N, N, 0, 0, 0, (long)M * N, 0};
+  int rc = launch<EpiStore, 2, true>(g, e, st, "pv_gemm_bf16_tn_splitk");
+  if (rc) return rc;
+  const long n = (long)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (const float*)workspace,
+                     splits, n, M, N, C, ldc, accumulate, (const int*)nullptr, 0);
   PV_LAUNCH_CHECK("splitk_reduce_kernel");
   return PV_OK;
 }

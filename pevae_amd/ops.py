@@ -569,6 +569,28 @@ def gemm_nt_wgrad(A, lda, Bm, ldb, M, N, K, sink=None, k_live=None, ws_tag="gemm
     return None if sink is not None else out
 
 
+GEMM_TN = os.environ.get("PEVAE_GEMM_TN", "1") == "1"      # A/B switch: weight gradients without transposed operand copies
+
+
+def gemm_tn_wgrad(A, lda, Bm, ldb, M, N, K, sink=None, ws_tag="gemm_splitk"):
+    """Weight-gradient GEMM C[M,N] = A^T B over K-major operands A [K][lda], B [K][ldb] (bf16; K = the token count, a
+    multiple of 64): what gemm_nt_wgrad computes from transposed copies, without the copies (pv_gemm_bf16_tn_splitk).
+    Accumulates into `sink` when given, else returns C."""
+    _need_cuda(A, Bm)
+    cus = device_info()["cu_count"] if not _DEV_CU else _DEV_CU[0]
+    if not _DEV_CU:
+        _DEV_CU.append(cus)
+    splits = C.c_int(1)
+    _lib.call("pv_gemm_splitk_plan", M, N, K, 2 * cus, C.byref(splits))
+    out = sink if sink is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
+    ws = None
+    if splits.value > 1:
+        ws = workspace(ws_tag, _lib.load().pv_gemm_splitk_ws_bytes(M, N, splits.value), torch.uint8, A.device)
+    _lib.call("pv_gemm_bf16_tn_splitk", _p(A), lda, _p(Bm), ldb, M, N, K, max(1, splits.value), _p(ws), _p(out),
+              out.stride(0), 1 if sink is not None else 0, _stream())
+    return None if sink is not None else out
+
+
 def gemm_nt_live_rows(A, lda, Bm, ldb, M, N, K, m_live, max_splits=4):
     """C[M,N] = A[M,K] B[N,K]^T where only the first *m_live rows (int32 device scalar) are wanted: the kernel walks the
     live tiles only and splits K on the device so that they still fill the chip (pv_gemm_bf16_nt_splitk with m_live).
@@ -1295,6 +1317,11 @@ class GRULayer(torch.autograd.Function):
         # optimizer: with gradient sinks they run beside whatever the backward pass does next (the latent stack's chain of
         # small kernels, the embedding gradients)
         def wgrads():
+            if GEMM_TN and Tt % 64 == 0:
+                # token-major operands as they are: dgi / dgh [Tt][K3], x_bf [Tt][Ep], h_prev = the first Tt rows of hseq
+                r_ih = gemm_tn_wgrad(dgi, K3, x_bf, Ep, 3 * H, E, Tt, s_ih, ws_tag="gemm_splitk_rnn")
+                r_hh = gemm_tn_wgrad(dgh, K3, hseq, Hk, 3 * H, H, Tt, s_hh, ws_tag="gemm_splitk_rnn")
+                return r_ih, r_hh
             dgiT = transpose_to_bf16(dgi, Tt, 3 * H, K3, Tp, out=workspace("gru_dgT", 3 * H * Tp, BF16, dev).view(3 * H, Tp))
             xT = transpose_to_bf16(x_bf, Tt, E, Ep, Tp, out=workspace("gru_xT", E * Tp, BF16, dev).view(E, Tp))
             r_ih = gemm_nt_wgrad(dgiT, Tp, xT, Tp, 3 * H, E, Tp, s_ih, ws_tag="gemm_splitk_rnn")
@@ -1392,12 +1419,16 @@ class LSTMLayer(torch.autograd.Function):
         wihT = transpose_to_bf16(w_ih.contiguous(), 4 * H, E, E, K4)
         dx_tm = gemm_nt(dg, K4, wihT, K4, Tt, E, K4)
         dx = dx_tm.view(L, Bpad, E)[:, :B].transpose(0, 1)
-        dgT = transpose_to_bf16(dg, Tt, 4 * H, K4, Tp, out=workspace("lstm_dgT", 4 * H * Tp, BF16, dev).view(4 * H, Tp))
-        xT = transpose_to_bf16(x_bf, Tt, E, Ep, Tp, out=workspace("gru_xT", E * Tp, BF16, dev).view(E, Tp))
-        hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
         p_ih, p_hh = ctx.params
-        dw_ih = gemm_nt_wgrad(dgT, Tp, xT, Tp, 4 * H, E, Tp, grad_sink(p_ih, (4 * H, E)))
-        dw_hh = gemm_nt_wgrad(dgT, Tp, hpT, Tp, 4 * H, H, Tp, grad_sink(p_hh, (4 * H, H)))
+        if GEMM_TN and Tt % 64 == 0:
+            dw_ih = gemm_tn_wgrad(dg, K4, x_bf, Ep, 4 * H, E, Tt, grad_sink(p_ih, (4 * H, E)))
+            dw_hh = gemm_tn_wgrad(dg, K4, hseq, Hk, 4 * H, H, Tt, grad_sink(p_hh, (4 * H, H)))
+        else:
+            dgT = transpose_to_bf16(dg, Tt, 4 * H, K4, Tp, out=workspace("lstm_dgT", 4 * H * Tp, BF16, dev).view(4 * H, Tp))
+            xT = transpose_to_bf16(x_bf, Tt, E, Ep, Tp, out=workspace("gru_xT", E * Tp, BF16, dev).view(E, Tp))
+            hpT = transpose_to_bf16(hseq, Tt, H, Hk, Tp, out=workspace("gru_hpT", H * Tp, BF16, dev).view(H, Tp))
+            dw_ih = gemm_nt_wgrad(dgT, Tp, xT, Tp, 4 * H, E, Tp, grad_sink(p_ih, (4 * H, E)))
+            dw_hh = gemm_nt_wgrad(dgT, Tp, hpT, Tp, 4 * H, H, Tp, grad_sink(p_hh, (4 * H, H)))
         has_h0, has_c0 = ctx.has_state
         return dx, (dh0 if has_h0 else None), (dc0 if has_c0 else None), dw_ih, dw_hh, db_ih, db_hh, None, None
 

@@ -666,6 +666,38 @@ def test_gemm_splitk_exact_and_colsum(dev):
     np.testing.assert_allclose(out.cpu().numpy(), x.sum(0).numpy(), rtol=1e-5, atol=1e-4)
 
 
+def test_gemm_tn_exact_integers(dev):
+    """C = A^T B over K-major operands (the weight-gradient form without transposed copies): exact on integer data with an
+    asymmetric pattern in both operands (row / column swaps and fragment-map mistakes show), leading dimensions wider than
+    M / N, with and without split-K, returned and accumulated into a gradient sink; equal to the nt form on the copies."""
+    import ctypes as C
+    from pevae_amd import _lib, ops
+    g = torch.Generator().manual_seed(23)
+    for (M, N, K, lda, ldb) in [(128, 128, 64, 128, 128), (96, 40, 1024, 96, 64), (1536, 100, 3200, 1536, 128),
+                                (136, 512, 640, 192, 512), (1536, 512, 12800, 1536, 512), (8, 3, 64, 8, 8)]:
+        A = torch.zeros(K, lda)
+        Bm = torch.zeros(K, ldb)
+        A[:, :M] = torch.randint(-2, 3, (K, M), generator=g).float() + (torch.arange(M) % 3 == 0).float()
+        Bm[:, :N] = torch.randint(-2, 3, (K, N), generator=g).float() + (torch.arange(K).view(-1, 1) % 5 == 0).float()
+        if lda > M:
+            A[:, M:] = 7.0                       # what lies past M / N inside the leading dimension must not leak into C
+        want = A[:, :M].t().double() @ Bm[:, :N].double()
+        Ab, Bb = A.to(dev).to(torch.bfloat16), Bm.to(dev).to(torch.bfloat16)
+        got = ops.gemm_tn_wgrad(Ab, lda, Bb, ldb, M, N, K)
+        assert torch.equal(got.cpu().double(), want), (M, N, K)
+        sink = torch.nn.Parameter(torch.zeros(M, N, device=dev))
+        sink.grad = torch.ones(M, N, device=dev)
+        assert ops.gemm_tn_wgrad(Ab, lda, Bb, ldb, M, N, K, ops.grad_sink(sink, (M, N))) is None
+        assert torch.equal(sink.grad.cpu().double(), want + 1), (M, N, K)
+        # one split, straight into C (no workspace)
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+        _lib.call("pv_gemm_bf16_tn_splitk", Ab.data_ptr(), lda, Bb.data_ptr(), ldb, M, N, K, 1, None, out.data_ptr(), N, 0,
+                  torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(out.cpu().double(), want), (M, N, K)
+    with pytest.raises(_lib.PevaeHipError):
+        ops.gemm_tn_wgrad(Ab, 8, Bb, 8, 8, 3, 96)          # K must be a multiple of 64
+
+
 def test_vocab_nll_skipping_ignored_tokens_matches_dense(dev):
     """Ignored-token compaction (pv_vocab_compact / _gather / live-row bounds / pv_scatter_rows_f32) against the dense
     computation of every row: same per-token NLL, same gradients (ignored rows contribute exactly zero either way)."""
