@@ -1577,6 +1577,12 @@ def _lin(A, sam, sak, Bm, sbk, sbn, bias, Cm, ldc, M, N, K, accumulate=0, alpha=
               accumulate, batch, bsa, bsb, bsc, _stream())
 
 
+# Off: measured 2.670 vs 2.664 ms per step with it (twice each) -- the only generic linear on the step's critical chain is
+# prior_fc, whose backward stands behind the join in front of the encoder recurrence either way, and the two extra
+# cross-queue edges cost what the 30 us of launches saved.
+LINEAR_WGRAD_SIDE = os.environ.get("PEVAE_LINEAR_WGRAD_SIDE", "0") == "1"
+
+
 class LinearF32(torch.autograd.Function):
     """y = x W^T + b in exact fp32 (Hidden2Gaussian nn_lib.py:198-199, LinearConnector nn_lib.py:143,
     Block linears dialog_models.py:258-263)."""
@@ -1609,16 +1615,24 @@ class LinearF32(torch.autograd.Function):
             _lin(dy2, N, 1, w, K, 1, None, dx, K, M, K, N)                 # dx = dy W
             dx = dx.view(ctx.xshape)
         p_w, p_b = ctx.params
+        # With gradient sinks inside DLSVAE.backward() the parameter gradients leave the critical chain (postponed
+        # side-stream launches, as the recurrences' and the Blocks'): nothing downstream reads them before the optimizer
         if ctx.needs_input_grad[1]:
             sink = grad_sink(p_w, (N, K))
-            dw = sink if sink is not None else torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            _lin(dy2, 1, N, x2, K, 1, None, dw, K, N, K, M, accumulate=1 if sink is not None else 0)   # dW = dy^T x
-            dw = None if sink is not None else dw
+            if sink is not None and ASYNC_WGRAD and LINEAR_WGRAD_SIDE:
+                defer_side_work(lambda s=sink: _lin(dy2, 1, N, x2, K, 1, None, s, K, N, K, M, accumulate=1), keep=(dy2, x2))
+            else:
+                dw = sink if sink is not None else torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                _lin(dy2, 1, N, x2, K, 1, None, dw, K, N, K, M, accumulate=1 if sink is not None else 0)   # dW = dy^T x
+                dw = None if sink is not None else dw
         if ctx.has_bias and ctx.needs_input_grad[2]:
             sink = grad_sink(p_b, (N,))
-            db = sink if sink is not None else torch.empty(N, dtype=torch.float32, device=dy.device)
-            _lib.call("pv_colsum_f32", _p(dy2), M, N, N, _p(db), 1 if sink is not None else 0, _stream())
-            db = None if sink is not None else db
+            if sink is not None and ASYNC_WGRAD and LINEAR_WGRAD_SIDE:
+                defer_side_work(lambda s=sink: _lib.call("pv_colsum_f32", _p(dy2), M, N, N, _p(s), 1, _stream()), keep=(dy2,))
+            else:
+                db = sink if sink is not None else torch.empty(N, dtype=torch.float32, device=dy.device)
+                _lib.call("pv_colsum_f32", _p(dy2), M, N, N, _p(db), 1 if sink is not None else 0, _stream())
+                db = None if sink is not None else db
         return dx, dw, db
 
 
