@@ -290,6 +290,16 @@ class DLSVAE(nn.Module):
                 ops.precompact_targets(labels, (Ld, B, Bpad), self.pad_id)
             if not self.use_feature and self.training:
                 dec.prepare_teacher_forced(data_feed["input_ids"])        # input embedding + dropout + input projection
+            if torch.is_grad_enabled() and self.training:
+                # W_hh^T / W_ih^T of both recurrences for the backward pass (GRU, one layer, one direction: as above)
+                enc = self.x_encoder.rnn if hasattr(self.x_encoder, "rnn") else None
+                for r in (rnn, enc):
+                    if r is None or r.cell != "gru" or r.num_layers != 1 or r.bidirectional:
+                        continue
+                    wi, wh, _b1, _b2 = r.layer_weights(0, 0)
+                    Hr = r.hidden_size
+                    _hk, k3, _bp, _ng = ops.gru_geometry(B, Hr)
+                    ops.pretranspose_weights([(wh, 3 * Hr, Hr, Hr, k3), (wi, 3 * Hr, wi.shape[1], wi.shape[1], k3)])
             if torch.is_grad_enabled():
                 # the id sorts of the table gradients (the lookups' backward passes are left with their segmented sums)
                 ops.presort_lookup(data_feed["sentence_embeddings"], self.x_embedding.weight, "words")

@@ -430,6 +430,7 @@ def clear_prepared():
     _PRECOMPACT.clear()
     _PREPROJ.clear()
     _PRESORTED.clear()
+    _PRETRANS.clear()
 
 
 def presort_lookup(ids, weight, tag):
@@ -520,9 +521,29 @@ def pack_matrix(w, ld=None):
     return cast_pack(w.contiguous(), 1, R, R, Cc, 0, Cc, 1, ld)
 
 
-def transpose_to_bf16(src, R, Cc, lds, rpad, out=None):
+_PRETRANS = {}          # (data_ptr, R, Cc, lds, rpad) -> transposed bf16 weight made ahead (pretranspose_weights)
+PRETRANSPOSE = os.environ.get("PEVAE_PRETRANSPOSE", "1") == "1"     # A/B switch
+
+
+def pretranspose_weights(items):
+    """The bf16 transposes of recurrence weights that the BACKWARD pass multiplies by (W_hh^T for the recurrence kernel, W_ih^T
+    for the input gradient), made during the forward pass on the side stream: the weights do not change in between, and
+    two of the four 5 us launches otherwise stand in front of a backward recurrence / the embedding gradient at the tail.
+    items: (w, R, Cc, lds, rpad) as transpose_to_bf16 takes them; consumed once each."""
+    if not PRETRANSPOSE:
+        return
+    for w, R, Cc, lds, rpad in items:
+        wc = w.contiguous()
+        _PRETRANS[(wc.data_ptr(), R, Cc, lds, rpad)] = (transpose_to_bf16(wc, R, Cc, lds, rpad, ahead=True), wc)
+
+
+def transpose_to_bf16(src, R, Cc, lds, rpad, out=None, ahead=False):
     """bf16 [Cc][rpad] = src[R][lds]^T (src fp32 or bf16), columns R..rpad zero."""
     _need_cuda(src)
+    if _PRETRANS and out is None and not ahead:
+        hit = _PRETRANS.pop((src.data_ptr(), R, Cc, lds, rpad), None)
+        if hit is not None:
+            return hit[0]
     if out is None:
         out = torch.empty((Cc, rpad), dtype=BF16, device=src.device)
     _lib.call("pv_transpose_to_bf16", _p(src), 1 if src.dtype == torch.float32 else 0, R, Cc, lds, _p(out), rpad,
