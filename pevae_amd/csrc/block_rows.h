@@ -33,7 +33,7 @@ constexpr int RR = 4;            // batch rows per workgroup
 constexpr int NCW = PV_ROWS_NCW;
 constexpr int NTR = (NCW + 1) * 64, NTCR = NCW * 64;
 constexpr int UR = (128 * RR + NTCR - 1) / NTCR;   // elements (of 4 columns) per compute thread of a 4 x 512 image
-constexpr int RDK = 16;          // weight-row segments (1 KiB per wave each) in flight per wave
+constexpr int RDK = 16;          // weight-row segments (1 KiB per wave each) in flight per wave (24: 256 registers, spills, slower)
 
 // Wave w's share of K: [w kper, w kper + kw), kper = K / NCW rounded up to a multiple of 4 (kw may be short or zero)
 __device__ __forceinline__ int rows_kper(int K) { return ((K + 4 * NCW - 1) / (4 * NCW)) * 4; }
