@@ -6,6 +6,7 @@
 //   * categorical KL / entropy rows                             (criterions.py:157-175, :196-211)
 //   * masked sum (loss assembly), dense log-softmax backward
 #include "common.h"
+#include <atomic>
 #include "../../include/pevae_hip.h"
 
 namespace {
@@ -442,19 +443,13 @@ namespace {
 //   out = lay + ls                                             (:3310)
 //   kl  = (ew + cw) * mean_b sum_d KL(prior || posterior)      (:3305-3306; as a VALUE both detached-direction terms are
 //         this number, their gradients differ: ew scales the prior's, cw the posterior's)
-// Workgroup g handles a contiguous run of elements and leaves its KL partial in part[g]; dls_level_kl_kernel adds
-// the partials in index order (fixed-order reduction, run-to-run identical).  One workgroup alone took 56 us at the
-// widest level (B * n = 131072).
-constexpr int DLS_WG_ELEMS = 2048, DLS_MAX_PART = 256;
-__global__ __launch_bounds__(64) void dls_level_kl_kernel(const float* __restrict__ part, int nparts, float scale,
-                                                          float* __restrict__ kl, const float* __restrict__ add) {
-  float s = 0.f;
-  for (int i0 = 0; i0 < nparts; i0 += 64) {                 // 64 partials per load, added in index order
-    const float v = i0 + (int)threadIdx.x < nparts ? part[i0 + threadIdx.x] : 0.f;
-    for (int k = 0; k < 64 && i0 + k < nparts; ++k) s += __shfl(v, k);
-  }
-  if (threadIdx.x == 0) kl[0] = add ? add[0] + scale * s : scale * s;      // (add: the running loss this term joins)
-}
+// Workgroup g handles a contiguous run of elements and leaves its KL partial in part[g]; the workgroup that arrives LAST
+// at the launch's counter adds the partials in index order (fixed-order reduction: run-to-run identical whichever
+// workgroup that is) and resets the counter for the next launch.  One workgroup alone took 56 us at the widest level
+// (B * n = 131072); the fold used to be a second launch (5 us + a launch gap on the latent stack's chain, three times
+// per step).  Partials and counter travel with agent-scope accesses: the workgroups sit on different XCDs.
+constexpr int DLS_WG_ELEMS = 2048, DLS_MAX_PART = 256, DLS_COUNTERS = 16;
+__device__ unsigned g_dls_counter[DLS_COUNTERS];            // zero when the library is loaded; every launch leaves its own at zero
 
 __global__ __launch_bounds__(256) void dls_level_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Pr,
                                                              const float* __restrict__ a2, const float* __restrict__ eps,
@@ -462,8 +457,11 @@ __global__ __launch_bounds__(256) void dls_level_fwd_kernel(const float* __restr
                                                              float* __restrict__ ls, float* __restrict__ out,
                                                              float* __restrict__ part, int per_wg,
                                                              const float* __restrict__ a1n, const float* __restrict__ a2n, int wn,
-                                                             float* __restrict__ q_in, float* __restrict__ p_in) {
+                                                             float* __restrict__ q_in, float* __restrict__ p_in,
+                                                             unsigned* __restrict__ counter, float scale,
+                                                             float* __restrict__ kl, const float* __restrict__ kl_add) {
   __shared__ float red[256];
+  __shared__ int last;
   float acc = 0.f;
   const int lo = blockIdx.x * per_wg, hi = min(B * n, lo + per_wg);
   const int Wn = wn + n;
@@ -495,7 +493,24 @@ __global__ __launch_bounds__(256) void dls_level_fwd_kernel(const float* __restr
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(part + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = old == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last || threadIdx.x >= 64) return;
+  float s = 0.f;
+  const int nparts = gridDim.x;
+  for (int i0 = 0; i0 < nparts; i0 += 64) {                 // 64 partials per load, added in index order
+    const float v = i0 + (int)threadIdx.x < nparts
+                        ? __hip_atomic_load(part + i0 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    for (int k = 0; k < 64 && i0 + k < nparts; ++k) s += __shfl(v, k);
+  }
+  if (threadIdx.x == 0) {
+    kl[0] = kl_add ? kl_add[0] + scale * s : scale * s;      // (kl_add: the running loss this term joins)
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // d_ls / d_out / g_kl: gradients of the three outputs (d_ls, d_out may be NULL).  dQ, dPr [B][2n]; da2, dlay [B][n].
@@ -593,11 +608,22 @@ int pv_dls_level_next_add_fwd(const float* Q, const float* Pr, const float* a2, 
   int wgs = (int)((total + DLS_WG_ELEMS - 1) / DLS_WG_ELEMS);
   if (wgs > DLS_MAX_PART) wgs = DLS_MAX_PART;
   const int per = (int)((total + wgs - 1) / wgs);
+  // a counter of its own per launch in flight: 16 in rotation (launches that could share one are 16 launches apart on
+  // streams that a step orders anyway)
+  static std::atomic<unsigned> next_counter{0};
+  static std::atomic<unsigned*> counters_of[64];            // per device: each GPU holds its own copy of the array
+  int dev = 0;
+  PV_HIP(hipGetDevice(&dev));
+  PV_REQUIRE(dev >= 0 && dev < 64, "pv_dls_level_fwd: device ordinal %d out of range", dev);
+  unsigned* counters = counters_of[dev].load();
+  if (!counters) {
+    PV_HIP(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_dls_counter)));
+    counters_of[dev].store(counters);
+  }
+  unsigned* counter = counters + next_counter.fetch_add(1) % DLS_COUNTERS;
   hipLaunchKernelGGL(dls_level_fwd_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, Q, Pr, a2, eps, lay, B, n, ew, cw, ls,
-                     out, kl_part, per, a1n, a2n, wn, q_in, p_in);
+                     out, kl_part, per, a1n, a2n, wn, q_in, p_in, counter, (ew + cw) / B, kl, kl_add);
   PV_LAUNCH_CHECK("dls_level_fwd_kernel");
-  hipLaunchKernelGGL(dls_level_kl_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_part, wgs, (ew + cw) / B, kl, kl_add);
-  PV_LAUNCH_CHECK("dls_level_kl_kernel");
   return PV_OK;
 }
 
