@@ -1428,10 +1428,13 @@ int pv_block_fwd(const pv_block_call* calls, int n, void* stream) {
       if (need > smem4) smem4 = need;
       if (cdiv(a.M, RR) > nslab4) nslab4 = cdiv(a.M, RR);
     }
-    static size_t seen4 = 0;
-    int rc = set_lds(block_fwd_rows_kernel, smem4, &seen4);
+    bool wide = false;
+    for (int b = 0; b < n; ++b) wide = wide || max3(calls[b].Din, calls[b].mid, calls[b].Dout) > 256;
+    static size_t seen4 = 0, seen4w = 0;
+    int rc = wide ? set_lds(block_fwd_rows_kernel<true>, smem4, &seen4w) : set_lds(block_fwd_rows_kernel<false>, smem4, &seen4);
     if (rc) return rc;
-    hipLaunchKernelGGL(block_fwd_rows_kernel, dim3(nslab4, n), dim3(NTR), smem4, (hipStream_t)stream, g1);
+    if (wide) hipLaunchKernelGGL(block_fwd_rows_kernel<true>, dim3(nslab4, n), dim3(NTR), smem4, (hipStream_t)stream, g1);
+    else hipLaunchKernelGGL(block_fwd_rows_kernel<false>, dim3(nslab4, n), dim3(NTR), smem4, (hipStream_t)stream, g1);
     PV_LAUNCH_CHECK("block_fwd_rows_kernel");
     return PV_OK;
   }
@@ -1549,8 +1552,10 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
     pr.r[b] = pr.r[0];
   }
   if ((phase & 1) && rows4) {
-    static size_t seen4 = 0;
-    int rc = set_lds(block_bwd_dx_rows_kernel, smem4, &seen4);
+    bool wide = false;
+    for (int b = 0; b < n; ++b) wide = wide || max3(calls[b].Din, calls[b].mid, calls[b].Dout) > 256;
+    static size_t seen4 = 0, seen4w = 0;
+    int rc = wide ? set_lds(block_bwd_dx_rows_kernel<true>, smem4, &seen4w) : set_lds(block_bwd_dx_rows_kernel<false>, smem4, &seen4);
     if (rc) return rc;
     BlockBwdGroup1 g1;
     for (int b = 0; b < PV_BLOCK_GROUP_MAX; ++b) {
@@ -1558,7 +1563,8 @@ int pv_block_bwd_phase(const pv_block_call* calls, int n, int phase, void* strea
       g1.a[b] = BlockBwdArgs1{a.dout, a.lddo, a.x, a.ldx, a.out, a.ldo, a.M, a.d, a.save, a.mean, a.rstd, a.dx, a.lddx, a.dY,
                               a.cpart, a.ppart, a.LD};
     }
-    hipLaunchKernelGGL(block_bwd_dx_rows_kernel, dim3(nwg_max, n), dim3(NTR), smem4, st, g1);
+    if (wide) hipLaunchKernelGGL(block_bwd_dx_rows_kernel<true>, dim3(nwg_max, n), dim3(NTR), smem4, st, g1);
+    else hipLaunchKernelGGL(block_bwd_dx_rows_kernel<false>, dim3(nwg_max, n), dim3(NTR), smem4, st, g1);
     PV_LAUNCH_CHECK("block_bwd_dx_rows_kernel");
   } else if (phase & 1) {
     static size_t seen = 0, seen_c = 0;

@@ -104,6 +104,7 @@ __device__ __forceinline__ void kloop4(const float* __restrict__ in, int LD, con
 
 // One layer's products of the calling compute wave, its partial result parked in red[w][RR][LD], and the next layer's
 // first segments requested (Wn == nullptr: none).
+template <bool WIDE>
 __device__ __forceinline__ void dense4(const float* __restrict__ in, int LD, const float* __restrict__ W, int N, int K,
                                        const float* __restrict__ Wn, int Nn, int Kn, int w, int lane, f32x4 (&ring)[RDK],
                                        float* __restrict__ red) {
@@ -112,7 +113,9 @@ __device__ __forceinline__ void dense4(const float* __restrict__ in, int LD, con
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[s][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (N > 256) kloop4<2>(in, LD, W, N, K, w, lane, ring, acc);
+  // WIDE = false: a launch without a layer wider than 256 columns runs a kernel without the two-super-tile loop (these
+  // kernels run through most of their code once: instruction fetch is part of a launch's fixed cost)
+  if (WIDE && N > 256) kloop4<2>(in, LD, W, N, K, w, lane, ring, acc);
   else kloop4<1>(in, LD, W, N, K, w, lane, ring, acc);
   if (Wn) ring4_fill(Wn, Nn, Kn, w, lane, ring);
 #pragma unroll
@@ -157,6 +160,7 @@ __host__ __device__ inline int rows_bwd_lds_floats(int LD, int part_width) { ret
 // (Tried and dropped: the storer wave touching one dword per 128-byte line of the coming layers' weights, as LDS-DMA into a
 // dummy area, to warm the L2 and the TLBs ahead of the compute waves -- every touch pulls its whole line through the same
 // L1 the weight stream is bound by: Block(256,128,128) forward 20.3 -> 27.6 us.)
+template <bool WIDE>
 __global__ __launch_bounds__(NTR) void block_fwd_rows_kernel(BlockFwdGroup1 grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BlockFwdArgs1& a = grp.a[blockIdx.y];
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(NTR) void block_fwd_rows_kernel(BlockFwdGroup1 grp)
     const float* in = (li & 1) || li == 4 ? buf1 : buf0;
     float* outb = (li & 1) ? buf0 : buf1;
     float* yb = (li & 1) ? yb1 : yb0;
-    dense4(in, LD, a.d.W[li], N, K, li < 4 ? a.d.W[li + 1] : nullptr, li < 4 ? Nof(li + 1) : 0, li < 4 ? Kof(li + 1) : 0, w, lane,
+    dense4<WIDE>(in, LD, a.d.W[li], N, K, li < 4 ? a.d.W[li + 1] : nullptr, li < 4 ? Nof(li + 1) : 0, li < 4 ? Kof(li + 1) : 0, w, lane,
            ring, red);
     BSTAMP(0, 2 + 2 * li);
     lds_barrier();                                 // the four partial results are in LDS
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(NTR) void block_fwd_rows_kernel(BlockFwdGroup1 grp)
   BSTAMP_FLUSH(0);
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(NTR) void block_bwd_dx_rows_kernel(BlockBwdGroup1 grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BlockBwdArgs1& a = grp.a[blockIdx.y];
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(NTR) void block_bwd_dx_rows_kernel(BlockBwdGroup1 g
         ys[u] = *(const f32x4*)(pbase + (size_t)min(r0 + row, M - 1) * pstride + (i - row * per) * 4);
       }
     }
-    dense4(in, LD, a.d.W[li], N, K, st < 4 ? a.d.W[li - 1] : nullptr, st < 4 ? Nof(st + 1) : 0, st < 4 ? Kof(st + 1) : 0, w, lane,
+    dense4<WIDE>(in, LD, a.d.W[li], N, K, st < 4 ? a.d.W[li - 1] : nullptr, st < 4 ? Nof(st + 1) : 0, st < 4 ? Kof(st + 1) : 0, w, lane,
            ring, red);
     lds_barrier();                               // the four partial results are in LDS
     const int off_b = st == 1 ? P.b3 : st == 2 ? P.b2 : st == 3 ? P.b1 : P.b4;

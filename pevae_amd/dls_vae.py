@@ -127,12 +127,21 @@ class DLSVAE(nn.Module):
         if self._cut is not None:
             self.backward_vocab(loss)
             return self.backward_rest(loss)
-        total = self.valid_loss(loss, batch_cnt, step=step)
-        # the backward seed is a cached scalar one: `total.backward()` alone fills a fresh one-element tensor every step
+        # valid_loss() is a plain sum of its terms (:3451-3465): d total / d term = 1 for each, so the backward pass starts
+        # from the terms themselves -- the sum is never formed (an add launch between the forward and the backward pass) --
+        # with a cached scalar one as every seed (`.backward()` alone fills a fresh one-element tensor every step)
+        terms = [loss.vae_nll]
+        if self.training and loss.vae_rkl is not None:
+            terms.append(loss.vae_rkl)
+        if self.config.do_pred and loss.get("rating_mse") is not None:
+            terms.append(loss.rating_mse)
+        terms = [t for t in terms if torch.is_tensor(t) and t.requires_grad]
+        if not terms:
+            return
         seed = self.__dict__.get("_one")
-        if seed is None or seed.device != total.device or seed.dtype != total.dtype:
-            seed = self.__dict__["_one"] = torch.ones((), dtype=total.dtype, device=total.device)
-        self._run_backward(lambda: total.backward(seed))
+        if seed is None or seed.device != terms[0].device or seed.dtype != terms[0].dtype:
+            seed = self.__dict__["_one"] = torch.ones((), dtype=terms[0].dtype, device=terms[0].device)
+        self._run_backward(lambda: torch.autograd.backward(terms, [seed] * len(terms)))
 
     @staticmethod
     def _run_backward(fn):
