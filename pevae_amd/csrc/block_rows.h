@@ -40,8 +40,9 @@ __device__ __forceinline__ int rows_kper(int K) { return ((K + 4 * NCW - 1) / (4
 __device__ __forceinline__ int rows_kw(int K, int w) { return max(0, min(rows_kper(K), K - w * rows_kper(K))); }
 
 // Segment s of wave w's share of Wop [K][N] (N > 256: two 256-column super-tiles per k, interleaved): the first RDK of them
+template <bool WIDE>
 __device__ __forceinline__ void ring4_fill(const float* __restrict__ W, int N, int K, int w, int lane, f32x4 (&ring)[RDK]) {
-  const int kw = rows_kw(K, w), nst = N > 256 ? 2 : 1, nseq = kw * nst;
+  const int kw = rows_kw(K, w), sh = WIDE && N > 256 ? 1 : 0, nseq = kw << sh;     // (sh: log2 of the super-tile count)
   if (nseq == 0) return;
   const float* base = W + (size_t)(w * rows_kper(K)) * N;
   const int c0 = min(4 * lane, N - 4), c1 = min(256 + 4 * lane, N - 4);
@@ -51,7 +52,7 @@ __device__ __forceinline__ void ring4_fill(const float* __restrict__ W, int N, i
 #if PV_ROWS_ABL & 1
     ring[t] = f32x4{(float)s, 1.f, 2.f, 3.f};
 #else
-    ring[t] = *(const f32x4*)(base + (size_t)(s / nst) * N + ((s % nst) ? c1 : c0));
+    ring[t] = *(const f32x4*)(base + (size_t)(s >> sh) * N + ((s & sh) ? c1 : c0));
 #endif
   }
 }
@@ -117,7 +118,7 @@ __device__ __forceinline__ void dense4(const float* __restrict__ in, int LD, con
   // kernels run through most of their code once: instruction fetch is part of a launch's fixed cost)
   if (WIDE && N > 256) kloop4<2>(in, LD, W, N, K, w, lane, ring, acc);
   else kloop4<1>(in, LD, W, N, K, w, lane, ring, acc);
-  if (Wn) ring4_fill(Wn, Nn, Kn, w, lane, ring);
+  if (Wn) ring4_fill<WIDE>(Wn, Nn, Kn, w, lane, ring);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int col = 256 * s + 4 * lane;
@@ -136,11 +137,42 @@ __device__ __forceinline__ f32x4 red4(const float* __restrict__ red, int LD, int
   return v;
 }
 
+// row of element i of a [RR][per] image (i < RR * per): three compares instead of an integer division (a division by a
+// run-time value is ~40 instructions, and these kernels run through their code once)
+__device__ __forceinline__ int row_of(int i, int per) { return (i >= per) + (i >= 2 * per) + (i >= 3 * per); }
+static_assert(RR == 4, "row_of() is written for four rows");
+
+// biases / gamma / beta -> LDS (PartLayout offsets) + the five 1/sigma: every load of the wave issued before the first LDS
+// write (one memory round trip), segment by segment -- a segment is at most 512 floats = two 16-byte pieces per lane --
+// instead of block_fused.hip's chunk-major walk with a seven-way source select per piece (530 instructions there, 18 % of
+// this kernel's code, which a workgroup runs through once: instruction fetch is part of the launch's fixed cost)
+__device__ __forceinline__ void wave_stage_params_rows(const BlockDesc& d, const PartLayout& P, float* par, int lane) {
+  const float* src[7] = {d.bias[0], d.bias[1], d.bias[2], d.bias[3], d.bias[4], d.gamma, d.beta};
+  const int beg[8] = {P.b1, P.b2, P.b3, P.b4, P.bt, P.dg, P.dbe, P.width};
+  f32x4 v[7][2];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int n4 = (beg[k + 1] - beg[k]) >> 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) v[k][j] = *(const f32x4*)(src[k] + 4 * min(lane + 64 * j, n4 - 1));
+  }
+  float isv = 0.f;
+  if (lane < 5) isv = d.inv_sigma[lane][0];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int n4 = (beg[k + 1] - beg[k]) >> 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (lane + 64 * j < n4) *(f32x4*)(par + beg[k] + 4 * (lane + 64 * j)) = v[k][j];
+  }
+  if (lane < 5) par[P.width + lane] = isv;
+}
+
 __device__ __forceinline__ void wave_copy_rows(const float* __restrict__ buf, int LD, float* __restrict__ g, size_t gs,
                                                int ncols, int r0, int M, int lane) {
   const int per = ncols / 4, nq = RR * per;
   for (int i = lane; i < nq; i += 64) {
-    const int row = i / per, c4 = (i - row * per) * 4;
+    const int row = row_of(i, per), c4 = (i - row * per) * 4;
     if (r0 + row < M) *(f32x4*)(g + (size_t)(r0 + row) * gs + c4) = *(const f32x4*)(buf + row * LD + c4);
   }
 }
@@ -191,7 +223,7 @@ __global__ __launch_bounds__(NTR) void block_fwd_rows_kernel(BlockFwdGroup1 grp)
 
   if (w == NCW) {
     // ---- the storer wave: parameters -> LDS, L2 warming, and every global store of saved state, one layer behind ----
-    wave_stage_params(a.d, P, par, lane);
+    wave_stage_params_rows(a.d, P, par, lane);
     lds_barrier();
     for (int li = 0; li < 5; ++li) {
       const float* in = (li & 1) || li == 4 ? buf1 : buf0;
@@ -222,20 +254,20 @@ __global__ __launch_bounds__(NTR) void block_fwd_rows_kernel(BlockFwdGroup1 grp)
 
   // ---- the four compute waves ----
   f32x4 ring[RDK];
-  ring4_fill(a.d.W[0], Din, Din, w, lane, ring);
+  ring4_fill<WIDE>(a.d.W[0], Din, Din, w, lane, ring);
   {
     const int per = Din / 4, nq = RR * per;       // <= 512: UR per thread
     f32x4 xv[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      const int i = min(tid + u * NTCR, nq - 1), row = i / per;
+      const int i = min(tid + u * NTCR, nq - 1), row = row_of(i, per);
       xv[u] = *(const f32x4*)(a.x + (size_t)min(r0 + row, M - 1) * a.ldx + (i - row * per) * 4);
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       const int i = tid + u * NTCR;
       if (i < nq) {
-        const int row = i / per, c4 = (i - row * per) * 4;
+        const int row = row_of(i, per), c4 = (i - row * per) * 4;
         const f32x4 v = xv[u];
         *(f32x4*)(xb + row * LD + c4) = v;
         *(f32x4*)(buf0 + row * LD + c4) = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
@@ -259,7 +291,7 @@ __global__ __launch_bounds__(NTR) void block_fwd_rows_kernel(BlockFwdGroup1 grp)
       const float is = isg[li];
       const int per = N >> 2, nit = RR * per;
       for (int i = tid; i < nit; i += NTCR) {
-        const int row = i / per, col = (i - row * per) * 4, gr = r0 + row;
+        const int row = row_of(i, per), col = (i - row * per) * 4, gr = r0 + row;
         const f32x4 y = red4(red, LD, row, col) * is + *(const f32x4*)(par + off_b + col);
         if (li < 3) {
           *(f32x4*)(yb + row * LD + col) = y;
@@ -347,7 +379,7 @@ __global__ __launch_bounds__(NTR) void block_bwd_dx_rows_kernel(BlockBwdGroup1 g
 
   if (w == NCW) {
     // ---- the storer wave: one step behind, gradients of the inner linears -> dY, column sums -> this workgroup's partial row
-    wave_stage_params(a.d, P, par, lane);
+    wave_stage_params_rows(a.d, P, par, lane);
     if (lane < RR) {
       const int grc = min(r0 + lane, M - 1);
       rowstat[lane] = a.mean[grc];
@@ -379,17 +411,17 @@ __global__ __launch_bounds__(NTR) void block_bwd_dx_rows_kernel(BlockBwdGroup1 g
 
   // ---- the four compute waves ----
   f32x4 ring[RDK];
-  ring4_fill(a.d.W[4], Din, Dout, w, lane, ring);
+  ring4_fill<WIDE>(a.d.W[4], Din, Dout, w, lane, ring);
   {
     const int pero = Dout / 4, nqo = RR * pero, peri = Din / 4, nqi = RR * peri;
     f32x4 dv[UR], ov[UR], bv[UR], xv[UR], yv[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      const int i = min(tid + u * NTCR, nqo - 1), ro = i / pero, gr = min(r0 + ro, M - 1), c4 = (i - ro * pero) * 4;
+      const int i = min(tid + u * NTCR, nqo - 1), ro = row_of(i, pero), gr = min(r0 + ro, M - 1), c4 = (i - ro * pero) * 4;
       dv[u] = *(const f32x4*)(a.dout + (size_t)gr * a.lddo + c4);
       ov[u] = *(const f32x4*)(a.out + (size_t)gr * a.ldo + c4);
       bv[u] = *(const f32x4*)(a.d.bias[4] + c4);
-      const int k = min(tid + u * NTCR, nqi - 1), rk = k / peri, gk = min(r0 + rk, M - 1), k4 = (k - rk * peri) * 4;
+      const int k = min(tid + u * NTCR, nqi - 1), rk = row_of(k, peri), gk = min(r0 + rk, M - 1), k4 = (k - rk * peri) * 4;
       xv[u] = *(const f32x4*)(a.x + (size_t)gk * a.ldx + k4);
       yv[u] = *(const f32x4*)(a.save + (size_t)gk * SW + L.y4 + k4);
     }
@@ -398,7 +430,7 @@ __global__ __launch_bounds__(NTR) void block_bwd_dx_rows_kernel(BlockBwdGroup1 g
     for (int u = 0; u < UR; ++u) {
       const int i = tid + u * NTCR;
       if (i < nqo) {
-        const int row = i / pero;
+        const int row = row_of(i, pero);
         f32x4 v = dv[u];
         if (r0 + row >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -406,7 +438,7 @@ __global__ __launch_bounds__(NTR) void block_bwd_dx_rows_kernel(BlockBwdGroup1 g
         *(f32x4*)(g0 + row * LD + (i - row * pero) * 4) = v;
       }
       if (i < nqi) {
-        const int row = i / peri;
+        const int row = row_of(i, peri);
         *(f32x4*)(sbuf + row * LD + (i - row * peri) * 4) = xv[u] + yv[u];
       }
     }
@@ -432,7 +464,7 @@ __global__ __launch_bounds__(NTR) void block_bwd_dx_rows_kernel(BlockBwdGroup1 g
     if (st > 0) {
 #pragma unroll
       for (int u = 0; u < UR; ++u) {
-        const int i = min(tid + u * NTCR, nit - 1), row = i / per;
+        const int i = min(tid + u * NTCR, nit - 1), row = row_of(i, per);
         ys[u] = *(const f32x4*)(pbase + (size_t)min(r0 + row, M - 1) * pstride + (i - row * per) * 4);
       }
     }
@@ -446,7 +478,7 @@ __global__ __launch_bounds__(NTR) void block_bwd_dx_rows_kernel(BlockBwdGroup1 g
     for (int u = 0; u < UR; ++u) {
       const int i = tid + u * NTCR;
       if (i >= nit) continue;
-      const int row = i / per, col = (i - row * per) * 4, gr = r0 + row;
+      const int row = row_of(i, per), col = (i - row * per) * 4, gr = r0 + row;
       const f32x4 acc = red4(red, LD, row, col) * is;
       if (st == 0) {
         *(f32x4*)(outb + row * LD + col) = acc;
