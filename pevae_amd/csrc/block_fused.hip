@@ -19,6 +19,7 @@
 // Arithmetic: exact fp32 (v_mfma_f32_16x16x4_f32), like the unfused path; sums run in a different order.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "linear_group.h"
 #include "../../include/pevae_hip.h"
 

@@ -19,7 +19,7 @@
 // lane l of a 4x4x1 MFMA: A = value for (block l / 4, row l % 4), B = value for (block l / 4, column l % 4),
 // D[vgpr r][lane l] = A[lane 4 (l / 4) + r] * B[lane l]   (tools/probe_mfma_4x4x1.hip, run on the MI355X).
 #pragma once
-#include <type_traits>
+// (included by block_fused.hip INSIDE its anonymous namespace: no #include here -- <type_traits> comes from there)
 
 #ifndef PV_ROWS_ABL
 #define PV_ROWS_ABL 0            // timing ablations (diagnostic builds only): 1 = no weight loads, 2 = no MFMAs, 3 = neither
