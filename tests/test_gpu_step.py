@@ -262,6 +262,62 @@ def test_split_backward_schedules_give_the_unsplit_gradients(dev, kw):
     gpu.split_backward = False
 
 
+def test_schedule_switches_leave_the_gradients_bitwise_alone(dev):
+    """Round-3 schedule changes move work, they do not change it: the decoder's teacher-forced input (embedding, dropout,
+    input projection) and the lookups' id sorts made beside the latent stack, the backward pass's weight transposes made
+    during the forward pass, the zero-grad fill beside the head of the forward pass -- each alone and all together leave
+    every gradient bit-identical to the step with all of them off; the weight-gradient GEMMs over K-major operands
+    (no transposed copies) agree with the copies' path to fp32 accumulation order."""
+    from pevae_amd import ops, optim
+    from pevae_amd.dls_vae import DLSVAE, default_config, synthetic_batch
+    from pevae_amd.optim import FlatAdam
+    B, Lq = 32, 10                                          # 10 x 32 time-major rows: a multiple of 64 (the tn GEMM's K)
+    cfg = default_config(vocab_size=517, embed_size=24, dec_cell_size=64, max_seq_len=Lq, n_user=40, n_item=30,
+                         latent_size=16, batch_size=B, latent_stack="dls", dropout=0.3)
+    torch.manual_seed(0)
+    gpu = DLSVAE(cfg).to(dev)
+    gpu.train()
+    opt = FlatAdam(gpu.parameters(), lr=1e-3, max_norm=5.0, guards=False)
+    feed = {k: v.to(dev) for k, v in synthetic_batch(cfg, B, 99).items()}
+    gen = torch.Generator().manual_seed(3)
+    eps = [torch.rand(B, d, generator=gen).to(dev) for d in (4, 8, 16)]
+    for name, shape in (("input_dropout", (B, Lq, 24)), ("output_dropout", (B, Lq, 64))):
+        getattr(gpu.x_decoder, name).mask = (torch.rand(shape, generator=gen) >= cfg.dropout).to(dev)
+    state = {n: b.clone() for n, b in gpu.named_buffers()}
+    names = ("HOIST_DECODER_INPUT", "PRESORT_SIDE", "PRETRANSPOSE", "GEMM_TN")
+    saved = {n: getattr(ops, n) for n in names}
+    saved_zero = optim.ZERO_BESIDE
+
+    def run(**on):
+        for n, b in gpu.named_buffers():
+            b.copy_(state[n])
+        for n in names:
+            setattr(ops, n, bool(on.get(n, False)))
+        optim.ZERO_BESIDE = bool(on.get("ZERO_BESIDE", False))
+        opt.zero_grad(beside_forward=True)
+        loss = gpu(feed, eps=eps)
+        gpu.backward(0, loss)
+        torch.cuda.synchronize()
+        ops.gru_check_all()
+        return opt.flat_g.clone(), float(loss.vae_nll.detach())
+
+    try:
+        want, nll = run()
+        assert float(want.abs().sum()) > 0
+        for sw in ("HOIST_DECODER_INPUT", "PRESORT_SIDE", "PRETRANSPOSE", "ZERO_BESIDE"):
+            got, nll2 = run(**{sw: True})
+            assert nll2 == nll and torch.equal(got, want), sw
+        got, nll2 = run(HOIST_DECODER_INPUT=True, PRESORT_SIDE=True, PRETRANSPOSE=True, ZERO_BESIDE=True)
+        assert nll2 == nll and torch.equal(got, want)
+        got, nll2 = run(GEMM_TN=True)
+        assert nll2 == nll
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(want.abs().max()))
+    finally:
+        for n in names:
+            setattr(ops, n, saved[n])
+        optim.ZERO_BESIDE = saved_zero
+
+
 def test_step_full_size_oracle_and_properties(dev):
     """BASELINE.json configs[1] at full size (bs=256, L=50, V=20004, H=512, DLS pyramid): the composed step against the
     CPU oracle (a few seconds on the host cores), plus properties that hold at any size."""
