@@ -27,6 +27,8 @@ from .enc2dec.encoders import EncoderRNN
 from .utils import Pack
 
 PREPARE_LATE = os.environ.get("PEVAE_PREPARE_LATE", "1") == "1"
+# the user / item / rating lookups (and the spectral pre-pass) beside the encoder's forward recurrence instead of in front of it
+HEAD_SIDE = os.environ.get("PEVAE_HEAD_SIDE", "1") == "1"
 PREPARE_ON_SIDE = os.environ.get("PEVAE_PREPARE_ON_SIDE", "1") == "1"      # DLSVAE._prepare_on_side
 
 # vocab = [<pad>, <unk>, <sys>, <usr>] + words by frequency (corpora.py:649).  <s> and </s> open and close every
@@ -193,11 +195,14 @@ class DLSVAE(nn.Module):
         if self.training and self.config.dropout > 0:
             ops.rng_advance(self.x_embedding.weight.device)      # new dropout masks every step, also under graph replay
         prep_late = PREPARE_LATE and self.latent_stack == "dls"
-        rating_ids = data_feed["ratings"].ge(3).long()                                    # :760
-        self.__dict__["_rating_ids"] = rating_ids
+        early_sn = self.latent_stack == "dls" and data_feed["user_ids"].is_cuda
+        head_side = (HEAD_SIDE and early_sn and prep_late and self.x_encoder.rnn.cell == "gru" and not self.split_backward
+                     and mode == TEACH_FORCE)
+        if not head_side:
+            rating_ids = data_feed["ratings"].ge(3).long()                                # :760
+            self.__dict__["_rating_ids"] = rating_ids
         if data_feed["user_ids"].is_cuda and mode == TEACH_FORCE and PREPARE_ON_SIDE and not prep_late:
             self._prepare_on_side(data_feed)
-        early_sn = self.latent_stack == "dls" and data_feed["user_ids"].is_cuda
         if early_sn:
             # all 105 power iterations (one launch group) beside the launches in front of the encoder recurrence, whose
             # launch joins the side stream; first read by the pyramids behind it
@@ -205,11 +210,29 @@ class DLSVAE(nn.Module):
                 self._sn_modules, self._sn_cache = L.spectral_modules(self), {}
             with ops.fork_side():
                 ops.spectral_prepass(self._sn_modules, self.training, cache=self._sn_cache)
-        user = ops.embedding(self.user_embedding.weight, data_feed["user_ids"])          # :758
-        item = ops.embedding(self.item_embedding.weight, data_feed["item_ids"])          # :759
-        rating = ops.embedding(self.rating_embedding.weight, rating_ids)                  # :760
-        words = ops.embedding(self.x_embedding.weight, data_feed["sentence_embeddings"], self.pad_id)
-        enc_outs, enc_last = self.x_encoder(words)                                        # :765
+        if head_side:
+            # only the word lookup stands in front of the encoder recurrence: the user / item / rating lookups feed the
+            # prior path behind it, so they run on the side stream beside the recurrence (128 of the 256 CUs), and so does
+            # the spectral pre-pass; joined in front of prior_fc
+            words = ops.embedding(self.x_embedding.weight, data_feed["sentence_embeddings"], self.pad_id)
+            with ops.fork_side():
+                rating_ids = data_feed["ratings"].ge(3).long()                            # :760
+                self.__dict__["_rating_ids"] = rating_ids
+                user = ops.embedding(self.user_embedding.weight, data_feed["user_ids"])          # :758
+                item = ops.embedding(self.item_embedding.weight, data_feed["item_ids"])          # :759
+                rating = ops.embedding(self.rating_embedding.weight, rating_ids)                  # :760
+            ops.FWD_RNN_BESIDE_SIDE = True
+            try:
+                enc_outs, enc_last = self.x_encoder(words)                                    # :765
+            finally:
+                ops.FWD_RNN_BESIDE_SIDE = False
+            ops.join_side_work()
+        else:
+            user = ops.embedding(self.user_embedding.weight, data_feed["user_ids"])          # :758
+            item = ops.embedding(self.item_embedding.weight, data_feed["item_ids"])          # :759
+            rating = ops.embedding(self.rating_embedding.weight, rating_ids)                  # :760
+            words = ops.embedding(self.x_embedding.weight, data_feed["sentence_embeddings"], self.pad_id)
+            enc_outs, enc_last = self.x_encoder(words)                                        # :765
         h = enc_last.transpose(0, 1).contiguous().squeeze(1)                              # :766
         if (self.split_backward == 2 and torch.is_grad_enabled() and h.requires_grad
                 and mode == TEACH_FORCE and not self.config.use_attention):

@@ -154,6 +154,8 @@ class on_side(object):
 
 SIDE_DX = os.environ.get("PEVAE_SIDE_DX", "1") == "1"
 LEAF_DECODER_INPUT = os.environ.get("PEVAE_LEAF_DECODER_INPUT", "1") == "1"
+# set by DLSVAE.forward around the encoder's launch (A/B: PEVAE_HEAD_SIDE): side work of the step's head beside the recurrence
+FWD_RNN_BESIDE_SIDE = False
 # the decoder's teacher-forced input (embedding, dropout, input projection) made beside the latent stack (A/B switch)
 HOIST_DECODER_INPUT = os.environ.get("PEVAE_HOIST_DECODER_INPUT", "1") == "1"
 SIDE_BLOCK_WGRAD = os.environ.get("PEVAE_SIDE_BLOCK_WGRAD", "1") == "1"
@@ -1271,7 +1273,10 @@ class GRULayer(torch.autograd.Function):
         hall = torch.empty(((L + 1), Bpad, H), dtype=torch.float32, device=dev)
         sync = torch.empty(_lib.load().pv_gru_sync_bytes(B), dtype=torch.uint8, device=dev)
         h0c = None if h0 is None else h0.contiguous()
-        join_side_work()
+        if not (FWD_RNN_BESIDE_SIDE and pre is None and h0 is None):
+            join_side_work()
+        # (else: the encoder's launch -- no initial state, nothing prepared ahead -- does not wait for the side stream: the
+        # forward recurrence holds 128 of the 256 CUs, so the head's side work runs beside it; its consumers join later)
         with timed("gru_fwd"):
             _lib.call("pv_gru_fwd", _p(xprojT), L * Bpad, _p(whh_bf), _p(b_hh.contiguous()), _p(h0c), _p(lengths), L, B, H, 0,
                       _p(hseq), _p(gsave), _p(hall), _p(hn), _p(sync), GRU_MAX_WGS, _stream())
