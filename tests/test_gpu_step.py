@@ -265,10 +265,11 @@ def test_split_backward_schedules_give_the_unsplit_gradients(dev, kw):
 def test_schedule_switches_leave_the_gradients_bitwise_alone(dev):
     """Round-3 schedule changes move work, they do not change it: the decoder's teacher-forced input (embedding, dropout,
     input projection) and the lookups' id sorts made beside the latent stack, the backward pass's weight transposes made
-    during the forward pass, the zero-grad fill beside the head of the forward pass -- each alone and all together leave
+    during the forward pass, the zero-grad fill beside the head of the forward pass, the user / item / rating
+    lookups beside the encoder's forward recurrence -- each alone and all together leave
     every gradient bit-identical to the step with all of them off; the weight-gradient GEMMs over K-major operands
     (no transposed copies) agree with the copies' path to fp32 accumulation order."""
-    from pevae_amd import ops, optim
+    from pevae_amd import dls_vae as dv, ops, optim
     from pevae_amd.dls_vae import DLSVAE, default_config, synthetic_batch
     from pevae_amd.optim import FlatAdam
     B, Lq = 32, 10                                          # 10 x 32 time-major rows: a multiple of 64 (the tn GEMM's K)
@@ -286,9 +287,10 @@ def test_schedule_switches_leave_the_gradients_bitwise_alone(dev):
     state = {n: b.clone() for n, b in gpu.named_buffers()}
     names = ("HOIST_DECODER_INPUT", "PRESORT_SIDE", "PRETRANSPOSE", "GEMM_TN")
     saved = {n: getattr(ops, n) for n in names}
-    saved_zero = optim.ZERO_BESIDE
+    saved_zero, saved_head = optim.ZERO_BESIDE, dv.HEAD_SIDE
 
     def run(**on):
+        dv.HEAD_SIDE = bool(on.get("HEAD_SIDE", False))
         for n, b in gpu.named_buffers():
             b.copy_(state[n])
         for n in names:
@@ -309,6 +311,11 @@ def test_schedule_switches_leave_the_gradients_bitwise_alone(dev):
             assert nll2 == nll and torch.equal(got, want), sw
         got, nll2 = run(HOIST_DECODER_INPUT=True, PRESORT_SIDE=True, PRETRANSPOSE=True, ZERO_BESIDE=True)
         assert nll2 == nll and torch.equal(got, want)
+        # the user / item / rating lookups beside the encoder's recurrence
+        got, nll2 = run(HEAD_SIDE=True)
+        assert nll2 == nll and torch.equal(got, want), "HEAD_SIDE"
+        got, nll2 = run(HOIST_DECODER_INPUT=True, PRESORT_SIDE=True, PRETRANSPOSE=True, ZERO_BESIDE=True, HEAD_SIDE=True)
+        assert nll2 == nll and torch.equal(got, want), "all"
         got, nll2 = run(GEMM_TN=True)
         assert nll2 == nll
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(want.abs().max()))
@@ -316,6 +323,7 @@ def test_schedule_switches_leave_the_gradients_bitwise_alone(dev):
         for n in names:
             setattr(ops, n, saved[n])
         optim.ZERO_BESIDE = saved_zero
+        dv.HEAD_SIDE = saved_head
 
 
 def test_step_full_size_oracle_and_properties(dev):
