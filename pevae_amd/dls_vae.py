@@ -196,8 +196,10 @@ class DLSVAE(nn.Module):
             ops.rng_advance(self.x_embedding.weight.device)      # new dropout masks every step, also under graph replay
         prep_late = PREPARE_LATE and self.latent_stack == "dls"
         early_sn = self.latent_stack == "dls" and data_feed["user_ids"].is_cuda
+        # (not with use_mutual: DeN_Auto's spectral pre-pass is several times the pyramid stack's, and beside the
+        # recurrence it costs that configuration 5.00 -> 5.19 ms per step)
         head_side = (HEAD_SIDE and early_sn and prep_late and self.x_encoder.rnn.cell == "gru" and not self.split_backward
-                     and mode == TEACH_FORCE)
+                     and mode == TEACH_FORCE and not self.use_mutual)
         if not head_side:
             rating_ids = data_feed["ratings"].ge(3).long()                                # :760
             self.__dict__["_rating_ids"] = rating_ids
