@@ -11,10 +11,15 @@ Deviations, all forced by the reference being un-runnable as written (SURVEY sec
   * uniform noise for `dis_reparameterization` (:3206-3207) can be passed in (`noise=[...]`) so that parity tests are
     deterministic; by default it is drawn on the device.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import dp, ops
+
+# DLS_Auto's batched consistency losses on a third stream beside the first level (forward) and at the head of the backward
+CONS_BESIDE = os.environ.get("PEVAE_CONS_BESIDE", "1") == "1"
 
 
 class SNLinear(nn.Module):
@@ -178,7 +183,7 @@ class DLSAuto(nn.Module):
         scaled = (lambda v: v) if cip == 1.0 else (lambda v: v * cip)     # cip_weight = 1 (the default): no launch
         batched = not restarted and not getattr(cfg, "ost", False) and all(
             a.shape[1] % 4 == 0 for a in list(act1) + [output]) and len(self.layers) < 7
-        use = lambda t: t
+        use, cons_beside = (lambda t: t), None
         # config.global_negatives under batch sharding: the score matrices of cons_loss span the GLOBAL batch (every rank
         # computes the same loss from gathered rows; dp.GatherRows), as one process at that batch would
         gather, _ = dp.global_rows(cfg)
@@ -190,8 +195,17 @@ class DLSAuto(nn.Module):
             # `output` and the activations of the fused levels have 2-4 readers in here (cons_loss, the level's Blocks,
             # two level kernels): one alias per reader, their gradients summed by one launch (ops.FanOut)
             use = ops.Fan(4, [output] + [a[-i - 1] for i in range(nl) for a in (act1, act2)])
-            rkl = scaled(ops.cons_loss_sum([(glob(use(output)), glob(rec_output))] +
-                                           [(glob(use(act1[-i - 1])), glob(use(act2[-i - 1]))) for i in range(nl)]))
+            pairs = ([(glob(use(output)), glob(rec_output))] +
+                     [(glob(use(act1[-i - 1])), glob(use(act2[-i - 1]))) for i in range(nl)])
+            if CONS_BESIDE and gather is None and output.is_cuda and ops.PRESORT_OK:   # (one capture for both passes)
+                # ... and nothing in the levels reads it: on a third stream beside the first level (and its backward at
+                # the head of the backward pass instead of between the levels' and the pyramids'); it meets the
+                # running loss behind the first level kernel, in the order it had: (cons + kl_0) + kl_1 + ...
+                with ops.fork_third():
+                    cons_beside = scaled(ops.cons_loss_sum(pairs))
+                rkl = None
+            else:
+                rkl = scaled(ops.cons_loss_sum(pairs))
         else:
             rkl = scaled(ops.cons_loss(glob(output), glob(rec_output)))
         last_sample = last_t = nxt = None
@@ -230,11 +244,18 @@ class DLSAuto(nn.Module):
                 more = i + 1 < len(self.layers)
                 if batched:
                     # the running loss rides through the level kernels (rkl <- rkl + klw inside the launch)
+                    if cons_beside is True:
+                        ops.join_third()                 # the sum made behind the previous level's kernel
+                        cons_beside = None
                     rkl_t = rkl if torch.is_tensor(rkl) else None
                     last_sample, output, rkl_new, q_n, p_n = ops.DlsLevelNext.apply(
                         res[2], res[0], use(a2), eps, lay_out, float(ew), float(cw), use(act1[-i - 2]) if more else None,
                         use(act2[-i - 2]) if more else None, rkl_t)
-                    rkl = rkl_new if rkl_t is not None else rkl + rkl_new
+                    rkl = rkl_new if rkl_t is not None or rkl is None else rkl + rkl_new
+                    if torch.is_tensor(cons_beside):
+                        with ops.fork_third():
+                            rkl = cons_beside + rkl
+                        cons_beside = True
                     nxt = (q_n, p_n) if more else None
                 else:
                     last_sample, output, klw = ops.DlsLevel.apply(res[2], res[0], a2, eps, lay_out, float(ew), float(cw))
@@ -251,6 +272,8 @@ class DLSAuto(nn.Module):
                 else:
                     last_sample = t_mean + a2                                                      # :3350
                 output = torch.nan_to_num(lay_out + last_sample)                                   # :3351
+        if cons_beside is True:
+            ops.join_third()
         if not restarted and not getattr(cfg, "ost", False):
             dens = self.density_term(output.shape[0])
             if dens:

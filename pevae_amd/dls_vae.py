@@ -192,6 +192,7 @@ class DLSVAE(nn.Module):
         # forward-time sorts of the lookups' ids (ops.PRESORT) fork a background stream that the lookup's backward joins:
         # not when forward and backward are captured into different HIP graphs (split_backward)
         ops.PRESORT_OK = not self.split_backward
+        ops.third_stream_reset()
         if self.training and self.config.dropout > 0:
             ops.rng_advance(self.x_embedding.weight.device)      # new dropout masks every step, also under graph replay
         prep_late = PREPARE_LATE and self.latent_stack == "dls"

@@ -327,6 +327,54 @@ class fork_side(object):
         return False
 
 
+class fork_third(object):
+    """Forward-time region on a THIRD stream, forked from the current one and joined by join_third() (and by every
+    join_side_work() of the step from then on: the region's autograd nodes run their backward there whenever the engine
+    reaches them).  For a short branch that must not queue behind what the side stream carries at that point (the
+    decoder half's preparation runs there beside the latent stack): DLS_Auto's batched consistency losses."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled) and torch.cuda.is_available()
+
+    def __enter__(self):
+        if not self.enabled:
+            return self
+        cur, st = _side_state()
+        if "stream3" not in st:
+            st["stream3"] = torch.cuda.Stream(device=cur.device)
+        if cur == st["stream3"]:
+            self.enabled = False
+            return self
+        st["stream3"].wait_stream(cur)
+        st["busy3"] = True
+        self.ctx = torch.cuda.stream(st["stream3"])
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_third():
+    """The current stream waits for what the third stream holds."""
+    if not _SIDE:
+        return
+    cur, st = _side_state()
+    if st.get("busy3") and cur != st["stream3"]:
+        cur.wait_stream(st["stream3"])
+
+
+def third_stream_reset():
+    """Head of a forward pass: no join waits for the third stream until a fork_third region has used it in this step
+    (a stream that was forked into a HIP-graph capture stays part of it, so waiting for it again is legal and free; one
+    that never joined this capture must not be waited for)."""
+    if _SIDE:
+        _cur, st = _side_state()
+        st["busy3"] = False
+
+
 def join_side_work():
     """Launch postponed side work, then make the current stream wait for the side streams (before a persistent kernel
     that needs every CU, and at the end of the backward pass)."""
@@ -351,6 +399,8 @@ def join_side_work():
     if st.get("busy2"):
         cur.wait_stream(st["stream2"])
         st["busy2"] = False
+    if st.get("busy3") and cur != st["stream3"]:
+        cur.wait_stream(st["stream3"])
     st["keep"] = []
 
 
