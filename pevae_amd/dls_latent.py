@@ -183,7 +183,7 @@ class DLSAuto(nn.Module):
         scaled = (lambda v: v) if cip == 1.0 else (lambda v: v * cip)     # cip_weight = 1 (the default): no launch
         batched = not restarted and not getattr(cfg, "ost", False) and all(
             a.shape[1] % 4 == 0 for a in list(act1) + [output]) and len(self.layers) < 7
-        use, cons_beside = (lambda t: t), None
+        use, cons_beside, held = (lambda t: t), None, None
         # config.global_negatives under batch sharding: the score matrices of cons_loss span the GLOBAL batch (every rank
         # computes the same loss from gathered rows; dp.GatherRows), as one process at that batch would
         gather, _ = dp.global_rows(cfg)
@@ -246,13 +246,14 @@ class DLSAuto(nn.Module):
                     # the running loss rides through the level kernels (rkl <- rkl + klw inside the launch)
                     if cons_beside is True:
                         ops.join_third()                 # the sum made behind the previous level's kernel
-                        cons_beside = None
+                        cons_beside = held = None
                     rkl_t = rkl if torch.is_tensor(rkl) else None
                     last_sample, output, rkl_new, q_n, p_n = ops.DlsLevelNext.apply(
                         res[2], res[0], use(a2), eps, lay_out, float(ew), float(cw), use(act1[-i - 2]) if more else None,
                         use(act2[-i - 2]) if more else None, rkl_t)
                     rkl = rkl_new if rkl_t is not None or rkl is None else rkl + rkl_new
                     if torch.is_tensor(cons_beside):
+                        held = rkl          # read on the third stream: its memory must not be handed out before the join
                         with ops.fork_third():
                             rkl = cons_beside + rkl
                         cons_beside = True
@@ -274,6 +275,7 @@ class DLSAuto(nn.Module):
                 output = torch.nan_to_num(lay_out + last_sample)                                   # :3351
         if cons_beside is True:
             ops.join_third()
+            held = None
         if not restarted and not getattr(cfg, "ost", False):
             dens = self.density_term(output.shape[0])
             if dens:
